@@ -1,0 +1,109 @@
+/* mte_kernels.h -- C ABI of libmte_hip.so, the gfx950 (MI355X) kernel library underneath mindtheedge_amd.
+ *
+ * The reference (liortalker/MindTheEdge) has no native code and no FFI: every op below replaces a PyTorch
+ * module call of the reference's hot path.  Each entry cites the reference call site it stands in for
+ * (paths relative to packnet_code/packnet_sfm/).  A maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless noted
+ *   - caller owns and pre-allocates every buffer (including scratch); no hidden allocation, no host sync;
+ *     kernels are enqueued on `stream` and are re-entrant
+ *   - return value: 0 = MTE_OK, negative = error (never throws):
+ *       -1 MTE_ERR_ARG  -2 MTE_ERR_LAUNCH  -3 MTE_ERR_UNSUPPORTED
+ *   - activations are NHWC ("pixel-major"): element (b,y,x,c) at ((b*H + y)*W + x)*ld + c, where `ld`
+ *     (elements per pixel) >= C lets a tensor be a channel slice of a wider buffer (decoder concat buffers)
+ *   - dtype: 0 = bf16 (raw 16-bit), 1 = fp32.  Channel counts / ld / slice offsets are multiples of 8
+ *   - loss maps are fp32 [B,H,W] (the reference's [B,1,H,W])
+ */
+#ifndef MTE_KERNELS_H
+#define MTE_KERNELS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
+
+#define MTE_OK 0
+#define MTE_ERR_ARG (-1)
+#define MTE_ERR_LAUNCH (-2)
+#define MTE_ERR_UNSUPPORTED (-3)
+#define MTE_DT_BF16 0
+#define MTE_DT_F32 1
+
+/* ---- convolution: nn.Conv2d(k, stride 1) + ConstantPad2d(k//2)  (networks/layers/packnet/layers01.py:29-31,61,116-117)
+ * y = conv(x, wpack) + bias.  wpack = [N][KH*KW][Cin_p] in `dtype` (see mte_pack_conv_weights).
+ * Also the data-gradient: call with the "backward" pack and x := dy. */
+int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
+                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
+/* weight gradient of the same conv: dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) */
+int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage,
+                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
+/* OIHW fp32 master weights -> forward pack [Cout][taps][Cin_p] and (optional) dgrad pack [Cin_p][taps rot180][Cout_p] */
+int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout, int Cin, int KH, int KW,
+                          int Cin_p, int Cout_p, int dtype, mte_stream_t stream);
+/* dw_stage -> OIHW fp32 gradient (drops channel padding) */
+int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, mte_stream_t stream);
+/* out[N] = column sums of y[M][N] (conv bias gradient) */
+int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, mte_stream_t stream);
+
+/* ---- GroupNorm(16, C) + ELU, optionally over y1 + scale2[b,c]*y2 (residual tail with Dropout2d)
+ *      (layers01.py:32-38 Conv2D; layers01.py:62-73 ResidualConv) */
+int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
+                 int B, int HW, int C, int dtype, mte_stream_t stream);
+int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, const double* stats,
+                   const float* gamma, const float* beta, void* z, long ldz,
+                   int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
+int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
+                   const double* stats, const float* gamma, const float* beta, float* red,
+                   void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta,
+                   int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
+
+/* ---- 3-D packing / unpacking stencils: packing + nn.Conv3d(1,4,3,pad 1) (+ view / PixelShuffle)
+ *      (layers01.py:127-149, 214-248 PackLayerConv3d; 251-287 UnpackLayerConv3d).  H,W,C describe x. */
+int mte_pack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, void* out, long ldo,
+                   int B, int H, int W, int C, int dtype, mte_stream_t stream);
+int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, long lddx,
+                        int B, int H, int W, int C, int dtype, mte_stream_t stream);
+int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
+                          int B, int H, int W, int C, int dtype, mte_stream_t stream);
+int mte_unpack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, void* out, long ldo,
+                     int B, int H, int W, int C, int dtype, mte_stream_t stream);
+int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, long lddx,
+                          int B, int H, int W, int C, int dtype, mte_stream_t stream);
+int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
+                            int B, int H, int W, int C, int dtype, mte_stream_t stream);
+
+/* ---- InvDepth head: sigmoid(conv3x3(x) + b) / min_depth  (layers01.py:99-123) */
+int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,
+                     int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);
+int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_out, const float* dout, float* dlogit_scratch,
+                     void* dx, long lddx, float* dwb, int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);
+
+/* ---- layout / wiring helpers (networks/depth/PackNetSAN01.py:92-143 cat + Upsample; models/model_utils.py:98-117 flip) */
+int mte_nchw_to_nhwc(const float* src, void* dst, long ldd, int B, int C, int H, int W, int Cp, int flip_w, int dtype, mte_stream_t stream);
+int mte_upsample_inv_fwd(const float* inv, void* dst, long ldd, int B, int h, int w, int dtype, mte_stream_t stream);
+int mte_upsample_inv_bwd(const void* dsrc, long lds_, float* dinv, int B, int h, int w, int accumulate, int dtype, mte_stream_t stream);
+int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix, int C, int dtype, mte_stream_t stream);
+
+/* ---- depth-edge loss: inv2depth + GradLayer + GradLoss('cross_entropy')
+ *      (utils/depth.py:104-121; losses/grad_loss.py:20-31,65-95,122-219) */
+int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal, const float* mask, double* sums, float* gmap,
+                      int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, mte_stream_t stream);
+int mte_edge_loss_finalize(const double* sums, int B, long numel, float weight, float pos_to_neg, int has_mask,
+                           float out_scale, float* loss_acc, float* loss_this, float* coef, mte_stream_t stream);
+int mte_edge_loss_bwd(const float* pred, const float* edge, const float* normal, const float* mask, const float* coef, const float* gout,
+                      float* dpred, int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, mte_stream_t stream);
+
+/* ---- silog supervised loss: depth2inv + sparse mask + SilogLoss (utils/depth.py:124-144; losses/supervised_loss.py:57-69,155-216) */
+int mte_silog_fwd(const float* inv, const float* depth, long n, double* sums, float out_scale, float* loss_acc, float* loss_this, float* aux, mte_stream_t stream);
+int mte_silog_bwd(const float* inv, const float* depth, const float* aux, const float* gout, float* dinv, long n, int accumulate, mte_stream_t stream);
+
+/* ---- optimizer: torch.optim.Adam step over a flat fp32 buffer (models/model_wrapper.py:142-180; trainers/common_trainer.py:125) */
+int mte_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  int step, float gscale, mte_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTE_KERNELS_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libmte_hip.so.  The prototypes are read from include/mte_kernels.h, which is the
+single source of truth for the C ABI.  There is NO fallback: if the library is missing or a kernel
+returns an error code the caller gets an exception."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "mte_kernels.h")
+LIB_PATH = os.path.join(_HERE, "csrc", "libmte_hip.so")
+
+_CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "mte_stream_t": ctypes.c_void_p}
+_ERRORS = {-1: "MTE_ERR_ARG (bad argument / unsupported shape)", -2: "MTE_ERR_LAUNCH (HIP launch failed)",
+           -3: "MTE_ERR_UNSUPPORTED"}
+
+
+class MteError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: [(ctype, argname), ...]} for every `int mte_*(...)` prototype."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(mte_\w+)\s*\(([^)]*)\)\s*;", text):
+        args = []
+        for a in m.group(2).split(","):
+            a = " ".join(a.split())
+            if "*" in a:
+                args.append((ctypes.c_void_p, a.split("*")[-1].strip()))
+            else:
+                ty, name = a.rsplit(" ", 1)
+                args.append((_CTYPES[ty.replace("const ", "").strip()], name))
+        protos[m.group(1)] = args
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self._protos = parse_header()
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise MteError("libmte_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `python mindtheedge_amd/_build.py`; there is no CPU/eager fallback." % LIB_PATH)
+            dll = ctypes.CDLL(LIB_PATH)
+            for name, args in self._protos.items():
+                fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
+                fn.argtypes = [t for t, _ in args]
+                fn.restype = ctypes.c_int
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        if name.startswith("mte_"):
+            fn = getattr(self.load(), name)
+
+            def call(*args):
+                rc = fn(*args)
+                if rc != 0:
+                    raise MteError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
+            return call
+        raise AttributeError(name)
+
+
+lib = _Lib()

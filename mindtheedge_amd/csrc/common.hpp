@@ -1,0 +1,96 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of mindtheedge_amd.
+// Wavefront = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MTE_OK 0
+#define MTE_ERR_ARG (-1)
+#define MTE_ERR_LAUNCH (-2)
+#define MTE_ERR_UNSUPPORTED (-3)
+
+#define MTE_DT_BF16 0
+#define MTE_DT_F32 1
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+    static constexpr int PER16 = 8;                      // elements per 16-byte chunk
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+template <> struct Elem<float> {
+    static constexpr int PER16 = 4;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+
+// 16-byte chunk <-> 8 floats (bf16) / 4 floats (f32).  Always fills/consumes v[0..PER16).
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& c, float* v);
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& c, float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(c[i] << 16);
+        v[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+    }
+}
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& c, float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(c[i]);
+}
+template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* v);
+template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* v) {
+    u32x4_t c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+    return c;
+}
+template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* v) {
+    u32x4_t c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(v[i]);
+    return c;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float elu1(float u) { return u > 0.f ? u : (__expf(u) - 1.f); }
+
+// XCD-aware bijective remap of a 1-D grid: blocks that share an XCD (bid % 8) get a contiguous
+// range of logical tile ids, so neighbouring tiles (shared halos / weight panels) hit one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+static inline int mte_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MTE_OK : MTE_ERR_LAUNCH;
+}
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,545 @@
+// Implicit-GEMM 2-D convolution (stride 1, zero pad k/2) for gfx950, NHWC activations.
+//
+//   forward / dgrad :  y[m][n] = bias[n] + sum_{tap,c} x[pix(m)+tap][c] * w[n][tap][c]
+//        GEMM view   :  M = B*H*W pixels, N = C_out, K = KH*KW*Cin_p   (dgrad = same kernel with the
+//                       180-degree-rotated, in/out-swapped weight pack produced by mte_pack_conv_weights)
+//   wgrad           :  dw[n][tap][c] = sum_m dy[m][n] * x[pix(m)+tap][c]   (reduction over pixels)
+//
+// Replaces the reference's nn.Conv2d + ConstantPad2d pairs (packnet_sfm/networks/layers/packnet/
+// layers01.py:29-31,61,116-117) and their autograd backward.  The pad is folded into the tile loader
+// (out-of-image taps load zeros), no padded copy is ever materialised.
+//
+// Data movement is expressed in 16-byte chunks so one template serves both element types:
+//   bf16 : chunk = 8 elements, v_mfma_f32_32x32x16_bf16  (one MFMA per 32 bytes of K per row)
+//   f32  : chunk = 4 elements, v_mfma_f32_32x32x2_f32 x4 (exact-fp32 validation mode, 1/16 rate)
+// Lane (r = lane&31, h = lane>>5) reads the 16-byte chunk (2*kk + h) of tile row r: for bf16 that is
+// k = 16*kk + 8*h + j (the native operand map); for f32 the four MFMAs take component i of both
+// operands, i.e. k = 8*kk + 4*h + i -- any k assignment is valid as long as A and B agree.
+//
+// Tile: 256 threads = 4 waves arranged WM x WN, each wave owns (TM*32) x (TN*32) outputs in fp32
+// accumulators; K step = 64 bytes per row; LDS double-buffered, register-staged (global loads of step
+// s+1 are in flight while step s computes).  LDS rows are 64 B; 16-B chunk c of row r is stored at chunk
+// slot c ^ ((r>>2)&3), which makes every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
+#include "common.hpp"
+
+namespace {
+
+struct ConvArgs {
+    const void* x; long ldx;        // input pixels, elements per pixel (>= Cin_p)
+    const void* w;                  // [N][taps][Cin_p] packed weights, same element type as x
+    const float* bias;              // [N] or null
+    void* y; long ldy; int out_f32; // output pixels
+    int B, H, W, Cin_p, N, KH, KW;
+    long M;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i]), __uint_as_float(b[i]), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 64 + ((kc ^ ((row >> 2) & 3)) << 4); }
+
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int PER16 = Elem<T>::PER16;
+    constexpr int A_CH = BM * 4 / 256;                 // 16-B chunks of the A tile per thread
+    constexpr int B_CH = (BN * 4 + 255) / 256;         // (BN = 32: only threads < 128 load)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                   // [2][BM*64]
+    char* sB = smem + 2 * BM * 64;                     // [2][BN*64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tiles_m = (int)((a.M + BM - 1) / BM);
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_n = id % tiles_n, tile_m = id / tiles_n;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int taps = a.KH * a.KW, pad_h = a.KH >> 1, pad_w = a.KW >> 1;
+    const int cpt = a.Cin_p / PER16;                   // chunks per tap
+    const int total_chunks = taps * cpt;
+    const int ksteps = (total_chunks + 3) >> 2;
+    const long Kp = (long)taps * a.Cin_p;
+    const T* __restrict__ xp = (const T*)a.x;
+    const T* __restrict__ wp = (const T*)a.w;
+
+    // ---- per-thread loader state: all chunks of a thread share kc = tid & 3
+    const int kc = tid & 3;
+    int c = kc, ty = 0, tx = 0;                        // chunk-in-tap, tap row/col of global chunk q = 4*s + kc
+    while (c >= cpt) { c -= cpt; if (++tx == a.KW) { tx = 0; ++ty; } }
+    long a_pix[A_CH]; int a_oy[A_CH], a_ox[A_CH]; bool a_ok[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int row = (tid + i * 256) >> 2;
+        const long m = m0 + row;
+        a_ok[i] = m < a.M;
+        const long mm = a_ok[i] ? m : 0;
+        const int hw = a.H * a.W;
+        const int b = (int)(mm / hw), rem = (int)(mm - (long)b * hw);
+        a_oy[i] = rem / a.W; a_ox[i] = rem - a_oy[i] * a.W;
+        a_pix[i] = mm;
+    }
+    u32x4_t ra[A_CH], rb[B_CH];
+
+    auto load_step = [&](int s) {
+        const bool tap_ok = ty < a.KH;
+        const int dy = ty - pad_h, dx = tx - pad_w;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+            const bool ok = a_ok[i] && tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (ok) v = *(const u32x4_t*)(xp + (a_pix[i] + (long)dy * a.W + dx) * a.ldx + c * PER16);
+            ra[i] = v;
+        }
+        const int q = 4 * s + kc;
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx >> 2, n = n0 + row;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (idx < BN * 4 && n < a.N && q < total_chunks) v = *(const u32x4_t*)(wp + (long)n * Kp + (long)q * PER16);
+            rb[i] = v;
+        }
+        // advance to global chunk q + 4
+        c += 4;
+        while (c >= cpt) { c -= cpt; if (++tx == a.KW) { tx = 0; ++ty; } }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int row = (tid + i * 256) >> 2;
+            *(u32x4_t*)(sA + buf * BM * 64 + lds_chunk_off(row, kc)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < BN * 4) *(u32x4_t*)(sB + buf * BN * 64 + lds_chunk_off(idx >> 2, kc)) = rb[i];
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < ksteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < ksteps) load_step(s + 1);
+        const char* pA = sA + buf * BM * 64;
+        const char* pB = sB + buf * BN * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(pA + lds_chunk_off((wm * TM + i) * 32 + r, 2 * kk + h));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(pB + lds_chunk_off((wn * TN + j) * 32 + r, 2 * kk + h));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        if (s + 1 < ksteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row][col]: col = lane&31 (channel n), row = (e&3) + 8*(e>>2) + 4*h (pixel m)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + r;
+        if (n >= a.N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < a.M) {
+                    const float v = acc[i][j][e] + bv;
+                    if (a.out_f32) ((float*)a.y)[m * a.ldy + n] = v;
+                    else Elem<T>::st((T*)a.y + m * a.ldy + n, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+int launch_igemm(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const size_t lds = 2 * (BM + BN) * 64;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+    return mte_check_launch();
+}
+
+template <typename T> int dispatch_igemm(const ConvArgs& a, hipStream_t st) {
+    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, st);       // 128 x 32
+    if (a.N <= 64 || (a.N % 128 != 0 && a.N < 128)) return launch_igemm<T, 2, 2, 2, 1>(a, st);   // 128 x 64
+    return launch_igemm<T, 2, 2, 2, 2>(a, st);                      // 128 x 128
+}
+
+// =====================================================================================================
+// wgrad: dw_stage[n][tap][c] (+)= sum_m dy[m][n] * x[pix(m)+tap][c]
+// One workgroup = (n tile, one tap, c tile, pixel split).  The reduction index (pixel) is the slow memory
+// dimension of both NHWC operands, so tiles are staged as [32 pixels][channels] and the MFMA operands
+// (8 consecutive k per lane) are fetched with the transposing LDS read ds_read_b64_tr_b16 (bf16) or with
+// plain 4-byte reads (f32 mode, one k per lane per MFMA).  Row strides are padded to an odd multiple of
+// 64 B so the four pixel rows a transposing read touches fall in different bank groups.
+// =====================================================================================================
+struct WgradArgs {
+    const void* x; long ldx;
+    const void* dy; long ldy;
+    float* dw;                      // [N][taps][Cin_p] fp32 staging (zeroed by caller when splits > 1)
+    int B, H, W, Cin_p, N, KH, KW;
+    long M;
+    int splits, blocks_per_split;   // pixel blocks of 32
+    int tiles_c, tiles_n;
+};
+
+template <int BYTES> __device__ __forceinline__ int padded_row(void) {
+    return (BYTES % 128 == 64) ? BYTES : BYTES + 64;
+}
+
+template <typename T, int WNO, int WC, int TNO, int TC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int BNO = WNO * TNO * 32, BC = WC * TC * 32;          // cout x cin tile
+    constexpr int PER16 = Elem<T>::PER16, ES = (int)sizeof(T);
+    constexpr int RS_Y = (BNO * ES % 128 == 64) ? BNO * ES : BNO * ES + 64;   // LDS row strides (bytes)
+    constexpr int RS_X = (BC * ES % 128 == 64) ? BC * ES : BC * ES + 64;
+    constexpr int KB = 32;                                             // pixels per step
+    constexpr int YCH = KB * BNO / PER16, XCH = KB * BC / PER16;       // chunks per tile
+    constexpr int YCT = (YCH + 255) / 256, XCT = (XCH + 255) / 256;
+    constexpr int YCPR = BNO / PER16, XCPR = BC / PER16;               // chunks per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sY = smem;                                    // [2][KB*RS_Y]
+    char* sX = smem + 2 * KB * RS_Y;                    // [2][KB*RS_X]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = blockIdx.x;
+    const int taps = a.KH * a.KW;
+    const int tile_c = id % a.tiles_c; id /= a.tiles_c;
+    const int tap = id % taps; id /= taps;
+    const int tile_n = id % a.tiles_n; id /= a.tiles_n;
+    const int split = id;
+    const int ty = tap / a.KW, tx = tap % a.KW;
+    const int dyo = ty - (a.KH >> 1), dxo = tx - (a.KW >> 1);
+    const int n0 = tile_n * BNO, c0 = tile_c * BC;
+    const T* __restrict__ xp = (const T*)a.x;
+    const T* __restrict__ yp = (const T*)a.dy;
+
+    const long nblk_total = (a.M + KB - 1) / KB;
+    const long blk0 = (long)split * a.blocks_per_split;
+    long blk1 = blk0 + a.blocks_per_split; if (blk1 > nblk_total) blk1 = nblk_total;
+
+    // loader state: per chunk slot the (row, chunk-in-row) is fixed; pixel coords advance by KB per step
+    int y_row[YCT], y_cc[YCT], x_row[XCT], x_cc[XCT];
+    int x_b[XCT], x_oy[XCT], x_ox[XCT];
+#pragma unroll
+    for (int i = 0; i < YCT; ++i) { const int idx = tid + i * 256; y_row[i] = idx / YCPR; y_cc[i] = idx % YCPR; }
+#pragma unroll
+    for (int i = 0; i < XCT; ++i) {
+        const int idx = tid + i * 256; x_row[i] = idx / XCPR; x_cc[i] = idx % XCPR;
+        const long m = blk0 * KB + x_row[i];
+        const int hw = a.H * a.W;
+        const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+        x_b[i] = b; x_oy[i] = rem / a.W; x_ox[i] = rem - x_oy[i] * a.W;
+    }
+    u32x4_t ry[YCT], rx[XCT];
+    auto load_step = [&](long blk) {
+#pragma unroll
+        for (int i = 0; i < YCT; ++i) {
+            const long m = blk * KB + y_row[i];
+            const int n = n0 + y_cc[i] * PER16;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if ((YCH % 256 == 0 || tid + i * 256 < YCH) && m < a.M && n < a.N) v = *(const u32x4_t*)(yp + m * a.ldy + n);
+            ry[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XCT; ++i) {
+            const int cc = c0 + x_cc[i] * PER16;
+            const int iy = x_oy[i] + dyo, ix = x_ox[i] + dxo;
+            const bool ok = (XCH % 256 == 0 || tid + i * 256 < XCH) && x_b[i] < a.B && cc < a.Cin_p &&
+                            (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (ok) v = *(const u32x4_t*)(xp + (((long)x_b[i] * a.H + iy) * a.W + ix) * a.ldx + cc);
+            rx[i] = v;
+            // advance this slot's pixel by KB
+            x_ox[i] += KB;
+            while (x_ox[i] >= a.W) { x_ox[i] -= a.W; if (++x_oy[i] == a.H) { x_oy[i] = 0; ++x_b[i]; } }
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < YCT; ++i)
+            if (YCH % 256 == 0 || tid + i * 256 < YCH) *(u32x4_t*)(sY + buf * KB * RS_Y + y_row[i] * RS_Y + y_cc[i] * 16) = ry[i];
+#pragma unroll
+        for (int i = 0; i < XCT; ++i)
+            if (XCH % 256 == 0 || tid + i * 256 < XCH) *(u32x4_t*)(sX + buf * KB * RS_X + x_row[i] * RS_X + x_cc[i] * 16) = rx[i];
+    };
+
+    f32x16_t acc[TNO][TC];
+#pragma unroll
+    for (int i = 0; i < TNO; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wno = wave / WC, wc = wave % WC;
+    const int r = lane & 31, h = lane >> 5;
+
+    if (blk0 < blk1) {
+        load_step(blk0);
+        store_step(0);
+        __syncthreads();
+        for (long blk = blk0; blk < blk1; ++blk) {
+            const int buf = (int)((blk - blk0) & 1);
+            if (blk + 1 < blk1) load_step(blk + 1);
+            const char* pY = sY + buf * KB * RS_Y;
+            const char* pX = sX + buf * KB * RS_X;
+            if constexpr (sizeof(T) == 2) {
+                // transposing read: 16-lane group g covers channels 16*(g&1).., pixels 8*(g>>1) + {0..3 | 4..7};
+                // lane 4q+p of the group supplies &tile[pixel base + q][channel base + 4p]
+                const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+                const int chb = 16 * (g & 1) + 4 * p, pxb = 8 * (g >> 1) + q;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {          // two k16 steps per 32-pixel block
+                    u32x4_t fy[TNO], fx[TC];
+#pragma unroll
+                    for (int i = 0; i < TNO; ++i) {
+                        const char* base = pY + (kk * 16 + pxb) * RS_Y + ((wno * TNO + i) * 32 + chb) * 2;
+                        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * RS_Y));
+                        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                        fy[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+                    }
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) {
+                        const char* base = pX + (kk * 16 + pxb) * RS_X + ((wc * TC + j) * 32 + chb) * 2;
+                        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * RS_X));
+                        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                        fx[j] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+                    }
+#pragma unroll
+                    for (int i = 0; i < TNO; ++i)
+#pragma unroll
+                        for (int j = 0; j < TC; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[i]),
+                                                                                __builtin_bit_cast(bf16x8_t, fx[j]), acc[i][j], 0, 0, 0);
+                }
+            } else {
+                // f32: one k (pixel) per lane-half per MFMA; lane (r,h) reads tile[pixel 2*k2 + h][channel r]
+#pragma unroll 4
+                for (int k2 = 0; k2 < KB / 2; ++k2) {
+                    float fy[TNO], fx[TC];
+#pragma unroll
+                    for (int i = 0; i < TNO; ++i) fy[i] = *(const float*)(pY + (2 * k2 + h) * RS_Y + ((wno * TNO + i) * 32 + r) * 4);
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) fx[j] = *(const float*)(pX + (2 * k2 + h) * RS_X + ((wc * TC + j) * 32 + r) * 4);
+#pragma unroll
+                    for (int i = 0; i < TNO; ++i)
+#pragma unroll
+                        for (int j = 0; j < TC; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fy[i], fx[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (blk + 1 < blk1) store_step(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: D[row = cout][col = cin]; col = lane&31 -> contiguous fp32 in the staging buffer
+    const long Kp = (long)taps * a.Cin_p;
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+        const int cc = c0 + (wc * TC + j) * 32 + r;
+        if (cc >= a.Cin_p) continue;
+#pragma unroll
+        for (int i = 0; i < TNO; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + (wno * TNO + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < a.N) {
+                    float* dst = a.dw + (long)n * Kp + (long)tap * a.Cin_p + cc;
+                    if (a.splits > 1) atomicAdd(dst, acc[i][j][e]);
+                    else *dst = acc[i][j][e];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int WNO, int WC, int TNO, int TC>
+int launch_wgrad(WgradArgs a, hipStream_t st) {
+    constexpr int BNO = WNO * TNO * 32, BC = WC * TC * 32, ES = (int)sizeof(T);
+    constexpr int RS_Y = (BNO * ES % 128 == 64) ? BNO * ES : BNO * ES + 64;
+    constexpr int RS_X = (BC * ES % 128 == 64) ? BC * ES : BC * ES + 64;
+    a.tiles_n = (a.N + BNO - 1) / BNO;
+    a.tiles_c = (a.Cin_p + BC - 1) / BC;
+    const int taps = a.KH * a.KW;
+    const long nblk = (a.M + 31) / 32;
+    const long base_wgs = (long)a.tiles_n * a.tiles_c * taps;
+    long splits = (1024 + base_wgs - 1) / base_wgs;            // aim for >= ~4 workgroups per CU
+    const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.blocks_per_split = (int)((nblk + splits - 1) / splits);
+    a.splits = (int)((nblk + a.blocks_per_split - 1) / a.blocks_per_split);
+    if (a.splits > 1) {
+        hipError_t e = hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st);
+        if (e != hipSuccess) return MTE_ERR_LAUNCH;
+    }
+    const size_t lds = 2 * 32 * (RS_Y + RS_X);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WNO, WC, TNO, TC>), dim3((unsigned)(base_wgs * a.splits)), dim3(256), lds, st, a);
+    return mte_check_launch();
+}
+
+template <typename T> int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
+    if (a.N <= 32) {
+        if (a.Cin_p <= 32) return launch_wgrad<T, 1, 4, 1, 1>(a, st);      // 32 x 128 would waste: 32 x (4*32)
+        return launch_wgrad<T, 1, 4, 1, 1>(a, st);                          // cout 32 x cin 128
+    }
+    if (a.N <= 64) return launch_wgrad<T, 2, 2, 1, 2>(a, st);              // cout 64 x cin 128
+    return launch_wgrad<T, 2, 2, 2, 2>(a, st);                              // cout 128 x cin 128
+}
+
+// ---- weight packing: OIHW fp32 master -> [N][taps][Cin_p] (forward) and [Cin_p8][taps flipped][Cout_p] (dgrad)
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
+                                    int Cout, int Cin, int KH, int KW, int Cin_p, int Cout_p) {
+    const int taps = KH * KW;
+    const long nf = (long)Cout * taps * Cin_p;
+    const long nb = wb ? (long)Cin_p * taps * Cout_p : 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nf + nb; i += (long)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            const int c = (int)(i % Cin_p); long t = i / Cin_p; const int tap = (int)(t % taps); const int n = (int)(t / taps);
+            const float v = c < Cin ? w[((long)n * Cin + c) * taps + tap] : 0.f;
+            Elem<T>::st(wf + i, v);
+        } else {
+            const long k = i - nf;
+            const int n = (int)(k % Cout_p); long t = k / Cout_p; const int tap = (int)(t % taps); const int c = (int)(t / taps);
+            // dgrad: dx[p][c] = sum_{tap', n} dy[p + tap' - pad][n] * w[n][c][taps-1-tap']
+            const float v = (c < Cin && n < Cout) ? w[((long)n * Cin + c) * taps + (taps - 1 - tap)] : 0.f;
+            Elem<T>::st(wb + k, v);
+        }
+    }
+}
+
+// staging [N][taps][Cin_p] fp32 -> OIHW fp32 gradient (overwrite)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ st, float* __restrict__ dw, int Cout, int Cin, int taps, int Cin_p) {
+    const long n = (long)Cout * Cin * taps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps); long t = i / taps; const int c = (int)(t % Cin); const int o = (int)(t / Cin);
+        dw[i] = st[((long)o * taps + tap) * Cin_p + c];
+    }
+}
+
+// column sums of a [M][N] (row stride ld) matrix: bias gradient
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, long ld, long M, int N, float* __restrict__ out) {
+    // block handles a slab of rows; thread t owns column (t % NC) of a 16-B chunk group
+    constexpr int PER16 = Elem<T>::PER16;
+    const int cpr = N / PER16;                       // chunks per row (N multiple of PER16)
+    const int tid = threadIdx.x;
+    float acc[PER16];
+#pragma unroll
+    for (int i = 0; i < PER16; ++i) acc[i] = 0.f;
+    const int cc = tid % cpr;                        // requires cpr <= 256 and 256 % cpr == 0 or we guard
+    const int rlane = tid / cpr, rstep = 256 / cpr;
+    if (rlane < rstep) {
+        for (long m = (long)blockIdx.x * rstep + rlane; m < M; m += (long)gridDim.x * rstep) {
+            float v[PER16];
+            unpack16<T>(*(const u32x4_t*)(y + m * ld + cc * PER16), v);
+#pragma unroll
+            for (int i = 0; i < PER16; ++i) acc[i] += v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PER16; ++i) atomicAdd(out + cc * PER16 + i, acc[i]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// y[B,H,W,(ldy)] = conv(x[B,H,W,(ldx)], wpack[N][KH*KW][Cin_p]) + bias; stride 1, zero pad k/2.
+int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
+                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, hipStream_t stream) {
+    if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W};
+    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, stream);
+    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, stream);
+    return MTE_ERR_UNSUPPORTED;
+}
+
+// dw_stage[N][KH*KW][Cin_p] (fp32) = sum over pixels of dy (x) shifted x.
+int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage,
+                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, hipStream_t stream) {
+    if (!x || !dy || !dw_stage) return MTE_ERR_ARG;
+    if (Cin_p % 8 != 0 || N % 8 != 0) return MTE_ERR_ARG;
+    WgradArgs a{x, ldx, dy, ldy, dw_stage, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, 0, 0, 0};
+    if (dtype == MTE_DT_BF16) return dispatch_wgrad<bf16_t>(a, stream);
+    if (dtype == MTE_DT_F32) return dispatch_wgrad<float>(a, stream);
+    return MTE_ERR_UNSUPPORTED;
+}
+
+int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout, int Cin, int KH, int KW,
+                          int Cin_p, int Cout_p, int dtype, hipStream_t stream) {
+    if (!w_oihw || !wfwd) return MTE_ERR_ARG;
+    const long n = (long)Cout * KH * KW * Cin_p + (wbwd ? (long)Cin_p * KH * KW * Cout_p : 0);
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (dtype == MTE_DT_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, w_oihw, (bf16_t*)wfwd, (bf16_t*)wbwd, Cout, Cin, KH, KW, Cin_p, Cout_p);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, stream, w_oihw, (float*)wfwd, (float*)wbwd, Cout, Cin, KH, KW, Cin_p, Cout_p);
+    return mte_check_launch();
+}
+
+int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, hipStream_t stream) {
+    if (!dw_stage || !dw_oihw) return MTE_ERR_ARG;
+    const long n = (long)Cout * Cin * KH * KW;
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, stream, dw_stage, dw_oihw, Cout, Cin, KH * KW, Cin_p);
+    return mte_check_launch();
+}
+
+// out[N] (fp32, zeroed here) = column sums of y[M][N] (bias gradient). N multiple of 8, N/8 must divide 256 or be <= 256.
+int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, hipStream_t stream) {
+    if (!y || !out || N % 8 != 0) return MTE_ERR_ARG;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (N / per16 > 256) return MTE_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(out, 0, sizeof(float) * N, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    const int rstep = 256 / (N / per16);
+    long want = (M + rstep - 1) / rstep;
+    const int grid = (int)(want > 1024 ? 1024 : (want < 1 ? 1 : want));
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)y, ld, M, N, out);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)y, ld, M, N, out);
+    return mte_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+// Small HBM-bound kernels around the conv stack (gfx950, NHWC activations):
+//   * InvDepth head: sigmoid(conv3x3(x, C->1) + b) / 0.5 and its backward   (layers01.py:99-123)
+//   * NCHW fp32 image -> NHWC compute-dtype tensor with zero channel padding (+ optional horizontal flip,
+//     SfmModel.py:58-96 / model_utils.py:98-117)
+//   * nearest x2 up-sampling of an inv-depth map into one channel block of a decoder concat buffer
+//     (PackNetSAN01.py:92-94,118-143) and its backward
+//   * channel-slice copy (skip connections into concat buffers)
+//   * fused Adam step over the flat fp32 master-parameter buffer (model_wrapper.py:142-180: Adam, wd 0)
+#include "common.hpp"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* v);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float* v) { unpack16<bf16_t>(*(const u32x4_t*)p, v); }
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float* v) {
+    unpack16<float>(*(const u32x4_t*)p, v); unpack16<float>(*(const u32x4_t*)(p + 4), v + 4);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* v);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float* v) { *(u32x4_t*)p = pack16<bf16_t>(v); }
+template <> __device__ __forceinline__ void st8<float>(float* p, const float* v) {
+    *(u32x4_t*)p = pack16<float>(v); *(u32x4_t*)(p + 4) = pack16<float>(v + 4);
+}
+
+struct HeadArgs {
+    const void* x; long ldx;
+    const float* w; const float* bias;      // w: [C][3][3] (OIHW with O = 1), bias [1]
+    float* out;                             // [B,H,W] inv-depth
+    const float* dlogit;                    // [B,H,W]
+    void* dx; long lddx;
+    float* dw;                              // [C*9 + 1] (dw then db), atomically accumulated
+    int B, H, W, C;
+    float inv_min_depth;                    // 1 / min_depth = 2
+    long npix;
+};
+
+// thread = (pixel, 8-channel block); the C/8 lanes of a pixel are adjacent lanes of one wave
+template <typename T>
+__global__ __launch_bounds__(256) void invdepth_fwd_kernel(HeadArgs a) {
+    const int cb = a.C >> 3;
+    const int j = threadIdx.x % cb;
+    const int c0 = j * 8;
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wr[t][i] = a.w[(c0 + i) * 9 + t];
+    const float bias = a.bias[0];
+    const long ppb = 256 / cb;                                  // pixels per block iteration
+    const long iters = (a.npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
+    for (long it = 0; it < iters; ++it) {
+        const long pixl = (it * gridDim.x + blockIdx.x) * ppb + threadIdx.x / cb;
+        const bool live = pixl < a.npix;
+        const long pix = live ? pixl : a.npix - 1;
+        const int x = (int)(pix % a.W); const long t2 = pix / a.W; const int y = (int)(t2 % a.H);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+                float v[8];
+                ld8<T>((const T*)a.x + (pix + (long)(t / 3 - 1) * a.W + (t % 3 - 1)) * a.ldx + c0, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc = fmaf(v[i], wr[t][i], acc);
+            }
+        }
+        for (int o = cb >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (live && j == 0) a.out[pix] = a.inv_min_depth / (1.f + __expf(-(acc + bias)));
+    }
+}
+
+// dlogit = dout * d(inv)/d(logit), inv = s/(1+e^-z) with s = 1/min_depth: d inv / dz = inv * (1 - inv/s)
+__global__ void invdepth_dlogit_kernel(const float* __restrict__ dout, const float* __restrict__ inv, float* __restrict__ dl, long n, float s) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = inv[i];
+        dl[i] = dout[i] * v * (1.f - v / s);
+    }
+}
+
+// dx[p][c] = sum_t dlogit[p - t] * w[c][t];  dw[c][t] += sum_p dlogit[p] * x[p + t][c];  db += sum_p dlogit[p]
+template <typename T>
+__global__ __launch_bounds__(256) void invdepth_bwd_kernel(HeadArgs a) {
+    extern __shared__ float sdw[];                               // [C*9 + 1]
+    for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) sdw[i] = 0.f;
+    __syncthreads();
+    const int cb = a.C >> 3;
+    const int j = threadIdx.x % cb;
+    const int c0 = j * 8;
+    float wr[9][8], gw[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wr[t][i] = a.w[(c0 + i) * 9 + t]; gw[t][i] = 0.f; }
+    float gb = 0.f;
+    const long ppb = 256 / cb;
+    const long iters = (a.npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
+    for (long it = 0; it < iters; ++it) {
+        const long pix = (it * gridDim.x + blockIdx.x) * ppb + threadIdx.x / cb;
+        if (pix >= a.npix) continue;
+        const int x = (int)(pix % a.W); const long t2 = pix / a.W; const int y = (int)(t2 % a.H);
+        const float dl0 = a.dlogit[pix];
+        if (j == 0) gb += dl0;
+        float dxv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dxv[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int oy = t / 3 - 1, ox = t % 3 - 1;
+            // weight gradient: x at p + t
+            if ((unsigned)(y + oy) < (unsigned)a.H && (unsigned)(x + ox) < (unsigned)a.W) {
+                float v[8];
+                ld8<T>((const T*)a.x + (pix + (long)oy * a.W + ox) * a.ldx + c0, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(dl0, v[i], gw[t][i]);
+            }
+            // data gradient: dlogit at p - t
+            if ((unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W) {
+                const float dl = a.dlogit[pix - (long)oy * a.W - ox];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dxv[i] = fmaf(dl, wr[t][i], dxv[i]);
+            }
+        }
+        st8<T>((T*)a.dx + pix * a.lddx + c0, dxv);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&sdw[(c0 + i) * 9 + t], gw[t][i]);
+    if (j == 0) atomicAdd(&sdw[a.C * 9], gb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) atomicAdd(&a.dw[i], sdw[i]);
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W, int Cp, long ldd, int flip) {
+    const long npix = (long)B * H * W;
+    for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % W); const long t = pix / W; const int y = (int)(t % H); const int b = (int)(t / H);
+        const int sx = flip ? W - 1 - x : x;
+        for (int c0 = 0; c0 < Cp; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (c0 + i < C) ? src[(((long)b * C + c0 + i) * H + y) * W + sx] : 0.f;
+            st8<T>(dst + pix * ldd + c0, v);
+        }
+    }
+}
+
+// dst[b, 2h+dy, 2w+dx, 0..7] = (inv[b,h,w], 0, ..., 0)
+template <typename T>
+__global__ void upsample_inv_kernel(const float* __restrict__ inv, T* __restrict__ dst, long ldd, int B, int h, int w) {
+    const long n = (long)B * 4 * h * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % (2 * w)); const long t = i / (2 * w); const int Y = (int)(t % (2 * h)); const int b = (int)(t / (2 * h));
+        float v[8] = {inv[((long)b * h + (Y >> 1)) * w + (X >> 1)], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        st8<T>(dst + i * ldd, v);
+    }
+}
+template <typename T>
+__global__ void upsample_inv_bwd_kernel(const T* __restrict__ dsrc, long lds_, float* __restrict__ dinv, int B, int h, int w, int accumulate) {
+    const long n = (long)B * h * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w); const long t = i / w; const int y = (int)(t % h); const int b = (int)(t / h);
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            s += Elem<T>::ld(dsrc + (((long)b * 2 * h + 2 * y + (d >> 1)) * (2 * w) + 2 * x + (d & 1)) * lds_);
+        dinv[i] = accumulate ? dinv[i] + s : s;
+    }
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long npix, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P;
+    const long n = npix * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cpr; const int cc = (int)(i % cpr);
+        *(u32x4_t*)(dst + pix * ldd + cc * P) = *(const u32x4_t*)(src + pix * lds_ + cc * P);
+    }
+}
+
+// torch.optim.Adam semantics (no weight decay, no amsgrad): bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t) from the host
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4_t pp = ((f32x4_t*)p)[i], gg = ((const f32x4_t*)g)[i], mm = ((f32x4_t*)m)[i], vv = ((f32x4_t*)v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gscale;
+            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) / bc2s + eps;
+            pp[k] -= (lr / bc1) * (mm[k] / denom);
+        }
+        ((f32x4_t*)p)[i] = pp; ((f32x4_t*)m)[i] = mm; ((f32x4_t*)v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float gk = g[i] * gscale;
+        const float mk = b1 * m[i] + (1.f - b1) * gk, vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        m[i] = mk; v[i] = vk;
+        p[i] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2s + eps));
+    }
+}
+
+inline int stream_grid(long n, int per = 256) { long g = (n + per - 1) / per; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+inline bool head_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <= 64 && (cb & (cb - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,
+                     int B, int H, int W, int C, float min_depth, int dtype, hipStream_t stream) {
+    if (!x || !w || !bias || !out || !head_ok(C)) return MTE_ERR_ARG;
+    HeadArgs a{}; a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.inv_min_depth = 1.f / min_depth; a.npix = (long)B * H * W;
+    const int ppb = 256 / (C / 8);
+    const int grid = stream_grid(a.npix, ppb * 4);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(invdepth_fwd_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
+    return mte_check_launch();
+}
+
+// dlogit_scratch [B*H*W] fp32; dwb [C*9 + 1] fp32 (zeroed here): dw (OIHW order, O = 1) followed by db
+int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_out, const float* dout, float* dlogit_scratch,
+                     void* dx, long lddx, float* dwb, int B, int H, int W, int C, float min_depth, int dtype, hipStream_t stream) {
+    if (!x || !w || !inv_out || !dout || !dlogit_scratch || !dx || !dwb || !head_ok(C)) return MTE_ERR_ARG;
+    const long npix = (long)B * H * W;
+    if (hipMemsetAsync(dwb, 0, sizeof(float) * (C * 9 + 1), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    hipLaunchKernelGGL(invdepth_dlogit_kernel, dim3(stream_grid(npix)), dim3(256), 0, stream, dout, inv_out, dlogit_scratch, npix, 1.f / min_depth);
+    HeadArgs a{}; a.x = x; a.ldx = ldx; a.w = w; a.dlogit = dlogit_scratch; a.dx = dx; a.lddx = lddx; a.dw = dwb;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
+    const int ppb = 256 / (C / 8);
+    long g = (npix + ppb * 16 - 1) / (ppb * 16); if (g > 2048) g = 2048; if (g < 1) g = 1;
+    const size_t lds = sizeof(float) * (C * 9 + 1);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(invdepth_bwd_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, a);
+    return mte_check_launch();
+}
+
+int mte_nchw_to_nhwc(const float* src, void* dst, long ldd, int B, int C, int H, int W, int Cp, int flip_w, int dtype, hipStream_t stream) {
+    if (!src || !dst || Cp % 8 != 0 || Cp < C) return MTE_ERR_ARG;
+    const int grid = stream_grid((long)B * H * W);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, src, (bf16_t*)dst, B, C, H, W, Cp, ldd, flip_w);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, stream, src, (float*)dst, B, C, H, W, Cp, ldd, flip_w);
+    return mte_check_launch();
+}
+
+int mte_upsample_inv_fwd(const float* inv, void* dst, long ldd, int B, int h, int w, int dtype, hipStream_t stream) {
+    if (!inv || !dst) return MTE_ERR_ARG;
+    const int grid = stream_grid((long)B * 4 * h * w);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(upsample_inv_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, inv, (bf16_t*)dst, ldd, B, h, w);
+    else hipLaunchKernelGGL(upsample_inv_kernel<float>, dim3(grid), dim3(256), 0, stream, inv, (float*)dst, ldd, B, h, w);
+    return mte_check_launch();
+}
+int mte_upsample_inv_bwd(const void* dsrc, long lds_, float* dinv, int B, int h, int w, int accumulate, int dtype, hipStream_t stream) {
+    if (!dsrc || !dinv) return MTE_ERR_ARG;
+    const int grid = stream_grid((long)B * h * w);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(upsample_inv_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dsrc, lds_, dinv, B, h, w, accumulate);
+    else hipLaunchKernelGGL(upsample_inv_bwd_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)dsrc, lds_, dinv, B, h, w, accumulate);
+    return mte_check_launch();
+}
+
+int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix, int C, int dtype, hipStream_t stream) {
+    if (!src || !dst || C % 8 != 0) return MTE_ERR_ARG;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    const int grid = stream_grid(npix * (C / per16));
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, npix, C);
+    else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)src, lds_, (float*)dst, ldd, npix, C);
+    return mte_check_launch();
+}
+
+// In-place Adam over flat fp32 buffers (16-byte aligned).  step >= 1.  gscale multiplies the gradient first
+// (1/world_size when the all-reduce summed instead of averaged; 1 otherwise).
+int mte_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  int step, float gscale, hipStream_t stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return MTE_ERR_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2), gscale);
+    return mte_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+// GroupNorm(16, C) + ELU (and the residual-sum / Dropout2d variants) for NHWC activations, gfx950.
+//
+//   forward : z = ELU( gamma_c * (v - mean_{b,g}) * rstd_{b,g} + beta_c ),  v = y1 + scale2[b,c] * y2
+//   Replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace) of Conv2D (layers01.py:32-38) and the
+//   residual tail ELU(GN(x_out + Dropout2d(conv1x1(x)))) of ResidualConv (layers01.py:62-73); scale2 is
+//   the per-(sample, channel) Dropout2d factor keep/(1-p) (null = no second input scaling).
+//
+// All kernels are HBM-bound streams: a thread owns one 16-byte channel chunk (8 bf16 / 4 f32 channels)
+// and walks pixels, so every wave instruction moves 1 KiB of contiguous NHWC bytes; statistics
+// accumulate in fp32 per thread, are combined per block through LDS and leave the block as one
+// double-precision atomic per (sample, group) -- GroupNorm statistics are per sample, so there is no
+// cross-GPU reduction anywhere in this file.
+#include "common.hpp"
+
+namespace {
+
+constexpr int GN_GROUPS = 16;
+
+struct GnArgs {
+    const void* y1; long ld1;
+    const void* y2; long ld2;          // nullable
+    const float* scale2;               // [B][C] or null
+    double* stats;                     // [B][16][2] (sum, sumsq)
+    const float* gamma; const float* beta;
+    void* z; long ldz;                 // forward output
+    const void* dz; long lddz;         // backward input
+    float* red;                        // [B][C][2]  (sum dyhat, sum dyhat*xhat)
+    void* d1; long ldd1;               // backward outputs
+    void* d2; long ldd2;
+    int B, HW, C;
+    float eps;
+    int blocks_per_sample;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_v(const GnArgs& a, long pix, int b, int ch0, float* v) {
+    constexpr int P = Elem<T>::PER16;
+    unpack16<T>(*(const u32x4_t*)((const T*)a.y1 + pix * a.ld1 + ch0), v);
+    if (a.y2) {
+        float w[P];
+        unpack16<T>(*(const u32x4_t*)((const T*)a.y2 + pix * a.ld2 + ch0), w);
+        if (a.scale2) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] += w[i] * a.scale2[(long)b * a.C + ch0 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] += w[i];
+        }
+    }
+}
+
+// thread -> (chunk column cc, pixel lane prow); block -> (pixel range of one sample)
+#define GN_THREAD_MAP()                                                            \
+    constexpr int P = Elem<T>::PER16;                                              \
+    const int cpr = a.C / P;                                                       \
+    const int cc = threadIdx.x % cpr, prow = threadIdx.x / cpr, rstep = 256 / cpr; \
+    const int b = blockIdx.y;                                                      \
+    const int ch0 = cc * P;                                                        \
+    const int per_blk = (a.HW + a.blocks_per_sample - 1) / a.blocks_per_sample;    \
+    const int p_begin = blockIdx.x * per_blk;                                      \
+    const int p_end = min(a.HW, p_begin + per_blk);                                \
+    const int gs = a.C / GN_GROUPS;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
+    GN_THREAD_MAP();
+    __shared__ float s_acc[GN_GROUPS * 2];
+    if (threadIdx.x < GN_GROUPS * 2) s_acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    float s[P], q[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    for (int p = p_begin + prow; p < p_end; p += rstep) {
+        float v[P];
+        load_v<T>(a, (long)b * a.HW + p, b, ch0, v);
+#pragma unroll
+        for (int i = 0; i < P; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
+    }
+    // combine channels of the same group held by this thread, then LDS atomics
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int g = (ch0 + i) / gs;
+        const bool last = (i == P - 1) || ((ch0 + i + 1) / gs != g);
+        if (!last) { s[i + 1 < P ? i + 1 : i] += s[i]; q[i + 1 < P ? i + 1 : i] += q[i]; }
+        else { atomicAdd(&s_acc[2 * g], s[i]); atomicAdd(&s_acc[2 * g + 1], q[i]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < GN_GROUPS * 2) atomicAdd(&a.stats[(long)b * GN_GROUPS * 2 + threadIdx.x], (double)s_acc[threadIdx.x]);
+}
+
+__device__ __forceinline__ void group_mean_rstd(const GnArgs& a, int b, int g, int gs, float& mean, float& rstd) {
+    const double n = (double)a.HW * gs;
+    const double S = a.stats[((long)b * GN_GROUPS + g) * 2], Q = a.stats[((long)b * GN_GROUPS + g) * 2 + 1];
+    const double m = S / n;
+    double var = Q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_elu_fwd_kernel(GnArgs a) {
+    GN_THREAD_MAP();
+    float ka[P], kb[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        float mean, rstd;
+        group_mean_rstd(a, b, (ch0 + i) / gs, gs, mean, rstd);
+        const float gm = a.gamma[ch0 + i];
+        ka[i] = rstd * gm;
+        kb[i] = a.beta[ch0 + i] - mean * rstd * gm;
+    }
+    for (int p = p_begin + prow; p < p_end; p += rstep) {
+        const long pix = (long)b * a.HW + p;
+        float v[P];
+        load_v<T>(a, pix, b, ch0, v);
+#pragma unroll
+        for (int i = 0; i < P; ++i) v[i] = elu1(fmaf(v[i], ka[i], kb[i]));
+        *(u32x4_t*)((T*)a.z + pix * a.ldz + ch0) = pack16<T>(v);
+    }
+}
+
+// pass 1 of the backward: red[b][c] = (sum_px dyhat, sum_px dyhat * xhat), dyhat = dz * elu'(u)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
+    GN_THREAD_MAP();
+    extern __shared__ float s_red[];                      // [C][2]
+    for (int i = threadIdx.x; i < a.C * 2; i += 256) s_red[i] = 0.f;
+    __syncthreads();
+    float mean[P], rstd[P], gm[P], bt[P], r1[P], r2[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        group_mean_rstd(a, b, (ch0 + i) / gs, gs, mean[i], rstd[i]);
+        gm[i] = a.gamma[ch0 + i]; bt[i] = a.beta[ch0 + i];
+        r1[i] = 0.f; r2[i] = 0.f;
+    }
+    for (int p = p_begin + prow; p < p_end; p += rstep) {
+        const long pix = (long)b * a.HW + p;
+        float v[P], g[P];
+        load_v<T>(a, pix, b, ch0, v);
+        unpack16<T>(*(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0), g);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float xh = (v[i] - mean[i]) * rstd[i];
+            const float u = fmaf(xh, gm[i], bt[i]);
+            const float dyh = g[i] * (u > 0.f ? 1.f : __expf(u));
+            r1[i] += dyh; r2[i] = fmaf(dyh, xh, r2[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) { atomicAdd(&s_red[2 * (ch0 + i)], r1[i]); atomicAdd(&s_red[2 * (ch0 + i) + 1], r2[i]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.C * 2; i += 256) atomicAdd(&a.red[(long)b * a.C * 2 + i], s_red[i]);
+}
+
+// pass 2: dv = rstd * (dyhat*gamma - (S1 + xhat*S2)/n), S1 = sum_{c in g} gamma_c r1, S2 = sum gamma_c r2
+template <typename T>
+__global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
+    GN_THREAD_MAP();
+    float mean[P], rstd[P], gm[P], bt[P], s1[P], s2[P], sc[P];
+    const float inv_n = 1.f / ((float)a.HW * gs);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int g = (ch0 + i) / gs;
+        group_mean_rstd(a, b, g, gs, mean[i], rstd[i]);
+        gm[i] = a.gamma[ch0 + i]; bt[i] = a.beta[ch0 + i];
+        sc[i] = (a.y2 && a.scale2) ? a.scale2[(long)b * a.C + ch0 + i] : 1.f;
+        if (i > 0 && (ch0 + i - 1) / gs == g) { s1[i] = s1[i - 1]; s2[i] = s2[i - 1]; }
+        else {
+            float t1 = 0.f, t2 = 0.f;
+            for (int c = g * gs; c < (g + 1) * gs; ++c) {
+                const float gc = a.gamma[c];
+                t1 = fmaf(gc, a.red[((long)b * a.C + c) * 2], t1);
+                t2 = fmaf(gc, a.red[((long)b * a.C + c) * 2 + 1], t2);
+            }
+            s1[i] = t1 * inv_n; s2[i] = t2 * inv_n;
+        }
+    }
+    for (int p = p_begin + prow; p < p_end; p += rstep) {
+        const long pix = (long)b * a.HW + p;
+        float v[P], g[P];
+        load_v<T>(a, pix, b, ch0, v);
+        unpack16<T>(*(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0), g);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float xh = (v[i] - mean[i]) * rstd[i];
+            const float u = fmaf(xh, gm[i], bt[i]);
+            const float dyh = g[i] * (u > 0.f ? 1.f : __expf(u));
+            v[i] = rstd[i] * (dyh * gm[i] - (s1[i] + xh * s2[i]));
+        }
+        *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
+        if (a.d2) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] *= sc[i];
+            *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
+        }
+    }
+}
+
+__global__ void gn_param_grad_kernel(const float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, bt = 0.f;
+    for (int b = 0; b < B; ++b) { bt += red[((long)b * C + c) * 2]; g += red[((long)b * C + c) * 2 + 1]; }
+    dgamma[c] = g; dbeta[c] = bt;
+}
+
+int gn_blocks(int B, int HW, int rstep) {
+    // ~8 workgroups per CU across the batch, at least 32 pixels per thread row
+    long want = (2048 + B - 1) / B;
+    long maxb = ((long)HW + 32L * rstep - 1) / (32L * rstep);
+    if (want > maxb) want = maxb;
+    return (int)(want < 1 ? 1 : want);
+}
+
+bool gn_shape_ok(int C, int dtype) {
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (C % GN_GROUPS != 0 || C % per16 != 0) return false;
+    const int cpr = C / per16;
+    return cpr <= 256 && 256 % cpr == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// stats[B][16][2] (double; zeroed here) <- per-(sample, group) sum and sum of squares of v = y1 + scale2*y2
+int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
+                 int B, int HW, int C, int dtype, hipStream_t stream) {
+    if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));
+    dim3 grid(a.blocks_per_sample, B);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, stream, a);
+    return mte_check_launch();
+}
+
+int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, const double* stats,
+                   const float* gamma, const float* beta, void* z, long ldz,
+                   int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
+    if (!y1 || !stats || !gamma || !beta || !z || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
+    GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
+    a.gamma = gamma; a.beta = beta; a.z = z; a.ldz = ldz; a.B = B; a.HW = HW; a.C = C; a.eps = eps;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));
+    dim3 grid(a.blocks_per_sample, B);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(gn_elu_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gn_elu_fwd_kernel<float>, grid, dim3(256), 0, stream, a);
+    return mte_check_launch();
+}
+
+// Backward of z = ELU(GN(y1 + scale2*y2)).  red[B][C][2] is scratch (zeroed here).  Writes d1 (grad of y1),
+// optionally d2 (grad of y2 = scale2 * d1), and dgamma/dbeta [C] (overwritten).
+int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
+                   const double* stats, const float* gamma, const float* beta, float* red,
+                   void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta,
+                   int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
+    if (!dz || !y1 || !stats || !gamma || !beta || !red || !d1 || !dgamma || !dbeta || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
+    if (hipMemsetAsync(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
+    a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;
+    a.B = B; a.HW = HW; a.C = C; a.eps = eps;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));
+    dim3 grid(a.blocks_per_sample, B);
+    const size_t lds = sizeof(float) * C * 2;
+    if (dtype == MTE_DT_BF16) {
+        hipLaunchKernelGGL(gn_elu_bwd_reduce_kernel<bf16_t>, grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(gn_elu_bwd_reduce_kernel<float>, grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<float>, grid, dim3(256), 0, stream, a);
+    }
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, B, C);
+    return mte_check_launch();
+}
+
+}  // extern "C"

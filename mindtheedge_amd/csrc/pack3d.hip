@@ -1,0 +1,459 @@
+// 3-D packing / unpacking stencils for gfx950 (NHWC activations).
+//
+// PackLayerConv3d  (layers01.py:214-248): x[B,C,H,W] -> pixel-unshuffle(2) -> Conv3d(1->4, 3x3x3, pad 1) over
+//   (packed channel d = 4c + 2*dy + dx, H/2, W/2) -> view [B, 16C, H/2, W/2] with channel = f*4C + d.
+// UnpackLayerConv3d (layers01.py:251-287): x[B,C,H,W] -> Conv3d(1->4) over (c, H, W) -> channel q = f*C + c
+//   -> PixelShuffle(2): out[b, q>>2, 2h + ((q&3)>>1), 2w + (q&1)].
+// The space-to-depth / depth-to-space permutes are folded into the stencil's addressing, so neither the
+// packed tensor nor the un-shuffled 4C tensor ever exists in HBM.
+//
+// Work split: one thread = one (volume pixel, block of 8 NHWC channels).  Lanes of one pixel are adjacent
+// (C/8 is a power of two <= 64), so the +-1 neighbours along the conv3d "depth" axis come from the
+// adjacent lane by a wave shuffle instead of a second, unaligned load.  27-tap fp32 FMA stencil; the 108
+// weights + 4 biases are wave-uniform scalar loads.  These kernels move 2..10 bytes per 27 FMAs: they sit
+// between the HBM and the fp32-VALU roofs, not on MFMA (N = 4 features cannot fill a matrix tile).
+#include "common.hpp"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) { unpack16<bf16_t>(*(const u32x4_t*)p, v); }
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+    unpack16<float>(*(const u32x4_t*)p, v); unpack16<float>(*(const u32x4_t*)(p + 4), v + 4);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) { *(u32x4_t*)p = pack16<bf16_t>(v); }
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v) {
+    *(u32x4_t*)p = pack16<float>(v); *(u32x4_t*)(p + 4) = pack16<float>(v + 4);
+}
+
+struct P3Args {
+    const void* x; long ldx;       // un-packed side  [B,H,W,C]      (pack: input;  unpack: input of conv3d)
+    const void* o; long ldo;       // feature side    pack: [B,H/2,W/2,16C]; unpack: [B,2H,2W,C] (after shuffle)
+    void* dst; long lddst;         // output of this launch
+    const float* w3; const float* b3;   // [4][3][3][3], [4]
+    float* dw3; float* db3;        // [108], [4] (atomic accumulate)
+    int B, H, W, C;                // dims of the UN-PACKED side tensor x
+    long total;                    // threads with work
+};
+
+// ------------------------------------------------------------------------------------------------
+// PACK.  Volume pixel (h,w) in [H/2, W/2]; thread block of 8 x-channels c0.. -> 32 packed depths d = 4c+s.
+// pv[1 + 4*ci + s] = x[b, 2h'+(s>>1), 2w'+(s&1), c0+ci];  pv[0] = depth 4*c0-1, pv[33] = depth 4*c0+32.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void pack_load_window(const P3Args& a, int b, int hh, int ww, int c0, int j, int cb, bool live, float* pv) {
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    const bool in = live && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2;
+    float last3 = 0.f, first0 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[8];
+        if (in) load8<T>((const T*)a.x + (((long)b * a.H + 2 * hh + (s >> 1)) * a.W + 2 * ww + (s & 1)) * a.ldx + c0, v);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pv[1 + 4 * i + s] = v[i];
+        if (s == 3) last3 = v[7];
+        if (s == 0) first0 = v[0];
+    }
+    const float lo = __shfl_up(last3, 1, 64), hi = __shfl_down(first0, 1, 64);
+    pv[0] = j > 0 ? lo : 0.f;
+    pv[33] = j < cb - 1 ? hi : 0.f;
+}
+
+#define P3_THREAD_MAP(HV, WV)                                                  \
+    const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;              \
+    const int cb = a.C >> 3;                                                   \
+    const bool live = gid < a.total;                                           \
+    const long g = live ? gid : a.total - 1;                                   \
+    const int j = (int)(g % cb);                                               \
+    long pix = g / cb;                                                         \
+    const int w = (int)(pix % (WV)); pix /= (WV);                              \
+    const int h = (int)(pix % (HV));                                           \
+    const int b = (int)(pix / (HV));                                           \
+    const int c0 = j * 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack3d_fwd_kernel(P3Args a) {
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    P3_THREAD_MAP(H2, W2);
+    float acc[4][32];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const float bv = a.b3[f];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[f][i] = bv;
+    }
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+            float pv[34];
+            pack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float wv = a.w3[((f * 3 + kd) * 3 + kh) * 3 + kw];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[f][i] = fmaf(wv, pv[i + kd], acc[f][i]);
+                }
+        }
+    if (!live) return;
+    const int D = a.C * 4;
+    T* op = (T*)a.dst + (((long)b * H2 + h) * W2 + w) * a.lddst;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store8<T>(op + f * D + 4 * c0 + 8 * k, &acc[f][8 * k]);
+}
+
+// dP(d,h,w) = sum_f sum_taps w3[f][kd][kh][kw] * dO[f][d-kd+1][h-kh+1][w-kw+1];  scatter back to x layout
+template <typename T>
+__global__ __launch_bounds__(256) void pack3d_bwd_data_kernel(P3Args a) {
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    P3_THREAD_MAP(H2, W2);
+    const int D = a.C * 4;
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+            const int hh = h - kh + 1, ww = w - kw + 1;
+            const bool in = live && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2;
+            for (int f = 0; f < 4; ++f) {
+                float pv[34];
+                const T* src = (const T*)a.o + (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + 4 * c0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (in) load8<T>(src + 8 * k, &pv[1 + 8 * k]);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pv[1 + 8 * k + i] = 0.f;
+                    }
+                }
+                const float lo = __shfl_up(pv[32], 1, 64), hi = __shfl_down(pv[1], 1, 64);
+                pv[0] = j > 0 ? lo : 0.f;
+                pv[33] = j < cb - 1 ? hi : 0.f;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float wv = a.w3[((f * 3 + kd) * 3 + kh) * 3 + kw];
+                    // dP[d] += w[kd] * dO[d - kd + 1]  -> window index (i + 1) - kd + 1 = i + 2 - kd
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[i] = fmaf(wv, pv[i + 2 - kd], acc[i]);
+                }
+            }
+        }
+    if (!live) return;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = acc[4 * i + s];
+        store8<T>((T*)a.dst + (((long)b * a.H + 2 * h + (s >> 1)) * a.W + 2 * w + (s & 1)) * a.lddst + c0, v);
+    }
+}
+
+// vals[40] per thread: [0..35] = dw3[f][kd][kh fixed][kw] at i = (f*3+kd)*3+kw, [36..39] = db3[f] (kh == 1 blocks only)
+// -> wave sums -> LDS -> one atomic per value per block into dwb[112]
+__device__ __forceinline__ void block_reduce_atomic(float (&vals)[40], int kh, float* dst, float* sred) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 40; ++i) {
+        const float s = wave_sum(vals[i]);
+        if (lane == 0) sred[wave * 40 + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 40) {
+        const int i = threadIdx.x;
+        float s = 0.f;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += sred[wv * 40 + i];
+        if (i < 36) atomicAdd(dst + (i / 3) * 9 + kh * 3 + (i % 3), s);
+        else if (kh == 1) atomicAdd(dst + 108 + (i - 36), s);
+    }
+}
+
+// dw3[f][kd][kh][kw] = sum dO[f][d][h][w] * P(d+kd-1, h+kh-1, w+kw-1);  db3[f] = sum dO[f]
+template <typename T>
+__global__ __launch_bounds__(256) void pack3d_bwd_weight_kernel(P3Args a) {
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    __shared__ float sred[4 * 40];
+    float acc[40];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) acc[i] = 0.f;
+    const int kh = blockIdx.y;                           // one kernel row per grid.y slice (register budget)
+    const int cb = a.C >> 3;
+    const int D = a.C * 4;
+    const long nthreads = (long)gridDim.x * blockDim.x;   // grid.x only; grid.y = kh
+    const long iters = (a.total + nthreads - 1) / nthreads;
+    for (long it = 0; it < iters; ++it) {
+        const long gid = it * nthreads + blockIdx.x * (long)blockDim.x + threadIdx.x;
+        const bool live = gid < a.total;
+        const long g = live ? gid : a.total - 1;
+        const int j = (int)(g % cb);
+        long pix = g / cb;
+        const int w = (int)(pix % W2); pix /= W2;
+        const int h = (int)(pix % H2);
+        const int b = (int)(pix / H2);
+        const int c0 = j * 8;
+        float go[4][32];
+        const T* src = (const T*)a.o + (((long)b * H2 + h) * W2 + w) * a.ldo + 4 * c0;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (live) load8<T>(src + f * D + 8 * k, &go[f][8 * k]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) go[f][8 * k + i] = 0.f;
+                }
+            }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) s += go[f][i];
+            acc[36 + f] += s;
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            float pv[34];
+            pack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) s = fmaf(go[f][i], pv[i + kd], s);
+                    acc[(f * 3 + kd) * 3 + kw] += s;
+                }
+        }
+    }
+    block_reduce_atomic(acc, kh, a.dw3, sred);
+}
+
+// ------------------------------------------------------------------------------------------------
+// UNPACK.  Volume = x itself: depth = channel c (C of them), pixel (h,w) in [H,W]; thread block of 8 depths.
+// feature side tensor o = [B,2H,2W,C] after the pixel shuffle: o3[f][c] lives at channel q>>2 of output
+// pixel (2h + ((q&3)>>1), 2w + (q&1)), q = f*C + c.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void unpack_load_window(const P3Args& a, int b, int hh, int ww, int c0, int j, int cb, bool live, float* pv) {
+    const bool in = live && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+    if (in) load8<T>((const T*)a.x + (((long)b * a.H + hh) * a.W + ww) * a.ldx + c0, &pv[1]);
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pv[1 + i] = 0.f;
+    }
+    const float lo = __shfl_up(pv[8], 1, 64), hi = __shfl_down(pv[1], 1, 64);
+    pv[0] = j > 0 ? lo : 0.f;
+    pv[9] = j < cb - 1 ? hi : 0.f;
+}
+
+// feature-side gather/scatter of the 8 values o3[f][c0..c0+7] at volume pixel (h,w)
+template <typename T>
+__device__ __forceinline__ void shuffled_ptrs(const P3Args& a, const void* base, long ld, int b, int h, int w, int f, int c0, const T** p) {
+    const int q0 = f * a.C + c0;            // multiple of 8 -> channels q0>>2 and (q0>>2)+1, 4 positions each
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        p[s] = (const T*)base + (((long)b * 2 * a.H + 2 * h + (s >> 1)) * (2 * a.W) + 2 * w + (s & 1)) * ld + (q0 >> 2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack3d_fwd_kernel(P3Args a) {
+    P3_THREAD_MAP(a.H, a.W);
+    float acc[4][8];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const float bv = a.b3[f];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[f][i] = bv;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            float pv[10];
+            unpack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float wv = a.w3[((f * 3 + kd) * 3 + kh) * 3 + kw];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[f][i] = fmaf(wv, pv[i + kd], acc[f][i]);
+                }
+        }
+    if (!live) return;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const T* p[4];
+        shuffled_ptrs<T>(a, a.dst, a.lddst, b, h, w, f, c0, p);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {       // q = q0 + i: position s = i&3, channel (q0>>2) + (i>>2)
+            T* d = (T*)p[s];
+            Elem<T>::st(d, acc[f][s]);
+            Elem<T>::st(d + 1, acc[f][4 + s]);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack_load_feat(const P3Args& a, int b, int hh, int ww, int f, int c0, int j, int cb, bool live, float* pv) {
+    const bool in = live && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+    if (in) {
+        const T* p[4];
+        shuffled_ptrs<T>(a, a.o, a.ldo, b, hh, ww, f, c0, p);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { pv[1 + s] = Elem<T>::ld(p[s]); pv[1 + 4 + s] = Elem<T>::ld(p[s] + 1); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pv[1 + i] = 0.f;
+    }
+    const float lo = __shfl_up(pv[8], 1, 64), hi = __shfl_down(pv[1], 1, 64);
+    pv[0] = j > 0 ? lo : 0.f;
+    pv[9] = j < cb - 1 ? hi : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack3d_bwd_data_kernel(P3Args a) {
+    P3_THREAD_MAP(a.H, a.W);
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float pv[10];
+                unpack_load_feat<T>(a, b, h - kh + 1, w - kw + 1, f, c0, j, cb, live, pv);
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float wv = a.w3[((f * 3 + kd) * 3 + kh) * 3 + kw];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(wv, pv[i + 2 - kd], acc[i]);
+                }
+            }
+    if (!live) return;
+    store8<T>((T*)a.dst + (((long)b * a.H + h) * a.W + w) * a.lddst + c0, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack3d_bwd_weight_kernel(P3Args a) {
+    __shared__ float sred[4 * 40];
+    float acc[40];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) acc[i] = 0.f;
+    const int kh = blockIdx.y;
+    const int cb = a.C >> 3;
+    const long nthreads = (long)gridDim.x * blockDim.x;   // grid.x only; grid.y = kh
+    const long iters = (a.total + nthreads - 1) / nthreads;
+    for (long it = 0; it < iters; ++it) {
+        const long gid = it * nthreads + blockIdx.x * (long)blockDim.x + threadIdx.x;
+        const bool live = gid < a.total;
+        const long g = live ? gid : a.total - 1;
+        const int j = (int)(g % cb);
+        long pix = g / cb;
+        const int w = (int)(pix % a.W); pix /= a.W;
+        const int h = (int)(pix % a.H);
+        const int b = (int)(pix / a.H);
+        const int c0 = j * 8;
+        float go[4][8];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            float tmp[10];
+            unpack_load_feat<T>(a, b, h, w, f, c0, j, cb, live, tmp);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { go[f][i] = tmp[1 + i]; s += tmp[1 + i]; }
+            acc[36 + f] += s;
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            float pv[10];
+            unpack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s = fmaf(go[f][i], pv[i + kd], s);
+                    acc[(f * 3 + kd) * 3 + kw] += s;
+                }
+        }
+    }
+    block_reduce_atomic(acc, kh, a.dw3, sred);
+}
+
+template <typename KB, typename KF>
+int launch_p3(int dtype, KB kb, KF kf, const P3Args& a, long threads, hipStream_t st, int gy = 1) {
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(kb, dim3(grid, gy), dim3(256), 0, st, a);
+    else if (dtype == MTE_DT_F32) hipLaunchKernelGGL(kf, dim3(grid, gy), dim3(256), 0, st, a);
+    else return MTE_ERR_UNSUPPORTED;
+    return mte_check_launch();
+}
+
+bool p3_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <= 64 && (cb & (cb - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// out[B,H/2,W/2,16C] = conv3d(pixel_unshuffle(x[B,H,W,C]))            (PackLayerConv3d up to its Conv2D)
+int mte_pack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, void* out, long ldo,
+                   int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (!x || !w3 || !b3 || !out || !p3_ok(C) || (H & 1) || (W & 1)) return MTE_ERR_ARG;
+    P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    return launch_p3(dtype, pack3d_fwd_kernel<bf16_t>, pack3d_fwd_kernel<float>, a, a.total, stream);
+}
+int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, long lddx,
+                        int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
+    P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    return launch_p3(dtype, pack3d_bwd_data_kernel<bf16_t>, pack3d_bwd_data_kernel<float>, a, a.total, stream);
+}
+// dwb[112] (fp32, zeroed here): [0..107] = dw3, [108..111] = db3
+int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
+                          int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (!x || !dout || !dwb || !p3_ok(C)) return MTE_ERR_ARG;
+    if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    long threads = a.total < 256L * 1024 ? a.total : 256L * 1024;
+    return launch_p3(dtype, pack3d_bwd_weight_kernel<bf16_t>, pack3d_bwd_weight_kernel<float>, a, threads, stream, 3);
+}
+
+// out[B,2H,2W,C] = pixel_shuffle(conv3d(x[B,H,W,C]))                   (UnpackLayerConv3d after its Conv2D)
+int mte_unpack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, void* out, long ldo,
+                     int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (!x || !w3 || !b3 || !out || !p3_ok(C)) return MTE_ERR_ARG;
+    P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.total = (long)B * H * W * (C / 8);
+    return launch_p3(dtype, unpack3d_fwd_kernel<bf16_t>, unpack3d_fwd_kernel<float>, a, a.total, stream);
+}
+int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, long lddx,
+                          int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
+    P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.total = (long)B * H * W * (C / 8);
+    return launch_p3(dtype, unpack3d_bwd_data_kernel<bf16_t>, unpack3d_bwd_data_kernel<float>, a, a.total, stream);
+}
+int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
+                            int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (!x || !dout || !dwb || !p3_ok(C)) return MTE_ERR_ARG;
+    if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.total = (long)B * H * W * (C / 8);
+    long threads = a.total < 256L * 2048 ? a.total : 256L * 2048;
+    return launch_p3(dtype, unpack3d_bwd_weight_kernel<bf16_t>, unpack3d_bwd_weight_kernel<float>, a, threads, stream, 3);
+}
+
+}  // extern "C"

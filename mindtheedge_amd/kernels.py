@@ -1,0 +1,469 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mte_kernels.h).
+
+Activations travel between layers as torch tensors of logical shape [B, C, H, W] whose memory is NHWC
+(``channels_last`` strides, possibly a channel slice of a wider buffer) in the compute dtype (bf16, or
+fp32 in validation mode).  PyTorch is used for device memory, streams and the autograd tape only: every
+arithmetic step of the hot path is a hand-written gfx950 kernel in libmte_hip.so.  There is no fallback
+path -- a missing library or an unsupported shape raises.
+"""
+import math
+
+import torch
+
+from ._lib import lib, MteError
+
+DT_BF16, DT_F32 = 0, 1
+_state = {"compute_dtype": torch.bfloat16, "weights_epoch": 0}
+
+
+def set_compute_dtype(dtype):
+    """'bf16' (default; MFMA bf16, fp32 accumulate) or 'fp32' (exact fp32 MFMA; validation mode)."""
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}.get(dtype, dtype)
+    assert dtype in (torch.bfloat16, torch.float32)
+    _state["compute_dtype"] = dtype
+
+
+def compute_dtype():
+    return _state["compute_dtype"]
+
+
+def bump_weights_epoch():
+    """Invalidate every cached bf16/fp32 weight pack (call after an optimizer step that writes parameters
+    behind autograd's version counters, e.g. the fused flat Adam)."""
+    _state["weights_epoch"] += 1
+
+
+def weights_epoch():
+    return _state["weights_epoch"]
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float32:
+        return DT_F32
+    raise MteError("unsupported activation dtype %s" % t.dtype)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise MteError("mindtheedge_amd kernels run on an MI355X only; got a %s tensor (no CPU fallback)" % t.device)
+
+
+def round8(c):
+    return (c + 7) // 8 * 8
+
+
+def new_act(B, C, H, W, dtype=None, device="cuda"):
+    """Uninitialised NHWC activation with logical shape [B,C,H,W]."""
+    return torch.empty((B, H, W, C), dtype=dtype or compute_dtype(), device=device).permute(0, 3, 1, 2)
+
+
+def is_act(t):
+    if t.dim() != 4 or t.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if C > 1 and sc != 1:
+        return False
+    ld = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C))
+    ok = ld >= C and (H == 1 or W == 1 or sh == W * ld) and (B == 1 or sb == H * W * ld)
+    per16 = 8 if t.dtype == torch.bfloat16 else 4
+    return bool(ok and ld % per16 == 0 and t.data_ptr() % 16 == 0)
+
+
+def as_act(t, dtype=None):
+    """Returns t as an NHWC activation in `dtype` (layout/dtype conversion only when necessary)."""
+    dtype = dtype or t.dtype
+    if t.dtype == dtype and is_act(t):
+        return t
+    out = new_act(t.shape[0], t.shape[1], t.shape[2], t.shape[3], dtype, t.device)
+    out.copy_(t)
+    return out
+
+
+def _pl(t):
+    """(device pointer, elements per pixel) of an NHWC activation."""
+    if not is_act(t):
+        raise MteError("expected an NHWC activation, got shape %s strides %s" % (tuple(t.shape), t.stride()))
+    B, C, H, W = t.shape
+    ld = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else (t.stride(0) if B > 1 else C))
+    return t.data_ptr(), ld
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------------------
+# weight packs
+# --------------------------------------------------------------------------------------------------
+class WeightPack:
+    """Kernel-ready copies of one OIHW fp32 conv weight: forward [Cout][taps][Cin_p] and data-gradient
+    [Cin_p][taps rot180][Cout] packs in the compute dtype.  Re-packed when the parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.wf = self.wb = None
+
+    def get(self, w, dtype, need_bwd):
+        key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
+        if key != self.key or (need_bwd and self.wb is None):
+            cout, cin, kh, kw = w.shape
+            cin_p = round8(cin)
+            self.wf = torch.empty((cout, kh * kw, cin_p), dtype=dtype, device=w.device)
+            self.wb = torch.empty((cin_p, kh * kw, cout), dtype=dtype, device=w.device) if need_bwd else None
+            lib.mte_pack_conv_weights(w.detach().contiguous().data_ptr(), self.wf.data_ptr(), _ptr(self.wb), cout, cin, kh, kw,
+                                      cin_p, cout, DT_BF16 if dtype == torch.bfloat16 else DT_F32, _stream())
+            self.key = key
+        return self.wf, self.wb
+
+
+def conv_forward(x, wf, bias, cout, kh, kw, out=None):
+    B, Cp, H, W = x.shape
+    if out is None:
+        out = new_act(B, cout, H, W, x.dtype, x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(out)
+    lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _stream())
+    return out
+
+
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True):
+    """-> (dx or None, dw (OIHW fp32) or None, dbias fp32)"""
+    cout, cin, kh, kw = w.shape
+    B, Cp, H, W = x.shape
+    dyp, lddy = _pl(dy)
+    xp, ldx = _pl(x)
+    st = _stream()
+    dw = dbias = dx = None
+    if need_dw:
+        stage = torch.empty((cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
+        lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
+        dw = torch.empty_like(w, dtype=torch.float32)
+        lib.mte_unpack_conv_wgrad(stage.data_ptr(), dw.data_ptr(), cout, cin, kh, kw, Cp, st)
+        dbias = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
+    if need_dx:
+        _, wb = pack.get(w, x.dtype, True)
+        dx = new_act(B, Cp, H, W, x.dtype, x.device)
+        dxp, lddx = _pl(dx)
+        lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), st)
+    return dx, dw, dbias
+
+
+def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
+    B, C, H, W = y1.shape
+    stats = torch.empty((B, 16, 2), dtype=torch.float64, device=y1.device)
+    p1, l1 = _pl(y1)
+    p2, l2 = _pl(y2) if y2 is not None else (0, 0)
+    st = _stream()
+    lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
+    z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
+    zp, lz = _pl(z)
+    lib.mte_gn_elu_fwd(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), zp, lz,
+                       B, H * W, C, eps, _dt(y1), st)
+    return z, stats
+
+
+def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2):
+    B, C, H, W = y1.shape
+    dz = as_act(dz, y1.dtype)
+    red = torch.empty((B, C, 2), dtype=torch.float32, device=y1.device)
+    d1 = new_act(B, C, H, W, y1.dtype, y1.device)
+    d2 = new_act(B, C, H, W, y1.dtype, y1.device) if need_d2 else None
+    dgamma = torch.empty((C,), dtype=torch.float32, device=y1.device)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=y1.device)
+    pz, lz = _pl(dz)
+    p1, l1 = _pl(y1)
+    p2, l2 = _pl(y2) if y2 is not None else (0, 0)
+    pd1, ld1 = _pl(d1)
+    pd2, ld2 = _pl(d2) if d2 is not None else (0, 0)
+    lib.mte_gn_elu_bwd(pz, lz, p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
+                       pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C, eps, _dt(y1), _stream())
+    return d1, d2, dgamma, dbeta
+
+
+GN_EPS = 1e-5
+
+
+class ConvGnEluFn(torch.autograd.Function):
+    """ELU(GroupNorm16(conv_k(zero_pad(x)) + b))  -- reference Conv2D.forward, layers01.py:35-38."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, pack):
+        wf, _ = pack.get(w, x.dtype, False)
+        cout, cin, kh, kw = w.shape
+        y = conv_forward(x, wf, b, cout, kh, kw)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS)
+        ctx.save_for_backward(x, w, y, stats, gamma, beta)
+        ctx.pack = pack
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, y, stats, gamma, beta = ctx.saved_tensors
+        dy, _, dgamma, dbeta = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False)
+        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0])
+        return dx, dw, db, dgamma, dbeta, None
+
+
+class ConvFn(torch.autograd.Function):
+    """Plain conv + bias (the 1x1 shortcut of ResidualConv, layers01.py:61)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, pack):
+        wf, _ = pack.get(w, x.dtype, False)
+        cout, cin, kh, kw = w.shape
+        y = conv_forward(x, wf, b, cout, kh, kw)
+        ctx.save_for_backward(x, w)
+        ctx.pack = pack
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = as_act(dy, x.dtype)
+        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0])
+        return dx, dw, db, None
+
+
+class ResidualTailFn(torch.autograd.Function):
+    """ELU(GroupNorm16(a + scale[b,c] * s)) -- ResidualConv tail with Dropout2d folded in (layers01.py:65-73)."""
+
+    @staticmethod
+    def forward(ctx, a, s, scale, gamma, beta):
+        z, stats = _gn_forward(a, s, scale, gamma, beta, GN_EPS)
+        ctx.save_for_backward(a, s, stats, gamma, beta)
+        ctx.scale = scale
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        a, s, stats, gamma, beta = ctx.saved_tensors
+        da, ds, dgamma, dbeta = _gn_backward(dz, a, s, ctx.scale, stats, gamma, beta, GN_EPS, True)
+        return da, ds, None, dgamma, dbeta
+
+
+class Pack3dFn(torch.autograd.Function):
+    """packing(r=2) + Conv3d(1->4) + view  (PackLayerConv3d.forward before its Conv2D, layers01.py:241-246)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, b3):
+        B, C, H, W = x.shape
+        out = new_act(B, 16 * C, H // 2, W // 2, x.dtype, x.device)
+        xp, ldx = _pl(x)
+        op, ldo = _pl(out)
+        w3c, b3c = w3.detach().contiguous().float(), b3.detach().contiguous().float()
+        lib.mte_pack3d_fwd(xp, ldx, w3c.data_ptr(), b3c.data_ptr(), op, ldo, B, H, W, C, _dt(x), _stream())
+        ctx.save_for_backward(x, w3c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w3c = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dout = as_act(dout, x.dtype)
+        dop, ldo = _pl(dout)
+        xp, ldx = _pl(x)
+        st = _stream()
+        dwb = torch.empty((112,), dtype=torch.float32, device=x.device)
+        lib.mte_pack3d_bwd_weight(xp, ldx, dop, ldo, dwb.data_ptr(), B, H, W, C, _dt(x), st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_act(B, C, H, W, x.dtype, x.device)
+            dxp, lddx = _pl(dx)
+            lib.mte_pack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), st)
+        return dx, dwb[:108].view(4, 1, 3, 3, 3), dwb[108:112]
+
+
+class Unpack3dFn(torch.autograd.Function):
+    """Conv3d(1->4) + view + PixelShuffle(2)  (UnpackLayerConv3d.forward after its Conv2D, layers01.py:281-286)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, b3):
+        B, C, H, W = x.shape
+        out = new_act(B, C, 2 * H, 2 * W, x.dtype, x.device)
+        xp, ldx = _pl(x)
+        op, ldo = _pl(out)
+        w3c, b3c = w3.detach().contiguous().float(), b3.detach().contiguous().float()
+        lib.mte_unpack3d_fwd(xp, ldx, w3c.data_ptr(), b3c.data_ptr(), op, ldo, B, H, W, C, _dt(x), _stream())
+        ctx.save_for_backward(x, w3c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w3c = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dout = as_act(dout, x.dtype)
+        dop, ldo = _pl(dout)
+        xp, ldx = _pl(x)
+        st = _stream()
+        dwb = torch.empty((112,), dtype=torch.float32, device=x.device)
+        lib.mte_unpack3d_bwd_weight(xp, ldx, dop, ldo, dwb.data_ptr(), B, H, W, C, _dt(x), st)
+        dx = new_act(B, C, H, W, x.dtype, x.device)
+        dxp, lddx = _pl(dx)
+        lib.mte_unpack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), st)
+        return dx, dwb[:108].view(4, 1, 3, 3, 3), dwb[108:112]
+
+
+class InvDepthFn(torch.autograd.Function):
+    """sigmoid(conv3x3(pad1(x)) + b) / min_depth -> fp32 [B,1,H,W]  (InvDepth.forward, layers01.py:120-123)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, min_depth):
+        B, C, H, W = x.shape
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+        xp, ldx = _pl(x)
+        wc = w.detach().contiguous().float()
+        lib.mte_invdepth_fwd(xp, ldx, wc.data_ptr(), b.detach().float().data_ptr(), out.data_ptr(), B, H, W, C, min_depth, _dt(x), _stream())
+        ctx.save_for_backward(x, wc, out)
+        ctx.min_depth = min_depth
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wc, out = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dout = dout.contiguous().float()
+        dx = new_act(B, C, H, W, x.dtype, x.device)
+        scratch = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+        dwb = torch.empty((C * 9 + 1,), dtype=torch.float32, device=x.device)
+        xp, ldx = _pl(x)
+        dxp, lddx = _pl(dx)
+        lib.mte_invdepth_bwd(xp, ldx, wc.data_ptr(), out.data_ptr(), dout.data_ptr(), scratch.data_ptr(), dxp, lddx, dwb.data_ptr(),
+                             B, H, W, C, ctx.min_depth, _dt(x), _stream())
+        return dx, dwb[:C * 9].view(1, C, 3, 3), dwb[C * 9:], None
+
+
+class ConcatFn(torch.autograd.Function):
+    """torch.cat((parts...[, nearest_up2(inv)]), 1) into one NHWC buffer whose channel count is padded to a
+    multiple of 8 (decoder version 'A', PackNetSAN01.py:105-143).  Backward hands out channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, inv, *parts):
+        B, _, H, W = parts[0].shape
+        dtype = parts[0].dtype
+        chans = [p.shape[1] for p in parts]
+        ctot = sum(chans) + (8 if inv is not None else 0)
+        buf = new_act(B, ctot, H, W, dtype, parts[0].device)
+        st = _stream()
+        off = 0
+        for p, c in zip(parts, chans):
+            p = as_act(p, dtype)
+            sp, lds_ = _pl(p)
+            dst = buf[:, off:off + c]
+            dp, ldd = _pl(dst)
+            lib.mte_copy_channels(sp, lds_, dp, ldd, B * H * W, c, _dt(p), st)
+            off += c
+        if inv is not None:
+            dst = buf[:, off:off + 8]
+            dp, ldd = _pl(dst)
+            lib.mte_upsample_inv_fwd(inv.contiguous().data_ptr(), dp, ldd, B, H // 2, W // 2, _dt(buf), st)
+        ctx.chans = chans
+        ctx.has_inv = inv is not None
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        dbuf = as_act(dbuf)
+        B, _, H, W = dbuf.shape
+        outs = []
+        off = 0
+        for c in ctx.chans:
+            outs.append(dbuf[:, off:off + c])
+            off += c
+        dinv = None
+        if ctx.has_inv:
+            dinv = torch.empty((B, 1, H // 2, W // 2), dtype=torch.float32, device=dbuf.device)
+            src = dbuf[:, off:off + 8]
+            sp, lds_ = _pl(src)
+            lib.mte_upsample_inv_bwd(sp, lds_, dinv.data_ptr(), B, H // 2, W // 2, 0, _dt(dbuf), _stream())
+        return (dinv,) + tuple(outs)
+
+
+def image_to_act(rgb, flip=False, dtype=None):
+    """fp32 NCHW image -> NHWC compute-dtype activation, channels zero-padded to a multiple of 8."""
+    _require_gpu(rgb)
+    B, C, H, W = rgb.shape
+    rgb = rgb.contiguous().float()
+    out = new_act(B, round8(C), H, W, dtype or compute_dtype(), rgb.device)
+    op, ldo = _pl(out)
+    lib.mte_nchw_to_nhwc(rgb.data_ptr(), op, ldo, B, C, H, W, round8(C), 1 if flip else 0, _dt(out), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------
+class EdgeLossFn(torch.autograd.Function):
+    """weight * class-balanced BCE of sigmoid(directional Sobel(depth) - thresh) against soft edge labels.
+    GradLoss.forward ('cross_entropy'), grad_loss.py:122-219, fused with inv2depth when from_inv."""
+
+    @staticmethod
+    def forward(ctx, pred, edge, normal, mask, weight, pos_to_neg, from_inv, is_grad, is_sigmoid, thresh, want_gmap):
+        B, _, H, W = edge.shape
+        pred, edge = pred.contiguous().float(), edge.contiguous().float()
+        normal = None if normal is None else normal.contiguous().float()
+        mask = None if mask is None else mask.contiguous().float()
+        dev = pred.device
+        sums = torch.empty((B * 6 + 4,), dtype=torch.float64, device=dev)
+        coef = torch.empty((2 * B + 1,), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        gmap = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_gmap else None
+        st = _stream()
+        lib.mte_edge_loss_fwd(pred.data_ptr(), edge.data_ptr(), _ptr(normal), _ptr(mask), sums.data_ptr(), _ptr(gmap),
+                              B, H, W, int(from_inv), int(is_grad), int(is_sigmoid), float(thresh), st)
+        lib.mte_edge_loss_finalize(sums.data_ptr(), B, edge.numel(), float(weight), float(pos_to_neg), int(mask is not None),
+                                   1.0, 0, loss.data_ptr(), coef.data_ptr(), st)
+        ctx.save_for_backward(pred, edge, normal, mask, coef)
+        ctx.cfg = (B, H, W, int(from_inv), int(is_grad), int(is_sigmoid), float(thresh))
+        if want_gmap:
+            ctx.mark_non_differentiable(gmap)
+        return loss, gmap
+
+    @staticmethod
+    def backward(ctx, gloss, _g):
+        pred, edge, normal, mask, coef = ctx.saved_tensors
+        B, H, W, from_inv, is_grad, is_sigmoid, thresh = ctx.cfg
+        dpred = torch.empty_like(pred)
+        gl = gloss.contiguous().float()
+        lib.mte_edge_loss_bwd(pred.data_ptr(), edge.data_ptr(), _ptr(normal), _ptr(mask), coef.data_ptr(), gl.data_ptr(),
+                              dpred.data_ptr(), B, H, W, from_inv, is_grad, is_sigmoid, thresh, _stream())
+        return (dpred,) + (None,) * 10
+
+
+class SilogFn(torch.autograd.Function):
+    """10*sqrt(mean(d^2) - 0.85*mean(d)^2), d = log(10(inv+1e-5)) - log(10/depth) over depth > 0
+    (SupervisedLoss 'sparse-silog' at scale 0: supervised_loss.py:57-69,155-216 + depth2inv)."""
+
+    @staticmethod
+    def forward(ctx, inv, depth):
+        inv, depth = inv.contiguous().float(), depth.contiguous().float()
+        dev = inv.device
+        sums = torch.empty((3,), dtype=torch.float64, device=dev)
+        aux = torch.empty((2,), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        lib.mte_silog_fwd(inv.data_ptr(), depth.data_ptr(), inv.numel(), sums.data_ptr(), 1.0, 0, loss.data_ptr(), aux.data_ptr(), _stream())
+        ctx.save_for_backward(inv, depth, aux)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        inv, depth, aux = ctx.saved_tensors
+        dinv = torch.empty_like(inv)
+        gl = gloss.contiguous().float()
+        lib.mte_silog_bwd(inv.data_ptr(), depth.data_ptr(), aux.data_ptr(), gl.data_ptr(), dinv.data_ptr(), inv.numel(), 0, _stream())
+        return dinv, None
+
+
+def adam_step_flat(p, g, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, gscale=1.0):
+    """In-place fused Adam over flat fp32 device buffers."""
+    _require_gpu(p)
+    lib.mte_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                      float(eps), int(step), float(gscale), _stream())
+    bump_weights_epoch()

@@ -1,0 +1,46 @@
+"""SfmModel: depth network + optional whole-batch horizontal-flip augmentation
+(reference: packnet_sfm/models/SfmModel.py:12-133).  The pose network slot exists for API parity only."""
+import random
+
+from .base_model import BaseModel
+from .model_utils import flip_batch_input, flip_output
+
+
+class SfmModel(BaseModel):
+    def __init__(self, depth_net=None, pose_net=None, rotation_mode='euler', flip_lr_prob=0.0,
+                 upsample_depth_maps=False, **kwargs):
+        super().__init__()
+        self.depth_net = depth_net
+        self.pose_net = pose_net
+        self.rotation_mode = rotation_mode
+        self.flip_lr_prob = flip_lr_prob
+        self.upsample_depth_maps = upsample_depth_maps
+        if upsample_depth_maps:
+            raise NotImplementedError("upsample_depth_maps=True is not used by the shipped edge-loss configs")
+        self._network_requirements = ['depth_net', 'pose_net']
+
+    def add_depth_net(self, depth_net):
+        self.depth_net = depth_net
+
+    def add_pose_net(self, pose_net):
+        self.pose_net = pose_net
+
+    def add_edge_loss(self, edge_loss_head):
+        self.edge_loss_head = edge_loss_head
+
+    def depth_net_flipping(self, batch, flip, output_features=False):
+        batch_input = {key: batch[key] for key in self._input_keys if key in batch}
+        batch_input['output_features'] = output_features
+        if flip:
+            return flip_output(self.depth_net(**flip_batch_input(batch_input)))
+        return self.depth_net(**batch_input)
+
+    def compute_depth_net(self, batch, force_flip=False, output_features=False):
+        flag_flip_lr = random.random() < self.flip_lr_prob if self.training else force_flip
+        return self.depth_net_flipping(batch, flag_flip_lr, output_features)
+
+    def forward(self, batch, return_logs=False, force_flip=False, output_features=False):
+        depth_output = self.compute_depth_net(batch, force_flip=force_flip, output_features=output_features)
+        if 'rgb_context' in batch and self.pose_net is not None:
+            raise NotImplementedError("pose networks / self-supervision are outside this build's scope")
+        return {**depth_output, 'poses': None}

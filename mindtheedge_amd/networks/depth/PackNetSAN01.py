@@ -1,0 +1,145 @@
+"""PackNet-SAN depth network (dense RGB path) on gfx950 kernels -- drop-in for
+packnet_sfm/networks/depth/PackNetSAN01.py: same constructor signature, module tree and state-dict keys
+(encoder.*, decoder.*, weight, bias), same forward contract:
+
+  train: {'inv_depths': [4 x fp32 [B,1,H/2^s,W/2^s]]}                         (reference :319-322)
+  eval : {'inv_depths': [[4 maps], [skip0..skip4, x5p]]}                       (reference :282-293)
+
+The sparse LiDAR (SAN / MinkowskiEngine) branch is outside this build's scope: passing
+``input_depth`` raises NotImplementedError instead of silently ignoring it.
+"""
+import torch
+import torch.nn as nn
+
+from ... import kernels as K
+from ..layers.packnet.layers01 import (PackLayerConv3d, UnpackLayerConv3d, Conv2D, ResidualBlock, InvDepth,
+                                      _ConvParams, _Conv3dParams)
+
+
+class PackNetSlimEnc01(nn.Module):
+    def __init__(self, version, in_channels, ni, n1, n2, n3, n4, n5, pack_kernel, num_blocks, num_3d_feat, dropout):
+        super().__init__()
+        self.version = version
+        self.in_channels = in_channels
+        self.pre_calc = Conv2D(in_channels, ni, 5, 1)
+        self.pack1 = PackLayerConv3d(n1, pack_kernel[0], d=num_3d_feat)
+        self.pack2 = PackLayerConv3d(n2, pack_kernel[1], d=num_3d_feat)
+        self.pack3 = PackLayerConv3d(n3, pack_kernel[2], d=num_3d_feat)
+        self.pack4 = PackLayerConv3d(n4, pack_kernel[3], d=num_3d_feat)
+        self.pack5 = PackLayerConv3d(n5, pack_kernel[4], d=num_3d_feat)
+        self.conv1 = Conv2D(ni, n1, 7, 1)
+        self.conv2 = ResidualBlock(n1, n2, num_blocks[0], 1, dropout=dropout)
+        self.conv3 = ResidualBlock(n2, n3, num_blocks[1], 1, dropout=dropout)
+        self.conv4 = ResidualBlock(n3, n4, num_blocks[2], 1, dropout=dropout)
+        self.conv5 = ResidualBlock(n4, n5, num_blocks[3], 1, dropout=dropout)
+
+    def forward(self, rgb):
+        x = self.pre_calc(rgb)
+        x1p = self.pack1(self.conv1(x))
+        x2p = self.pack2(self.conv2(x1p))
+        x3p = self.pack3(self.conv3(x2p))
+        x4p = self.pack4(self.conv4(x3p))
+        x5p = self.pack5(self.conv5(x4p))
+        return x5p, [x, x1p, x2p, x3p, x4p]
+
+
+class Decoder(nn.Module):
+    def __init__(self, version, out_channels, ni, n1, n2, n3, n4, n5, unpack_kernel, iconv_kernel, num_3d_feat):
+        super().__init__()
+        if version != 'A':
+            raise NotImplementedError("only feature stacking 'A' (concatenation) is built; the shipped YAMLs use '1A'")
+        self.version = version
+        self.unpack5 = UnpackLayerConv3d(n5, n5, unpack_kernel[0], d=num_3d_feat)
+        self.unpack4 = UnpackLayerConv3d(n5, n4, unpack_kernel[1], d=num_3d_feat)
+        self.unpack3 = UnpackLayerConv3d(n4, n3, unpack_kernel[2], d=num_3d_feat)
+        self.unpack2 = UnpackLayerConv3d(n3, n2, unpack_kernel[3], d=num_3d_feat)
+        self.unpack1 = UnpackLayerConv3d(n2, n1, unpack_kernel[4], d=num_3d_feat)
+        self.iconv5 = Conv2D(n5 + n4, n5, iconv_kernel[0], 1)
+        self.iconv4 = Conv2D(n4 + n3, n4, iconv_kernel[1], 1)
+        self.iconv3 = Conv2D(n3 + n2 + out_channels, n3, iconv_kernel[2], 1)
+        self.iconv2 = Conv2D(n2 + n1 + out_channels, n2, iconv_kernel[3], 1)
+        self.iconv1 = Conv2D(n1 + ni + out_channels, n1, iconv_kernel[4], 1)
+        self.disp4_layer = InvDepth(n4, out_channels=out_channels)
+        self.disp3_layer = InvDepth(n3, out_channels=out_channels)
+        self.disp2_layer = InvDepth(n2, out_channels=out_channels)
+        self.disp1_layer = InvDepth(n1, out_channels=out_channels)
+
+    def forward(self, x5p, skips):
+        skip1, skip2, skip3, skip4, skip5 = skips
+        iconv5 = self.iconv5(K.ConcatFn.apply(None, self.unpack5(x5p), skip5))
+        iconv4 = self.iconv4(K.ConcatFn.apply(None, self.unpack4(iconv5), skip4))
+        inv_depth4 = self.disp4_layer(iconv4)
+        iconv3 = self.iconv3(K.ConcatFn.apply(inv_depth4, self.unpack3(iconv4), skip3))
+        inv_depth3 = self.disp3_layer(iconv3)
+        iconv2 = self.iconv2(K.ConcatFn.apply(inv_depth3, self.unpack2(iconv3), skip2))
+        inv_depth2 = self.disp2_layer(iconv2)
+        iconv1 = self.iconv1(K.ConcatFn.apply(inv_depth2, self.unpack1(iconv2), skip1))
+        inv_depth1 = self.disp1_layer(iconv1)
+        return [inv_depth1, inv_depth2, inv_depth3, inv_depth4]
+
+
+class _SparseBranchPlaceholder(nn.Module):
+    """Stands where the reference's MinkowskiEncoder ('mconvs') sits; holds no parameters."""
+
+
+class PackNetSAN01(nn.Module):
+    def __init__(self, dropout=None, version=None, freeze_encoder=False, freeze_decoder=False, freeze_san=False,
+                 input_channels=3, is_depth_aux_net=False, output_channels=1, **kwargs):
+        super().__init__()
+        self.version = version[1:]
+        self.in_channels = input_channels
+        self.is_depth_aux_net = is_depth_aux_net      # the reference reads this attribute but never sets it
+        if is_depth_aux_net:
+            raise NotImplementedError("depth_aux_net does not exist in the reference either (never constructed)")
+        ni, n1, n2, n3, n4, n5 = 32, 32, 64, 128, 256, 512
+        num_blocks = [2, 2, 3, 3]
+        pack_kernel = [5, 3, 3, 3, 3]
+        unpack_kernel = [3, 3, 3, 3, 3]
+        iconv_kernel = [3, 3, 3, 3, 3]
+        num_3d_feat = 4
+        self.encoder = PackNetSlimEnc01(self.version, self.in_channels, ni, n1, n2, n3, n4, n5,
+                                        pack_kernel, num_blocks, num_3d_feat, dropout)
+        if freeze_encoder:
+            self.freeze_weights(self.encoder.parameters())
+        self.decoder = Decoder(self.version, output_channels, ni, n1, n2, n3, n4, n5, unpack_kernel, iconv_kernel, num_3d_feat)
+        if freeze_decoder:
+            self.freeze_weights(self.decoder.parameters())
+        self.mconvs = _SparseBranchPlaceholder()
+        self.weight = nn.Parameter(torch.ones(5), requires_grad=not freeze_san)
+        self.bias = nn.Parameter(torch.zeros(5), requires_grad=not freeze_san)
+        self.init_weights()
+
+    def init_weights(self):
+        """xavier-uniform conv / conv3d weights, zero biases (reference :214-220)."""
+        for m in self.modules():
+            if isinstance(m, (_ConvParams, _Conv3dParams)):
+                nn.init.xavier_uniform_(m.weight)
+                m.bias.data.zero_()
+
+    @staticmethod
+    def freeze_weights(params):
+        for p in params:
+            p.requires_grad = False
+
+    def run_network(self, rgb, input_depth=None):
+        if input_depth is not None:
+            raise NotImplementedError("the sparse LiDAR (SAN) branch is out of scope of this build (SURVEY.md 8(f-1))")
+        x5p, skips = self.encoder(rgb)
+        return [self.decoder(x5p, skips), skips + [x5p]]
+
+    def forward(self, rgb, input_depth=None, rgb_edge=None, output_features=False, **kwargs):
+        if self.in_channels == 4:
+            rgb = torch.cat((rgb, rgb_edge), dim=1)
+        if not self.training:
+            out = self.run_network(rgb, input_depth)
+            if self.in_channels == 4:
+                out[0] = out[0] * rgb_edge            # as the reference: list * tensor is an upstream bug; kept failing loudly
+            return {'inv_depths': out}
+        if input_depth is not None:
+            raise NotImplementedError("training with input_depth needs the SAN branch (SURVEY.md 8(f-1)); "
+                                      "SemiSupEdgeModel never uses its outputs, so drop the key from the batch")
+        inv_depths, feats = self.run_network(rgb)
+        output = {'inv_depths': inv_depths}
+        if output_features:
+            output['skip_feat_rgb'] = feats
+        return output

@@ -1,0 +1,197 @@
+"""GPU parity (-m gpu): every HIP layer/loss kernel, called through the C ABI via the drop-in modules, against the
+golden vectors produced by the real reference (tests/golden).  fp32 compute mode must match to 2e-4 relative
+(max-norm; the bar the north star states is 1e-3); bf16 mode is checked at bf16-rounding tolerances."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": dict(y=2e-4, g=5e-4), "bf16": dict(y=3e-2, g=6e-2)}
+
+
+@pytest.fixture(params=["fp32", "bf16"])
+def mode(request):
+    from mindtheedge_amd import kernels as K
+    K.set_compute_dtype(request.param)
+    yield request.param
+    K.set_compute_dtype("bf16")
+
+
+def _load(module, g):
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    module.load_state_dict(sd, strict=True)
+    return module.cuda()
+
+
+def _check(module, g, mode, report=None):
+    x = g["x"].cuda().requires_grad_(True)
+    y = module(x)
+    assert rel_err(y.float().cpu(), g["y"]) < TOL[mode]["y"]
+    (y.float() * g["G"].cuda()).sum().backward()
+    assert rel_err(x.grad.cpu(), g["dx"]) < TOL[mode]["g"]
+    for n, p in module.named_parameters():
+        ref = g["g." + n]
+        err = rel_err(p.grad.cpu(), ref)
+        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 2e-2), (n, err)
+
+
+@pytest.mark.parametrize("name,args", [("conv2d_k3", (16, 32, 3, 1)), ("conv2d_k5_rgb", (3, 32, 5, 1)), ("conv2d_k7", (32, 32, 7, 1)),
+                                       ("conv2d_k3_odd65", (65, 32, 3, 1)), ("conv2d_k3_odd193", (193, 128, 3, 1))])
+def test_conv2d_block(name, args, mode):
+    from mindtheedge_amd.networks.layers.packnet.layers01 import Conv2D
+    g = load_golden("layer_" + name)
+    m = _load(Conv2D(*args), g)
+    cin = args[0]
+    x = g["x"].cuda().requires_grad_(True)
+    y = m(x)
+    assert tuple(y.shape) == tuple(g["y"].shape)
+    assert rel_err(y.float().cpu(), g["y"]) < TOL[mode]["y"]
+    (y.float() * g["G"].cuda()).sum().backward()
+    for n, p in m.named_parameters():
+        ref = g["g." + n]
+        err = rel_err(p.grad.cpu(), ref)
+        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 2e-2), (n, err)
+    # input gradient: the image entry point is not differentiable (rgb needs no grad); check dgrad through the
+    # activation entry instead
+    from mindtheedge_amd import kernels as K
+    xa = K.image_to_act(g["x"].cuda()).detach().requires_grad_(True)
+    ya = m(xa)
+    (ya.float() * g["G"].cuda()).sum().backward()
+    assert rel_err(xa.grad.float().cpu()[:, :cin], g["dx"]) < TOL[mode]["g"]
+    if K.round8(cin) != cin:
+        assert float(xa.grad.float()[:, cin:].abs().max()) == 0.0
+
+
+def _act_in(g):
+    from mindtheedge_amd import kernels as K
+    return K.image_to_act(g["x"].cuda()).detach().requires_grad_(True)
+
+
+def _check_act(module, g, mode):
+    xa = _act_in(g)
+    y = module(xa)
+    assert tuple(y.shape) == tuple(g["y"].shape)
+    assert rel_err(y.float().cpu(), g["y"]) < TOL[mode]["y"]
+    (y.float() * g["G"].cuda()).sum().backward()
+    assert rel_err(xa.grad.float().cpu(), g["dx"]) < TOL[mode]["g"]
+    for n, p in module.named_parameters():
+        ref = g["g." + n]
+        err = rel_err(p.grad.cpu(), ref)
+        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 2e-2), (n, err)
+
+
+@pytest.mark.parametrize("name,args", [("resconv_32_64", (32, 64, 1)), ("resconv_64_64", (64, 64, 1))])
+def test_residual_conv(name, args, mode):
+    from mindtheedge_amd.networks.layers.packnet.layers01 import ResidualConv
+    g = load_golden("layer_" + name)
+    _check_act(_load(ResidualConv(*args, dropout=None), g), g, mode)
+
+
+@pytest.mark.parametrize("name,cin", [("invdepth_32", 32), ("invdepth_256", 256)])
+def test_inv_depth(name, cin, mode):
+    from mindtheedge_amd.networks.layers.packnet.layers01 import InvDepth
+    g = load_golden("layer_" + name)
+    _check_act(_load(InvDepth(cin), g), g, mode)
+
+
+@pytest.mark.parametrize("name,args", [("pack3d_c16_k5", (16, 5)), ("pack3d_c32_k3", (32, 3))])
+def test_pack_layer_conv3d(name, args, mode):
+    from mindtheedge_amd.networks.layers.packnet.layers01 import PackLayerConv3d
+    g = load_golden("layer_" + name)
+    _check_act(_load(PackLayerConv3d(*args, d=4), g), g, mode)
+
+
+@pytest.mark.parametrize("name,args", [("unpack3d_64_32", (64, 32, 3)), ("unpack3d_32_16", (32, 16, 3))])
+def test_unpack_layer_conv3d(name, args, mode):
+    from mindtheedge_amd.networks.layers.packnet.layers01 import UnpackLayerConv3d
+    g = load_golden("layer_" + name)
+    _check_act(_load(UnpackLayerConv3d(*args, d=4), g), g, mode)
+
+
+def test_residual_conv_dropout_mask_matches_oracle(mode):
+    """Dropout2d on the shortcut = per-(sample, channel) scale; compare with the oracle given the same mask."""
+    from mindtheedge_amd.networks.layers.packnet.layers01 import ResidualConv
+    from mindtheedge_amd import kernels as K
+    from oracle import packnet_oracle as po
+    g = load_golden("layer_resconv_32_64")
+    m = _load(ResidualConv(32, 64, 1, dropout=None), g)
+    P = {"m." + k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    keep = (torch.rand(2, 64, generator=torch.Generator().manual_seed(3)) >= 0.5).float() * 2.0
+    ref = po.residual_conv(g["x"], P, "m", keep)
+    y = m(K.image_to_act(g["x"].cuda()), channel_scale=keep.cuda())
+    assert rel_err(y.float().cpu(), ref) < TOL[mode]["y"]
+
+
+# ------------------------------------------------------------------------------------------ losses (fp32 always)
+def test_grad_layer_maps():
+    from mindtheedge_amd.losses.grad_loss import GradLayer
+    g = load_golden("loss_gradlayer")
+    gl = GradLayer()
+    x = g["x"].cuda()
+    assert rel_err(gl(x, None)[0].cpu(), g["mag"]) < 1e-5
+    assert rel_err(gl(x, g["normal"].cuda())[0].cpu(), g["mag_n"]) < 1e-5
+    assert rel_err(gl(x, g["normal_edges"].cuda())[0].cpu(), g["mag_e"]) < 1e-5      # bin-edge angles pick the same kernel
+
+
+@pytest.mark.parametrize("case", ["nomask", "binmask", "onesmask", "allneg", "nonormal", "allpos"])
+def test_grad_loss_cases(case):
+    from mindtheedge_amd.losses.grad_loss import GradLoss
+    from oracle import loss_oracle as lo
+    g = load_golden("loss_gradloss")
+    head = GradLoss("cross_entropy", True, [], 10.0, 1.0)
+    edge = {"allneg": torch.zeros_like(g["edge"]), "allpos": torch.ones_like(g["edge"])}.get(case, g["edge"]).cuda()
+    mask = {"binmask": g["mask"], "onesmask": torch.ones_like(g["mask"])}.get(case)
+    mask = None if mask is None else mask.cuda()
+    normal = None if case == "nonormal" else g["normal"].cuda()
+    d = lo.inv2depth(g["inv"]).cuda().requires_grad_(True)
+    loss, gmap = head(d, edge, mask, True, True, 4, normal)
+    assert rel_err(loss.cpu(), g["loss_" + case]) < 1e-4
+    assert rel_err(gmap.cpu(), g["g_" + case]) < 1e-5
+    loss.backward()
+    assert rel_err(d.grad.cpu(), g["ddepth_" + case]) < 2e-4
+    # fused inv2depth variant: same loss, chain rule through 1/clamp(inv)
+    inv = g["inv"].cuda().requires_grad_(True)
+    loss2, _ = head(inv, edge, mask, True, True, 4, normal, from_inv_depth=True, return_grad_map=False)
+    assert rel_err(loss2.cpu(), g["loss_" + case]) < 1e-4
+    loss2.backward()
+    ref = g["ddepth_" + case] * (-(lo.inv2depth(g["inv"]) ** 2))
+    assert rel_err(inv.grad.cpu(), ref) < 2e-4
+
+
+def test_grad_loss_probability_input():
+    from mindtheedge_amd.losses.grad_loss import GradLoss
+    g = load_golden("loss_gradloss")
+    head = GradLoss("cross_entropy", True, [], 10.0, 1.0)
+    p = g["prob"].cuda().requires_grad_(True)
+    loss, _ = head(p, g["edge"].cuda(), None, False, False, 4, None)
+    assert rel_err(loss.cpu(), g["loss_prob"]) < 1e-4
+    loss.backward()
+    assert rel_err(p.grad.cpu(), g["dprob"]) < 2e-4
+
+
+def test_silog_supervised_loss():
+    from mindtheedge_amd.losses.supervised_loss import SupervisedLoss
+    g = load_golden("loss_silog")
+    sup = SupervisedLoss(supervised_method="sparse-silog", supervised_num_scales=1)
+    inv = g["inv"].cuda().requires_grad_(True)
+    out = sup([inv], g["depth"].cuda())
+    assert rel_err(out["loss"].cpu(), g["loss"]) < 1e-4
+    out["loss"].sum().backward()
+    assert rel_err(inv.grad.cpu(), g["dinv"]) < 2e-4
+    empty = sup([g["inv"].cuda()], torch.zeros_like(g["depth"]).cuda())
+    assert math.isnan(float(empty["loss"]))
+
+
+def test_adam_flat_steps():
+    from mindtheedge_amd import kernels as K
+    g = load_golden("adam_steps")
+    for i in range(3):
+        p = g["p%d_init" % i].clone().cuda().flatten()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in range(3):
+            K.adam_step_flat(p, g["g%d_s%d" % (i, step)].cuda().flatten().contiguous(), m, v, step + 1, lr=1e-4)
+            assert rel_err(p.cpu(), g["p%d_s%d" % (i, step)].flatten()) < 1e-6
