@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- training images/sec of PackNet-SAN + depth-edge loss at 384x1280, bf16 compute, on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = zero_grad + forward (dropout 0.5, random whole-batch flip) + silog/edge loss + backward + bucketed RCCL
+gradient all-reduce (N > 1) + fused Adam, on a synthetic batch of 8 frames per GPU that is already resident in HBM
+(SURVEY.md 8(d) recipe).  Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel family
+(MFMA implicit-GEMM convolutions; algorithmic FLOPs / HIP-event time measured inside the timed region) and, at N = 1,
+"cpu_baseline": the CPU oracle (oracle/) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+class ConvTimer:
+    """HIP-event bracket around every conv launch (events are recorded on the stream the kernels run on)."""
+
+    def __init__(self, K):
+        self.K, self.records, self.enabled = K, [], False
+        lib = K.lib
+        self._orig = {}
+        for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad"):
+            self._orig[name] = getattr(lib, name)
+
+    def install(self):
+        K = self.K
+        outer = self
+
+        class Proxy:
+            def __getattr__(self_, name):
+                fn = getattr(outer._lib, name)
+                if name not in outer._orig or not outer.enabled:
+                    return fn
+
+                def timed(*args):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn(*args)
+                    e1.record()
+                    if name == "mte_conv2d_igemm":
+                        B, H, W, Cin_p, N, KH, KW = args[7:14]
+                    else:
+                        B, H, W, Cin_p, N, KH, KW = args[5:12]
+                    outer.records.append((name, e0, e1, 2.0 * B * H * W * Cin_p * N * KH * KW))
+                return timed
+        self._lib = K.lib
+        K.lib = Proxy()
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, fl in self.records:
+            d = out.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += fl
+        return out
+
+
+def conv_flops_per_image(H, W):
+    """Algorithmic conv FLOPs per image forward (285.27 GMAC at 384x1280, scales with pixels)."""
+    return 2.0 * 285.27e9 * (H * W) / (384.0 * 1280.0)
+
+
+def device_batch(B, H, W, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g, device=device)
+    batch = {"rgb": r(B, 3, H, W)}
+    batch["depth"] = (r(B, 1, H, W) < 0.05).float() * (1.0 + 79.0 * r(B, 1, H, W))
+    for s in range(4):
+        sfx = "" if s == 0 else "_%d" % s
+        h, w = H >> s, W >> s
+        batch["edge" + sfx] = (r(B, 1, h, w) < 0.03).float() * r(B, 1, h, w)
+        batch["normal" + sfx] = (r(B, 1, h, w) * 2 - 1) * math.pi
+    return batch
+
+
+def cpu_baseline(H, W, steps):
+    """The CPU oracle (verified against the reference's golden vectors) timed on this host: B=1 training step,
+    fp32, all physical cores."""
+    from oracle import packnet_oracle as po, loss_oracle as lo
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    cores = min(cores, 128)
+    torch.set_num_threads(cores)
+    P = {k: v.clone().requires_grad_(True) for k, v in po.reference_init_params().items()}
+    names = [k for k in P if k not in ("weight", "bias")]
+    opt = torch.optim.Adam([P[k] for k in names], lr=1e-4)
+    batch = lo.synthetic_batch(1, H, W, seed=0)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        g = torch.Generator().manual_seed(it)
+        keeps = {}
+        for li, nb in zip((2, 3, 4, 5), po.NUM_BLOCKS):
+            c = (po.N2, po.N3, po.N4, po.N5)[li - 2]
+            for b in range(nb):
+                keeps["encoder.conv%d.%d" % (li, b)] = (torch.rand(1, c, generator=g) >= 0.5).float() * 2.0
+        inv = po.packnet_san01(batch["rgb"], P, training=True, channel_keeps=keeps)["inv_depths"]
+        loss = lo.semisup_edge_model_loss(inv, batch)["loss"].sum()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / max(1, len(times) - 1)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": 1.0 / t, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed B=1 %dx%d fp32 training steps (fwd+loss+bwd+Adam) of the CPU oracle after 1 warm-up; %s" % (steps, H, W, model)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "mindtheedge_amd", "csrc", "libmte_hip.so")):
+        if rank == 0:
+            ge.build()
+        if world > 1:
+            dist.barrier()
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
+    from mindtheedge_amd.models.SemiSupEdgeModel import SemiSupEdgeModel
+    from mindtheedge_amd.losses.grad_loss import GradLoss
+    from mindtheedge_amd.trainers.data_parallel import FlatParameters, BucketedAllReduce, FusedAdam, broadcast_parameters
+    import random
+
+    K.set_compute_dtype(args.dtype)
+    torch.manual_seed(42)                                # default_config.py:16 seed; xavier init per PackNetSAN01.init_weights
+    net = PackNetSAN01(dropout=0.5, version="1A").to(dev)
+    model = SemiSupEdgeModel(supervised_loss_weight=1.0, depth_edges_loss_weight=1.0, supervised_method="sparse-silog",
+                             supervised_num_scales=1, edges_depth_edge_loss_all_scales=True, flip_lr_prob=0.5)
+    model.add_depth_net(net)
+    model.add_edge_loss(GradLoss("cross_entropy", True, [], 10.0, 1.0))
+    B, H, W = args.batch, args.height, args.width
+    batch = device_batch(B, H, W, seed=1234 + rank, device=dev)
+    random.seed(100 + rank)
+    torch.manual_seed(1000 + rank)                       # decorrelated per-rank dropout masks
+
+    timer = None
+    if not args.no_kernel_timing:
+        timer = ConvTimer(K)
+        timer.install()
+
+    if args.mode == "train":
+        model.train()
+        flat = FlatParameters(net.parameters())
+        broadcast_parameters(flat)
+        reducer = BucketedAllReduce(flat) if world > 1 else None
+        opt = FusedAdam(flat, lr=1e-4, reducer=reducer)
+
+        def step():
+            opt.zero_grad()
+            out = model(batch)
+            out["loss"].backward()
+            opt.step()
+            return out["loss"]
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model(batch)["inv_depths"][0][0]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        last = step()
+    sync()
+    if timer:
+        timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if timer:
+        timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final = float(last.detach().float().sum()) if args.mode == "train" else float(last.float().mean())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        res = {"metric": "training images/sec, PackNet-SAN+edge-loss 384x1280 bf16" if args.mode == "train"
+               else "inference images/sec, PackNet-SAN 384x1280 bf16",
+               "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic (SURVEY.md 8(d): rgb U[0,1), 5% sparse depth, soft thin edges, uniform normals; xavier init seed 42)",
+               "config": {"workload": ("T8: PackNet-SAN + silog + 4-scale depth-edge loss training step" if args.mode == "train" else
+                                       "I%d: PackNet-SAN depth inference" % B) + ", %dx%d, %d frames/GPU, dropout 0.5, flip 0.5" % (H, W, B),
+                          "global_batch": B * world, "height": H, "width": W,
+                          "parallelism": "dp%d (bucketed RCCL all-reduce overlapped with backward)" % world if world > 1 else "single GPU"},
+               "final_loss" if args.mode == "train" else "mean_inv_depth": final}
+        passes = 3.0 if args.mode == "train" else 1.0
+        step_flops = conv_flops_per_image(H, W) * B * passes
+        res["mfma_fraction_of_step"] = step_flops / (ms * 1e-3) / (BF16_DENSE_PEAK_TFLOPS * 1e12)
+        if timer:
+            s = timer.summary()
+            tot_t = sum(v[1] for v in s.values())
+            tot_f = sum(v[2] for v in s.values())
+            n = sum(v[0] for v in s.values())
+            if tot_t > 0:
+                ach = tot_f / tot_t / 1e12
+                res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                                   "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
+                                   "unit": "TFLOP/s", "frac": ach / (BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else 157.3),
+                                   "traffic": None, "launches_per_step": n / args.steps,
+                                   "avg_launch_ms": tot_t / n * 1e3, "conv_ms_per_step": tot_t / args.steps * 1e3,
+                                   "executed_flops_per_step": tot_f / args.steps, "algorithmic_flops_per_step": step_flops,
+                                   "by_kernel": {k: {"launches_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps * 1e3,
+                                                     "tflops": v[2] / v[1] / 1e12 if v[1] > 0 else None} for k, v in s.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(H, W, args.cpu_steps)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,9 @@ class _Lib:
             if not os.path.exists(LIB_PATH):
                 raise MteError("libmte_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "or `python mindtheedge_amd/_build.py`; there is no CPU/eager fallback." % LIB_PATH)
+            # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be in the process before this library so that
+            # both resolve to ONE HIP runtime (loading /opt/rocm's copy first leaves torch's runtime without a device)
+            import torch  # noqa: F401
             dll = ctypes.CDLL(LIB_PATH)
             for name, args in self._protos.items():
                 fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #define MTE_OK 0
 #define MTE_ERR_ARG (-1)
@@ -91,6 +92,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 static inline int mte_check_launch() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "[libmte_hip] launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
     return e == hipSuccess ? MTE_OK : MTE_ERR_LAUNCH;
 }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -469,6 +469,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, lo
     for (int i = 0; i < PER16; ++i) acc[i] = 0.f;
     const int cc = tid % cpr;                        // requires cpr <= 256 and 256 % cpr == 0 or we guard
     const int rlane = tid / cpr, rstep = 256 / cpr;
+    extern __shared__ float s_col[];                  // [N]
+    for (int i = tid; i < N; i += 256) s_col[i] = 0.f;
+    __syncthreads();
     if (rlane < rstep) {
         for (long m = (long)blockIdx.x * rstep + rlane; m < M; m += (long)gridDim.x * rstep) {
             float v[PER16];
@@ -477,8 +480,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, lo
             for (int i = 0; i < PER16; ++i) acc[i] += v[i];
         }
 #pragma unroll
-        for (int i = 0; i < PER16; ++i) atomicAdd(out + cc * PER16 + i, acc[i]);
+        for (int i = 0; i < PER16; ++i) atomicAdd(&s_col[cc * PER16 + i], acc[i]);      // LDS atomics
     }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) atomicAdd(out + i, s_col[i]);                     // one global atomic per column per block
 }
 
 }  // namespace
@@ -488,6 +493,7 @@ extern "C" {
 // y[B,H,W,(ldy)] = conv(x[B,H,W,(ldx)], wpack[N][KH*KW][Cin_p]) + bias; stride 1, zero pad k/2.
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
@@ -500,6 +506,7 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
 // dw_stage[N][KH*KW][Cin_p] (fp32) = sum over pixels of dy (x) shifted x.
 int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dy || !dw_stage) return MTE_ERR_ARG;
     if (Cin_p % 8 != 0 || N % 8 != 0) return MTE_ERR_ARG;
     WgradArgs a{x, ldx, dy, ldy, dw_stage, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, 0, 0, 0};
@@ -510,6 +517,7 @@ int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* d
 
 int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout, int Cin, int KH, int KW,
                           int Cin_p, int Cout_p, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!w_oihw || !wfwd) return MTE_ERR_ARG;
     const long n = (long)Cout * KH * KW * Cin_p + (wbwd ? (long)Cin_p * KH * KW * Cout_p : 0);
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
@@ -521,6 +529,7 @@ int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout,
 }
 
 int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dw_stage || !dw_oihw) return MTE_ERR_ARG;
     const long n = (long)Cout * Cin * KH * KW;
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
@@ -530,15 +539,17 @@ int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int C
 
 // out[N] (fp32, zeroed here) = column sums of y[M][N] (bias gradient). N multiple of 8, N/8 must divide 256 or be <= 256.
 int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y || !out || N % 8 != 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (N / per16 > 256) return MTE_ERR_UNSUPPORTED;
     if (hipMemsetAsync(out, 0, sizeof(float) * N, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     const int rstep = 256 / (N / per16);
     long want = (M + rstep - 1) / rstep;
+    want = (want + 31) / 32;                          // >= 32 rows per thread
     const int grid = (int)(want > 1024 ? 1024 : (want < 1 ? 1 : want));
-    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)y, ld, M, N, out);
-    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)y, ld, M, N, out);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), sizeof(float) * N, stream, (const bf16_t*)y, ld, M, N, out);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), sizeof(float) * N, stream, (const float*)y, ld, M, N, out);
     return mte_check_launch();
 }
 

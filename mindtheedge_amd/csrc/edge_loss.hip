@@ -277,6 +277,7 @@ extern "C" {
 // Forward pass of one scale.  sums: [B*6 + 4] doubles (zeroed here).  gmap nullable.
 int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal, const float* mask, double* sums, float* gmap,
                       int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!pred || !edge || !sums) return MTE_ERR_ARG;
     if (hipMemsetAsync(sums, 0, sizeof(double) * (B * 6 + 4), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     EdgeArgs a{}; a.pred = pred; a.edge = edge; a.normal = normal; a.mask = mask; a.sums = sums; a.gmap = gmap;
@@ -287,6 +288,7 @@ int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal,
 // loss_this (nullable) <- weight * balanced BCE;  *loss_acc (nullable) += out_scale * loss;  coef: [2B + 1] floats
 int mte_edge_loss_finalize(const double* sums, int B, long numel, float weight, float pos_to_neg, int has_mask,
                            float out_scale, float* loss_acc, float* loss_this, float* coef, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!sums || !coef) return MTE_ERR_ARG;
     hipLaunchKernelGGL(edge_loss_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, B, numel, weight, pos_to_neg, has_mask, out_scale, loss_acc, loss_this, coef);
     return mte_check_launch();
@@ -294,6 +296,7 @@ int mte_edge_loss_finalize(const double* sums, int B, long numel, float weight, 
 // dpred <- gout * d loss / d pred  (gout: device scalar, nullable = 1)
 int mte_edge_loss_bwd(const float* pred, const float* edge, const float* normal, const float* mask, const float* coef, const float* gout,
                       float* dpred, int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!pred || !edge || !coef || !dpred) return MTE_ERR_ARG;
     EdgeArgs a{}; a.pred = pred; a.edge = edge; a.normal = normal; a.mask = mask; a.coef = coef; a.gout = gout; a.dpred = dpred;
     a.B = B; a.H = H; a.W = W; a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.thresh = thresh;
@@ -303,6 +306,7 @@ int mte_edge_loss_bwd(const float* pred, const float* edge, const float* normal,
 
 // sums[3] doubles (zeroed here); aux[2] floats
 int mte_silog_fwd(const float* inv, const float* depth, long n, double* sums, float out_scale, float* loss_acc, float* loss_this, float* aux, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!inv || !depth || !sums || !aux) return MTE_ERR_ARG;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 3, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     long g = (n + 255) / 256; if (g > 1024) g = 1024; if (g < 1) g = 1;
@@ -311,6 +315,7 @@ int mte_silog_fwd(const float* inv, const float* depth, long n, double* sums, fl
     return mte_check_launch();
 }
 int mte_silog_bwd(const float* inv, const float* depth, const float* aux, const float* gout, float* dinv, long n, int accumulate, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!inv || !depth || !aux || !dinv) return MTE_ERR_ARG;
     long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
     hipLaunchKernelGGL(silog_bwd_kernel, dim3((unsigned)g), dim3(256), 0, stream, inv, depth, aux, gout, dinv, n, accumulate);

@@ -213,6 +213,7 @@ extern "C" {
 
 int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,
                      int B, int H, int W, int C, float min_depth, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !w || !bias || !out || !head_ok(C)) return MTE_ERR_ARG;
     HeadArgs a{}; a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.C = C;
     a.inv_min_depth = 1.f / min_depth; a.npix = (long)B * H * W;
@@ -226,6 +227,7 @@ int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias,
 // dlogit_scratch [B*H*W] fp32; dwb [C*9 + 1] fp32 (zeroed here): dw (OIHW order, O = 1) followed by db
 int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_out, const float* dout, float* dlogit_scratch,
                      void* dx, long lddx, float* dwb, int B, int H, int W, int C, float min_depth, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !w || !inv_out || !dout || !dlogit_scratch || !dx || !dwb || !head_ok(C)) return MTE_ERR_ARG;
     const long npix = (long)B * H * W;
     if (hipMemsetAsync(dwb, 0, sizeof(float) * (C * 9 + 1), stream) != hipSuccess) return MTE_ERR_LAUNCH;
@@ -241,6 +243,7 @@ int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_o
 }
 
 int mte_nchw_to_nhwc(const float* src, void* dst, long ldd, int B, int C, int H, int W, int Cp, int flip_w, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!src || !dst || Cp % 8 != 0 || Cp < C) return MTE_ERR_ARG;
     const int grid = stream_grid((long)B * H * W);
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, src, (bf16_t*)dst, B, C, H, W, Cp, ldd, flip_w);
@@ -249,6 +252,7 @@ int mte_nchw_to_nhwc(const float* src, void* dst, long ldd, int B, int C, int H,
 }
 
 int mte_upsample_inv_fwd(const float* inv, void* dst, long ldd, int B, int h, int w, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!inv || !dst) return MTE_ERR_ARG;
     const int grid = stream_grid((long)B * 4 * h * w);
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(upsample_inv_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, inv, (bf16_t*)dst, ldd, B, h, w);
@@ -256,6 +260,7 @@ int mte_upsample_inv_fwd(const float* inv, void* dst, long ldd, int B, int h, in
     return mte_check_launch();
 }
 int mte_upsample_inv_bwd(const void* dsrc, long lds_, float* dinv, int B, int h, int w, int accumulate, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dsrc || !dinv) return MTE_ERR_ARG;
     const int grid = stream_grid((long)B * h * w);
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(upsample_inv_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dsrc, lds_, dinv, B, h, w, accumulate);
@@ -264,6 +269,7 @@ int mte_upsample_inv_bwd(const void* dsrc, long lds_, float* dinv, int B, int h,
 }
 
 int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!src || !dst || C % 8 != 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     const int grid = stream_grid(npix * (C / per16));
@@ -276,6 +282,7 @@ int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix
 // (1/world_size when the all-reduce summed instead of averaged; 1 otherwise).
 int mte_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   int step, float gscale, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!p || !g || !m || !v || n <= 0 || step < 1) return MTE_ERR_ARG;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,

@@ -227,6 +227,7 @@ extern "C" {
 // stats[B][16][2] (double; zeroed here) <- per-(sample, group) sum and sum of squares of v = y1 + scale2*y2
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
                  int B, int HW, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     if (hipMemsetAsync(stats, 0, sizeof(double) * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
@@ -241,6 +242,7 @@ int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float
 int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, const double* stats,
                    const float* gamma, const float* beta, void* z, long ldz,
                    int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y1 || !stats || !gamma || !beta || !z || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
     a.gamma = gamma; a.beta = beta; a.z = z; a.ldz = ldz; a.B = B; a.HW = HW; a.C = C; a.eps = eps;
@@ -258,6 +260,7 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
                    const double* stats, const float* gamma, const float* beta, float* red,
                    void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta,
                    int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dz || !y1 || !stats || !gamma || !beta || !red || !d1 || !dgamma || !dbeta || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     if (hipMemsetAsync(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;

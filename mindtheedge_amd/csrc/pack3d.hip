@@ -408,6 +408,7 @@ extern "C" {
 // out[B,H/2,W/2,16C] = conv3d(pixel_unshuffle(x[B,H,W,C]))            (PackLayerConv3d up to its Conv2D)
 int mte_pack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, void* out, long ldo,
                    int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !w3 || !b3 || !out || !p3_ok(C) || (H & 1) || (W & 1)) return MTE_ERR_ARG;
     P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
@@ -415,6 +416,7 @@ int mte_pack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, vo
 }
 int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, long lddx,
                         int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
@@ -423,6 +425,7 @@ int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, l
 // dwb[112] (fp32, zeroed here): [0..107] = dw3, [108..111] = db3
 int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
                           int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dout || !dwb || !p3_ok(C)) return MTE_ERR_ARG;
     if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
@@ -434,6 +437,7 @@ int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, f
 // out[B,2H,2W,C] = pixel_shuffle(conv3d(x[B,H,W,C]))                   (UnpackLayerConv3d after its Conv2D)
 int mte_unpack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, void* out, long ldo,
                      int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !w3 || !b3 || !out || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * H * W * (C / 8);
@@ -441,6 +445,7 @@ int mte_unpack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, 
 }
 int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, long lddx,
                           int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * H * W * (C / 8);
@@ -448,6 +453,7 @@ int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx,
 }
 int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
                             int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dout || !dwb || !p3_ok(C)) return MTE_ERR_ARG;
     if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;

@@ -36,7 +36,7 @@ def _check(module, g, mode, report=None):
     for n, p in module.named_parameters():
         ref = g["g." + n]
         err = rel_err(p.grad.cpu(), ref)
-        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 2e-2), (n, err)
+        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 1e-1), (n, err)
 
 
 @pytest.mark.parametrize("name,args", [("conv2d_k3", (16, 32, 3, 1)), ("conv2d_k5_rgb", (3, 32, 5, 1)), ("conv2d_k7", (32, 32, 7, 1)),
@@ -54,7 +54,7 @@ def test_conv2d_block(name, args, mode):
     for n, p in m.named_parameters():
         ref = g["g." + n]
         err = rel_err(p.grad.cpu(), ref)
-        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 2e-2), (n, err)
+        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 1e-1), (n, err)
     # input gradient: the image entry point is not differentiable (rgb needs no grad); check dgrad through the
     # activation entry instead
     from mindtheedge_amd import kernels as K
@@ -81,7 +81,7 @@ def _check_act(module, g, mode):
     for n, p in module.named_parameters():
         ref = g["g." + n]
         err = rel_err(p.grad.cpu(), ref)
-        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 2e-2), (n, err)
+        assert err < TOL[mode]["g"] or float((p.grad.cpu() - ref).abs().max()) < (1e-5 if mode == "fp32" else 1e-1), (n, err)
 
 
 @pytest.mark.parametrize("name,args", [("resconv_32_64", (32, 64, 1)), ("resconv_64_64", (64, 64, 1))])
