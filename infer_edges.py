@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""infer_edges.py -- depth inference core of the reference script (/root/reference/infer_edges.py:237-366, rows H3):
+image [1,3,H,W] in [0,1] -> model_wrapper.depth(image)['inv_depths'][0][0] -> inv2depth -> .npy float32 metres.
+The reference's BSDS / Canny evaluation around it is out of scope (py-bsds500, OpenCV)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def infer_depth(model_wrapper, image):
+    """image: fp32 [B,3,H,W] on the GPU, H and W multiples of 32 -> depth [B,1,H,W] fp32 (metres)."""
+    import torch
+    from mindtheedge_amd.utils.depth import inv2depth
+    model_wrapper.eval()
+    with torch.no_grad():
+        pred_inv_depth = model_wrapper.depth(image, rgb_edge=None)['inv_depths'][0][0]
+    return inv2depth(pred_inv_depth)
+
+
+def main():
+    ap = argparse.ArgumentParser(description='PackNet-SAN depth inference on MI355X')
+    ap.add_argument('--config', type=str, required=True, help='YAML (model.depth_net.checkpoint_path may name a .ckpt)')
+    ap.add_argument('--input', type=str, nargs='*', default=[], help='.npy images [3,H,W] or [H,W,3] in [0,1] (or uint8)')
+    ap.add_argument('--output', type=str, default='results')
+    ap.add_argument('--synthetic', type=int, default=0, help='number of synthetic frames of the configured shape')
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from mindtheedge_amd.utils.config import load_config
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    config = load_config(args.config)
+    if not os.path.exists(config.model.depth_net.checkpoint_path or ''):
+        config.model.depth_net.checkpoint_path = ''
+    wrapper = ModelWrapper(config).cuda()
+    os.makedirs(args.output, exist_ok=True)
+    shape = config.datasets.augmentation.image_shape
+    H, W = eval(shape) if isinstance(shape, str) else tuple(shape)
+    images = []
+    for p in args.input:
+        a = np.load(p).astype(np.float32)
+        if a.shape[-1] == 3:
+            a = a.transpose(2, 0, 1)
+        images.append(torch.from_numpy(a / (255.0 if a.max() > 1.5 else 1.0)))
+    g = torch.Generator().manual_seed(0)
+    images += [torch.rand(3, H, W, generator=g) for _ in range(args.synthetic)]
+    for ctr, img in enumerate(images):
+        depth = infer_depth(wrapper, img.unsqueeze(0).cuda())
+        np.save(os.path.join(args.output, '%08d_regular.npy' % ctr), depth[0, 0].cpu().numpy())
+    print('wrote %d depth maps to %s' % (len(images), args.output))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,78 @@
+"""One-process-per-GPU trainer: the MI355X replacement of CommonTrainer/HorovodTrainer
+(packnet_sfm/trainers/common_trainer.py:22-185, horovod_trainer.py).  Same surface: ``Trainer(**config.arch,
+checkpoint=None).fit(module)``, ``proc_rank``, ``world_size``, ``is_rank_0``.  The inner loop is the reference's
+zero_grad -> to-device -> training_step -> backward -> optimizer.step, minus its 4-6 ``.item()`` host syncs per step:
+running means are accumulated on the device and read once per ``log_every`` steps."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def sample_to_cuda(data, device):
+    if isinstance(data, dict):
+        return {k: sample_to_cuda(v, device) for k, v in data.items()}
+    if isinstance(data, (list, tuple)):
+        return [sample_to_cuda(v, device) for v in data]
+    if torch.is_tensor(data):
+        return data.to(device, non_blocking=True)
+    return data
+
+
+class Trainer:
+    def __init__(self, min_epochs=0, max_epochs=50, validate_first=False, checkpoint=None, log_every=50, **kwargs):
+        self.min_epochs, self.max_epochs, self.validate_first = min_epochs, max_epochs, validate_first
+        self.checkpoint, self.log_every = checkpoint, log_every
+        self.distributed = int(os.environ.get('WORLD_SIZE', '1')) > 1
+        if self.distributed and not dist.is_initialized():
+            local = int(os.environ.get('LOCAL_RANK', '0'))
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        self.device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+
+    @property
+    def proc_rank(self):
+        return dist.get_rank() if dist.is_initialized() else 0
+
+    @property
+    def world_size(self):
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    @property
+    def is_rank_0(self):
+        return self.proc_rank == 0
+
+    def fit(self, module, train_dataloader, epochs=None):
+        if self.device is None:
+            raise RuntimeError("mindtheedge_amd trains on MI355X GPUs only")
+        module.to(self.device)
+        optimizer, scheduler = module.configure_optimizers()
+        history = []
+        for epoch in range(module.current_epoch, epochs if epochs is not None else self.max_epochs):
+            if hasattr(getattr(train_dataloader, 'sampler', None), 'set_epoch'):
+                train_dataloader.sampler.set_epoch(epoch)
+            history.append(self.train(train_dataloader, module, optimizer))
+            module.current_epoch += 1
+            scheduler.step()
+        return history
+
+    def train(self, dataloader, module, optimizer):
+        module.train()
+        run = torch.zeros(3, device=self.device)               # loss, supervised, edge running sums (device side)
+        n, last = 0, None
+        for i, batch in enumerate(dataloader):
+            optimizer.zero_grad()
+            batch = sample_to_cuda(batch, self.device)
+            output = module.training_step(batch, i, None)
+            output['loss'].backward()
+            optimizer.step()
+            m = output['metrics']
+            run += torch.stack([output['loss'].detach().sum(), m['supervised_loss'].sum(), m['edge_loss'].sum()])
+            n += 1
+            if self.is_rank_0 and self.log_every and n % self.log_every == 0:
+                last = (run / n).tolist()                       # the only host sync
+                print('step {} | Avg. {:.4f} | Sup. {:.4f} | Edge RGB {:.4f}'.format(n, *last), flush=True)
+        if n:
+            last = (run / n).tolist()
+        return {'steps': n, 'avg_loss': last[0] if last else None, 'avg_supervised': last[1] if last else None,
+                'avg_edge': last[2] if last else None}

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""train_edges.py <config.yaml> -- entry point with the reference's calling convention (/root/reference/train_edges.py:17-69):
+parse the YAML over the defaults, build ModelWrapper (registry -> SemiSupEdgeModel + PackNetSAN01 + GradLoss), fit.
+Multi-GPU: `python -m torch.distributed.run --nproc-per-node N train_edges.py <yaml>` (one process per GPU, RCCL).
+Datasets are outside this build's scope: `--synthetic` trains on synthetic frames of the
+configured image_shape; otherwise pass `--data module:callable` returning an iterable of batch dicts."""
+import argparse
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser(description='PackNet-SAN + depth-edge-loss training on MI355X')
+    ap.add_argument('file', type=str, help='Input file (.yaml)')
+    ap.add_argument('--synthetic', action='store_true')
+    ap.add_argument('--steps', type=int, default=20, help='steps per epoch for --synthetic')
+    ap.add_argument('--epochs', type=int, default=1)
+    ap.add_argument('--data', type=str, default=None)
+    args = ap.parse_args()
+    assert args.file.endswith('.yaml'), 'You need to provide a .yaml file'
+    import torch
+    from mindtheedge_amd.utils.config import load_config
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.trainers.trainer import Trainer
+    from mindtheedge_amd.utils.synthetic import SyntheticLoader
+    config = load_config(args.file)
+    config.model.depth_net.checkpoint_path = config.model.depth_net.checkpoint_path if os.path.exists(
+        config.model.depth_net.checkpoint_path or '') else ''
+    trainer = Trainer(**config.arch)
+    wrapper = ModelWrapper(config)
+    H, W = tuple(config.datasets.augmentation.image_shape) if not isinstance(config.datasets.augmentation.image_shape, str) \
+        else eval(config.datasets.augmentation.image_shape)
+    if args.data:
+        mod, fn = args.data.split(':')
+        loader = getattr(importlib.import_module(mod), fn)(config, trainer.proc_rank, trainer.world_size)
+    else:
+        assert args.synthetic, 'no dataset: pass --synthetic or --data module:callable'
+        loader = SyntheticLoader(config.datasets.train.batch_size, H, W, args.steps, trainer.device, trainer.proc_rank)
+    hist = trainer.fit(wrapper, loader, epochs=args.epochs)
+    if trainer.is_rank_0:
+        print(hist)
+
+
+if __name__ == '__main__':
+    main()
