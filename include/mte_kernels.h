@@ -33,9 +33,12 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
 
 /* ---- convolution: nn.Conv2d(k, stride 1) + ConstantPad2d(k//2)  (networks/layers/packnet/layers01.py:29-31,61,116-117)
  * y = conv(x, wpack) + bias.  wpack = [N][KH*KW][Cin_p] in `dtype` (see mte_pack_conv_weights).
- * Also the data-gradient: call with the "backward" pack and x := dy. */
+ * Also the data-gradient: call with the "backward" pack and x := dy.
+ * workspace (nullable): fp32 scratch of >= B*H*W*N elements; when given, shapes with few output tiles and a long
+ * reduction (pack4/pack5.conv at low resolution) are split along K over several workgroups. */
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
-                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
+                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
+                     float* workspace, long workspace_elems, mte_stream_t stream);
 /* weight gradient of the same conv: dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) */
 int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
@@ -46,6 +49,17 @@ int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout,
 int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, mte_stream_t stream);
 /* out[N] = column sums of y[M][N] (conv bias gradient) */
 int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, mte_stream_t stream);
+
+/* ---- LDS-patch convolution for the high-resolution, few-channel layers (bf16, C_out <= 64, W % 32 == 0, k in {1,3,5,7}):
+ * same math as mte_conv2d_igemm / mte_conv2d_wgrad, different tiling (the 8x32-pixel tile's input patch is staged once
+ * per 32-channel slice and reused by all k*k taps).  *_supported and *_pack_elems are queries (they return a value). */
+int mte_conv2d_patch_supported(int W, int Cin_p, int N, int KH, int KW, int dtype);
+long mte_conv2d_patch_pack_elems(int Cin_p, int N, int KH, int KW);
+int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
+int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
+int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage,
+                           int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 
 /* ---- GroupNorm(16, C) + ELU, optionally over y1 + scale2[b,c]*y2 (residual tail with Dropout2d)
  *      (layers01.py:32-38 Conv2D; layers01.py:62-73 ResidualConv) */

@@ -18,21 +18,27 @@ class MteError(RuntimeError):
     pass
 
 
+RETURNS = {}
+# entry points that return a value (capability / size queries) instead of an error code
+QUERIES = ("mte_conv2d_patch_supported", "mte_conv2d_patch_pack_elems")
+
+
 def parse_header(path=HEADER):
-    """-> {name: [(ctype, argname), ...]} for every `int mte_*(...)` prototype."""
+    """-> {name: [(ctype, argname), ...]} for every `int|long mte_*(...)` prototype (RETURNS[name] = restype)."""
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(mte_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(int|long)\s+(mte_\w+)\s*\(([^)]*)\)\s*;", text):
+        RETURNS[m.group(2)] = ctypes.c_long if m.group(1) == "long" else ctypes.c_int
         args = []
-        for a in m.group(2).split(","):
+        for a in m.group(3).split(","):
             a = " ".join(a.split())
             if "*" in a:
                 args.append((ctypes.c_void_p, a.split("*")[-1].strip()))
             else:
                 ty, name = a.rsplit(" ", 1)
                 args.append((_CTYPES[ty.replace("const ", "").strip()], name))
-        protos[m.group(1)] = args
+        protos[m.group(2)] = args
     return protos
 
 
@@ -53,13 +59,15 @@ class _Lib:
             for name, args in self._protos.items():
                 fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
                 fn.argtypes = [t for t, _ in args]
-                fn.restype = ctypes.c_int
+                fn.restype = RETURNS.get(name, ctypes.c_int)
             self._dll = dll
         return self._dll
 
     def __getattr__(self, name):
         if name.startswith("mte_"):
             fn = getattr(self.load(), name)
+            if name in QUERIES:
+                return fn
 
             def call(*args):
                 rc = fn(*args)

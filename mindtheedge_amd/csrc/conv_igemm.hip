@@ -31,6 +31,7 @@ struct ConvArgs {
     void* y; long ldy; int out_f32; // output pixels
     int B, H, W, Cin_p, N, KH, KW;
     long M;
+    int splits; float* ws;          // split-K: partial sums are atomically added into ws[M][N] (fp32), finished separately
 };
 
 template <typename T> struct Mma;
@@ -62,7 +63,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (int)((a.M + BM - 1) / BM);
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int ntiles = tiles_m * tiles_n;
+    const int split = blockIdx.x / ntiles;
+    const int id = xcd_remap(blockIdx.x - split * ntiles, ntiles);
     const int tile_n = id % tiles_n, tile_m = id / tiles_n;
     const long m0 = (long)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -70,15 +73,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int taps = a.KH * a.KW, pad_h = a.KH >> 1, pad_w = a.KW >> 1;
     const int cpt = a.Cin_p / PER16;                   // chunks per tap
     const int total_chunks = taps * cpt;
-    const int ksteps = (total_chunks + 3) >> 2;
+    const int ksteps_all = (total_chunks + 3) >> 2;
+    const int per_split = (ksteps_all + a.splits - 1) / a.splits;
+    const int s_begin = split * per_split;
+    const int s_end = min(ksteps_all, s_begin + per_split);
     const long Kp = (long)taps * a.Cin_p;
     const T* __restrict__ xp = (const T*)a.x;
     const T* __restrict__ wp = (const T*)a.w;
 
     // ---- per-thread loader state: all chunks of a thread share kc = tid & 3
     const int kc = tid & 3;
-    int c = kc, ty = 0, tx = 0;                        // chunk-in-tap, tap row/col of global chunk q = 4*s + kc
-    while (c >= cpt) { c -= cpt; if (++tx == a.KW) { tx = 0; ++ty; } }
+    int c, ty, tx;                                     // chunk-in-tap, tap row/col of global chunk q = 4*s + kc
+    {
+        const int q0 = 4 * s_begin + kc, tap0 = q0 / cpt;
+        c = q0 - tap0 * cpt; ty = tap0 / a.KW; tx = tap0 - ty * a.KW;
+    }
     long a_pix[A_CH]; int a_oy[A_CH], a_ox[A_CH]; bool a_ok[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
@@ -141,11 +150,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
-    load_step(0);
+    if (s_begin < s_end) {
+    load_step(s_begin);
     store_step(0);
     __syncthreads();
-    for (int s = 0; s < ksteps; ++s) {
-        const int buf = s & 1;
+    }
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        const int ksteps = s_end;
         if (s + 1 < ksteps) load_step(s + 1);
         const char* pA = sA + buf * BM * 64;
         const char* pB = sB + buf * BN * 64;
@@ -178,7 +190,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 const long m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < a.M) {
                     const float v = acc[i][j][e] + bv;
-                    if (a.out_f32) ((float*)a.y)[m * a.ldy + n] = v;
+                    if (a.splits > 1) atomicAdd(a.ws + m * a.N + n, acc[i][j][e]);
+                    else if (a.out_f32) ((float*)a.y)[m * a.ldy + n] = v;
                     else Elem<T>::st((T*)a.y + m * a.ldy + n, v);
                 }
             }
@@ -186,19 +199,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+// y = T(ws + bias) after a split-K launch
+template <typename T>
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, long ldy, long M, int N) {
+    const long n4 = M * N / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long m = (i * 4) / N; const int n = (int)((i * 4) % N);
+        const f32x4_t v = ((const f32x4_t*)ws)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Elem<T>::st(y + m * ldy + n + k, v[k] + (bias ? bias[n + k] : 0.f));
+    }
+}
+
+// split-K factor for small-M / huge-K layers (pack5.conv: 120 tiles for 256 CUs); 1 = no split
+inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems) {
+    if (tiles >= 384 || ws_elems < M * N || N % 4 != 0) return 1;
+    long s = (768 + tiles - 1) / tiles;
+    const long max_s = ksteps / 16;                    // keep >= 16 K-steps (1 KiB of K per row) per split
+    if (s > max_s) s = max_s;
+    return (int)(s < 1 ? 1 : s);
+}
+
 template <typename T, int WM, int WN, int TM, int TN>
-int launch_igemm(const ConvArgs& a, hipStream_t st) {
+int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
+    a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems) : 1;
+    if (a.splits > 1 && hipMemsetAsync(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
     const size_t lds = 2 * (BM + BN) * 64;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds, st, a);
+    if (a.splits > 1) {
+        long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, a.ws, a.bias, (T*)a.y, a.ldy, a.M, a.N);
+    }
     return mte_check_launch();
 }
 
-template <typename T> int dispatch_igemm(const ConvArgs& a, hipStream_t st) {
-    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, st);       // 128 x 32
-    if (a.N <= 64 || (a.N % 128 != 0 && a.N < 128)) return launch_igemm<T, 2, 2, 2, 1>(a, st);   // 128 x 64
-    return launch_igemm<T, 2, 2, 2, 2>(a, st);                      // 128 x 128
+template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st) {
+    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st);       // 128 x 32
+    if (a.N <= 64 || (a.N % 128 != 0 && a.N < 128)) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st);   // 128 x 64
+    return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st);                      // 128 x 128
 }
 
 // =====================================================================================================
@@ -491,15 +532,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, lo
 extern "C" {
 
 // y[B,H,W,(ldy)] = conv(x[B,H,W,(ldx)], wpack[N][KH*KW][Cin_p]) + bias; stride 1, zero pad k/2.
+// workspace (nullable): fp32 scratch of workspace_elems >= B*H*W*N elements enables split-K for small-M / huge-K shapes.
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
-                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, hipStream_t stream) {
+                     int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
+                     float* workspace, long workspace_elems, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
-    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W};
-    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, stream);
-    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, stream);
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace};
+    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream);
+    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream);
     return MTE_ERR_UNSUPPORTED;
 }
 

@@ -1,0 +1,407 @@
+// LDS-patch convolution kernels for the high-resolution, few-channel layers (C_out <= 64) -- gfx950, bf16.
+//
+// Why a second conv path: with N = C_out = 32/64 the implicit GEMM of conv_igemm.hip re-streams the activation
+// tile once per filter tap (K = taps * C_in), i.e. 128 B of global->LDS traffic per MFMA cycle per CU for N = 32 --
+// several times what L2 delivers.  These layers (pre_calc, conv1 7x7, pack1.conv 5x5, conv2.*, iconv1/2,
+// unpack1/2.conv and their gradients) hold ~45 % of the network's MACs.  Here a workgroup stages the input PATCH
+// of its 8 x 32-pixel output tile once per 32-channel slice -- (8+k-1) x (32+k-1) pixels x 64 B -- and all k*k taps
+// read their A fragments from that patch at shifted LDS addresses, cutting global->LDS traffic by ~k*k/1.7.
+//
+//   forward / dgrad : weights come as 1-KiB fragment blocks [slice][tap][kk][nt][lane][8] straight from global/L2
+//                     into registers (coalesced, one tap ahead); accumulators 2 x NT tiles of 32x32 per wave.
+//   wgrad           : dW[n][tap][c] = sum_px dy[px][n] * x[px+tap][c]; both operands are pixel-major, so the
+//                     8-consecutive-k fragments come from ds_read_b64_tr_b16; every tap's 32x32 accumulator stays in
+//                     registers (taps dealt round-robin to the 4 waves) while the workgroup sweeps its pixel tiles;
+//                     one fp32 atomic pass at the end.
+//
+// Reference ops replaced: nn.Conv2d + ConstantPad2d of Conv2D / ResidualConv (layers01.py:29-31,61) and their autograd.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;                     // output tile (pixels)
+
+__device__ __forceinline__ int swz_off(int p, int kc) { return p * 64 + ((kc ^ ((p >> 2) & 3)) << 4); }
+
+struct PatchArgs {
+    const bf16_t* x; long ldx;
+    const bf16_t* wp;                              // patch-packed weights
+    const float* bias;
+    bf16_t* y; long ldy;
+    int B, H, W, Cin_p, N;
+};
+
+// ---- forward / dgrad --------------------------------------------------------------------------------------
+template <int K, int NT>
+__global__ __launch_bounds__(256) void conv_patch_fwd_kernel(PatchArgs a) {
+    constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
+    constexpr int PCH = PH * PW * 4;                               // 16-B chunks per patch slice
+    constexpr int NCH = (PCH + 255) / 256;
+    constexpr int PBYTES = PH * PW * 64;
+    constexpr int OBYTES = TH * TW * NT * 64;                      // output staging (bf16 [256 px][32*NT])
+    constexpr int LDS_BYTES = (2 * PBYTES > OBYTES) ? 2 * PBYTES : OBYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = a.W / TW, tiles_y = (a.H + TH - 1) / TH;
+    int id = xcd_remap(blockIdx.x, tiles_x * tiles_y * a.B);
+    const int tx_ = id % tiles_x; id /= tiles_x;
+    const int ty_ = id % tiles_y; const int b = id / tiles_y;
+    const int x0 = tx_ * TW, y0 = ty_ * TH;
+    const int cpt = a.Cin_p >> 3;                                  // 16-B chunks per pixel
+    const int nslices = (a.Cin_p + 31) >> 5;
+
+    u32x4_t st[NCH];
+    auto load_patch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idc = tid + i * 256;
+            const int p = idc >> 2, kc = idc & 3;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = y0 + py - PAD, ix = x0 + px - PAD;
+            const int cc = s * 4 + kc;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if ((PCH % 256 == 0 || idc < PCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cpt)
+                v = *(const u32x4_t*)(a.x + (((long)b * a.H + iy) * a.W + ix) * a.ldx + cc * 8);
+            st[i] = v;
+        }
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idc = tid + i * 256;
+            if (PCH % 256 == 0 || idc < PCH) *(u32x4_t*)(smem + buf * PBYTES + swz_off(idc >> 2, idc & 3)) = st[i];
+        }
+    };
+
+    f32x16_t acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    load_patch(0);
+    store_patch(0);
+    __syncthreads();
+    const u32x4_t* wl = (const u32x4_t*)a.wp + lane;               // fragment block = 64 lanes x 16 B
+    for (int s = 0; s < nslices; ++s) {
+        const char* P = smem + (s & 1) * PBYTES;
+        if (s + 1 < nslices) load_patch(s + 1);
+        const u32x4_t* wsl = wl + (long)s * TAPS * 2 * NT * 64;
+        u32x4_t bn[2][NT];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bn[kk][n] = wsl[(kk * NT + n) * 64];
+#pragma unroll 1
+        for (int t = 0; t < TAPS; ++t) {
+            u32x4_t bc[2][NT];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bc[kk][n] = bn[kk][n];
+            if (t + 1 < TAPS) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bn[kk][n] = wsl[(((t + 1) * 2 + kk) * NT + n) * 64];
+            }
+            const int dy = t / K, dx = t - dy * K;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int p = (wave * 2 + m + dy) * PW + dx + r;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const u32x4_t fa = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                                            __builtin_bit_cast(bf16x8_t, bc[kk][n]), acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < nslices) store_patch((s + 1) & 1);
+        __syncthreads();
+    }
+    // ---- epilogue: stage the tile as bf16 [pixel][N] in LDS, then 16-byte coalesced stores
+    constexpr int NB = NT * 64;                                    // bytes per pixel
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ch = n * 32 + r;
+        const float bv = (a.bias && ch < a.N) ? a.bias[ch] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int px = (e & 3) + 8 * (e >> 2) + 4 * h;
+                *(bf16_t*)(smem + ((wave * 2 + m) * TW + px) * NB + ch * 2) = f2bf(acc[m][n][e] + bv);
+            }
+    }
+    __syncthreads();
+    constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
+    const int cpp = a.N >> 3;                                      // valid chunks per pixel
+#pragma unroll
+    for (int i = 0; i < OCH / 256; ++i) {
+        const int idc = tid + i * 256;
+        const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
+        const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
+        if (yy < a.H && c < cpp)
+            *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * NB + c * 16);
+    }
+}
+
+// generic pack [N][taps][Cin_p] -> fragment blocks [slice][tap][kk][nt][lane = h*32 + r][8]
+__global__ void repack_patch_kernel(const bf16_t* __restrict__ wg, bf16_t* __restrict__ wp, int N, int taps, int Cin_p, int NT) {
+    const int nslices = (Cin_p + 31) >> 5;
+    const long total = (long)nslices * taps * 2 * NT * 64 * 8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7); long t = i >> 3;
+        const int lane = (int)(t & 63); t >>= 6;
+        const int nt = (int)(t % NT); t /= NT;
+        const int kk = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % taps); const int s = (int)(t / taps);
+        const int n = nt * 32 + (lane & 31), c = s * 32 + kk * 16 + (lane >> 5) * 8 + j;
+        wp[i] = (n < N && c < Cin_p) ? wg[((long)n * taps + tap) * Cin_p + c] : (bf16_t)0;
+    }
+}
+
+// ---- wgrad ---------------------------------------------------------------------------------------------------
+struct PatchWgradArgs {
+    const bf16_t* x; long ldx;
+    const bf16_t* dy; long lddy;
+    float* dw;                                     // [N][taps][Cin_p] fp32 stage, zeroed by the launcher
+    int B, H, W, Cin_p, N;
+    int groups;                                    // workgroups per channel slice
+};
+
+template <int K, int NT>
+__global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a) {
+    constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
+    constexpr int TPW = (TAPS + 3) / 4;                            // taps per wave
+    constexpr int XCH = PH * PW * 4, NXC = (XCH + 255) / 256;      // x patch chunks (64 B per pixel)
+    constexpr int YRS = NT == 1 ? 64 : 192;                        // dy row stride: odd multiple of 64 B (tr-read banks)
+    constexpr int YCH = TH * TW * NT * 4, NYC = YCH / 256;
+    constexpr int XBYTES = PH * PW * 64, YBYTES = TH * TW * YRS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][XBYTES] then [2][YBYTES]
+    char* sX = smem;
+    char* sY = smem + 2 * XBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.y;
+    const int tiles_x = a.W / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * a.B;
+    const int per = (ntiles + a.groups - 1) / a.groups;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    const int cpt = a.Cin_p >> 3, npp = a.N >> 3;
+
+    u32x4_t sx[NXC], sy[NYC];
+    auto load_tile = [&](int tile) {
+        int id = tile;
+        const int tx_ = id % tiles_x; id /= tiles_x;
+        const int ty_ = id % tiles_y; const int b = id / tiles_y;
+        const int x0 = tx_ * TW, y0 = ty_ * TH;
+#pragma unroll
+        for (int i = 0; i < NXC; ++i) {
+            const int idc = tid + i * 256;
+            const int p = idc >> 2, kc = idc & 3;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = y0 + py - PAD, ix = x0 + px - PAD;
+            const int cc = slice * 4 + kc;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if ((XCH % 256 == 0 || idc < XCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cpt)
+                v = *(const u32x4_t*)(a.x + (((long)b * a.H + iy) * a.W + ix) * a.ldx + cc * 8);
+            sx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NYC; ++i) {
+            const int idc = tid + i * 256;
+            const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
+            const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (yy < a.H && c < npp) v = *(const u32x4_t*)(a.dy + (((long)b * a.H + yy) * a.W + xx) * a.lddy + c * 8);
+            sy[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NXC; ++i) {
+            const int idc = tid + i * 256;
+            if (XCH % 256 == 0 || idc < XCH) *(u32x4_t*)(sX + buf * XBYTES + idc * 16) = sx[i];      // plain [pixel][64 B]
+        }
+#pragma unroll
+        for (int i = 0; i < NYC; ++i) {
+            const int idc = tid + i * 256;
+            const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
+            *(u32x4_t*)(sY + buf * YBYTES + pix * YRS + c * 16) = sy[i];
+        }
+    };
+
+    f32x16_t acc[TPW][NT];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+
+    // transposing-read lane roles: 16-lane group g: channels 16*(g&1) + 4p.., pixels 8*(g>>1) + q (+4 for the 2nd read)
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int chb = 16 * (g & 1) + 4 * pp, pxb = 8 * (g >> 1) + q;
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+        __syncthreads();
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const int buf = (tile - t_begin) & 1;
+            if (tile + 1 < t_end) load_tile(tile + 1);
+            const char* X = sX + buf * XBYTES;
+            const char* Y = sY + buf * YBYTES;
+#pragma unroll 1
+            for (int ks = 0; ks < TH * 2; ++ks) {                  // 16 pixels of one tile row per k-step
+                const int row = ks >> 1, col0 = (ks & 1) * 16;
+                u32x4_t fy[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const char* base = Y + (row * TW + col0 + pxb) * YRS + (n * 32 + chb) * 2;
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * YRS));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fy[n] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+                }
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int tap = wave + 4 * i;
+                    if (tap < TAPS) {
+                        const int dyy = tap / K, dxx = tap - dyy * K;
+                        const char* base = X + ((row + dyy) * PW + col0 + dxx + pxb) * 64 + chb * 2;
+                        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * 64));
+                        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                        const u32x4_t fx = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[n]),
+                                                                               __builtin_bit_cast(bf16x8_t, fx), acc[i][n], 0, 0, 0);
+                    }
+                }
+            }
+            if (tile + 1 < t_end) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // D[row = cout][col = cin]: col = lane&31 -> contiguous fp32 in the stage
+    const int r = lane & 31, h = lane >> 5;
+    const int cc = slice * 32 + r;
+    if (cc < a.Cin_p) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int tap = wave + 4 * i;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int co = n * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (co < a.N) atomicAdd(a.dw + ((long)co * TAPS + tap) * a.Cin_p + cc, acc[i][n][e]);
+                    }
+            }
+        }
+    }
+}
+
+template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
+    const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
+    hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    return mte_check_launch();
+}
+template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
+    switch (K) {
+        case 1: return launch_fwd<1, NT>(a, st);
+        case 3: return launch_fwd<3, NT>(a, st);
+        case 5: return launch_fwd<5, NT>(a, st);
+        case 7: return launch_fwd<7, NT>(a, st);
+    }
+    return MTE_ERR_UNSUPPORTED;
+}
+
+template <int K, int NT> int launch_wgrad(PatchWgradArgs a, hipStream_t st) {
+    constexpr int PH = TH + K - 1, PW = TW + K - 1;
+    constexpr int YRS = NT == 1 ? 64 : 192;
+    const size_t lds = 2 * (PH * PW * 64 + TH * TW * YRS);
+    const int nslices = (a.Cin_p + 31) / 32;
+    const long ntiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
+    long groups = (512 + nslices - 1) / nslices;                   // ~2 workgroups per CU in total
+    if (groups > ntiles) groups = ntiles;
+    a.groups = (int)groups;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_patch_wgrad_kernel<K, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MTE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    if (hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT>), dim3((unsigned)groups, nslices), dim3(256), lds, st, a);
+    return mte_check_launch();
+}
+template <int NT> int dispatch_wgrad(const PatchWgradArgs& a, int K, hipStream_t st) {
+    switch (K) {
+        case 1: return launch_wgrad<1, NT>(a, st);
+        case 3: return launch_wgrad<3, NT>(a, st);
+        case 5: return launch_wgrad<5, NT>(a, st);
+        case 7: return launch_wgrad<7, NT>(a, st);
+    }
+    return MTE_ERR_UNSUPPORTED;
+}
+
+inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
+    if (KH == 7 && N > 32) return false;             // 13 taps x 2 tiles of accumulators per wave would spill in wgrad
+    return W % TW == 0 && Cin_p % 8 == 0 && N % 8 == 0 && N <= 64 && KH == KW && (KH == 1 || KH == 3 || KH == 5 || KH == 7);
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 if the LDS-patch kernels cover this conv shape (bf16, C_out <= 64, W % 32 == 0, k in {1,3,5,7}), else 0.
+int mte_conv2d_patch_supported(int W, int Cin_p, int N, int KH, int KW, int dtype) {
+    return (dtype == MTE_DT_BF16 && patch_shape_ok(W, Cin_p, N, KH, KW)) ? 1 : 0;
+}
+
+// elements (bf16) of the fragment-block weight pack for mte_conv2d_patch_fwd
+long mte_conv2d_patch_pack_elems(int Cin_p, int N, int KH, int KW) {
+    return (long)((Cin_p + 31) / 32) * KH * KW * 2 * ((N + 31) / 32) * 64 * 8;
+}
+
+// generic pack [N][taps][Cin_p] (bf16, from mte_pack_conv_weights) -> fragment blocks
+int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N, int KH, int KW, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!wgeneric || !wpatch) return MTE_ERR_ARG;
+    const long total = mte_conv2d_patch_pack_elems(Cin_p, N, KH, KW);
+    long g = (total + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(repack_patch_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)wgeneric, (bf16_t*)wpatch, N, KH * KW, Cin_p, (N + 31) / 32);
+    return mte_check_launch();
+}
+
+// y = conv(x, wpatch) + bias for C_out <= 64 (forward, or data-gradient with the backward pack); bf16 only.
+int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N};
+    return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
+}
+
+// dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) for C_out <= 64; bf16 only.
+int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage,
+                           int B, int H, int W, int Cin_p, int N, int KH, int KW, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !dy || !dw_stage || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
+    PatchWgradArgs a{(const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, dw_stage, B, H, W, Cin_p, N, 1};
+    return N <= 32 ? dispatch_wgrad<1>(a, KH, stream) : dispatch_wgrad<2>(a, KH, stream);
+}
+
+}  // extern "C"

@@ -77,36 +77,43 @@ __device__ __forceinline__ void pack_load_window(const P3Args& a, int b, int hh,
     const int c0 = j * 8;
 
 template <typename T>
-__global__ __launch_bounds__(256) void pack3d_fwd_kernel(P3Args a) {
+__global__ __launch_bounds__(256, 3) void pack3d_fwd_kernel(P3Args a) {
     const int H2 = a.H >> 1, W2 = a.W >> 1;
     P3_THREAD_MAP(H2, W2);
-    float acc[4][32];
+    const int D = a.C * 4;
+    T* op = (T*)a.dst + (((long)b * H2 + h) * W2 + w) * a.lddst;
+    // two of the four 3-D features per pass: 64 accumulators instead of 128 keeps 4 waves/SIMD resident; the
+    // input window is re-read from L1 on the second pass
+#pragma unroll 1
+    for (int fp = 0; fp < 2; ++fp) {
+        float acc[2][32];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const float bv = a.b3[f];
+        for (int f = 0; f < 2; ++f) {
+            const float bv = a.b3[2 * fp + f];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) acc[f][i] = bv;
-    }
-    for (int kh = 0; kh < 3; ++kh)
-        for (int kw = 0; kw < 3; ++kw) {
+            for (int i = 0; i < 32; ++i) acc[f][i] = bv;
+        }
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - 3 * kh;
             float pv[34];
             pack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 2; ++f)
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
-                    const float wv = a.w3[((f * 3 + kd) * 3 + kh) * 3 + kw];
+                    const float wv = a.w3[(((2 * fp + f) * 3 + kd) * 3 + kh) * 3 + kw];
 #pragma unroll
                     for (int i = 0; i < 32; ++i) acc[f][i] = fmaf(wv, pv[i + kd], acc[f][i]);
                 }
         }
-    if (!live) return;
-    const int D = a.C * 4;
-    T* op = (T*)a.dst + (((long)b * H2 + h) * W2 + w) * a.lddst;
+        if (live) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) store8<T>(op + f * D + 4 * c0 + 8 * k, &acc[f][8 * k]);
+                for (int k = 0; k < 4; ++k) store8<T>(op + (2 * fp + f) * D + 4 * c0 + 8 * k, &acc[f][8 * k]);
+        }
+    }
 }
 
 // dP(d,h,w) = sum_f sum_taps w3[f][kd][kh][kw] * dO[f][d-kd+1][h-kh+1][w-kw+1];  scatter back to x layout
@@ -118,10 +125,12 @@ __global__ __launch_bounds__(256) void pack3d_bwd_data_kernel(P3Args a) {
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-    for (int kh = 0; kh < 3; ++kh)
-        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - 3 * kh;
             const int hh = h - kh + 1, ww = w - kw + 1;
             const bool in = live && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2;
+#pragma unroll 1
             for (int f = 0; f < 4; ++f) {
                 float pv[34];
                 const T* src = (const T*)a.o + (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + 4 * c0;
@@ -175,63 +184,81 @@ __device__ __forceinline__ void block_reduce_atomic(float (&vals)[40], int kh, f
 }
 
 // dw3[f][kd][kh][kw] = sum dO[f][d][h][w] * P(d+kd-1, h+kh-1, w+kw-1);  db3[f] = sum dO[f]
-template <typename T>
-__global__ __launch_bounds__(256) void pack3d_bwd_weight_kernel(P3Args a) {
-    const int H2 = a.H >> 1, W2 = a.W >> 1;
-    __shared__ float sred[4 * 40];
-    float acc[40];
+// vals[10]: [kd*3+kw] for fixed (f, kh), [9] = bias sum -> wave sums -> LDS -> one atomic per value per block
+__device__ __forceinline__ void block_reduce_atomic10(float (&vals)[10], int f, int kh, float* dst, float* sred) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 40; ++i) acc[i] = 0.f;
-    const int kh = blockIdx.y;                           // one kernel row per grid.y slice (register budget)
+    for (int i = 0; i < 10; ++i) {
+        const float s = wave_sum(vals[i]);
+        if (lane == 0) sred[wave * 10 + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const int i = threadIdx.x;
+        float s = 0.f;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += sred[wv * 10 + i];
+        if (i < 9) atomicAdd(dst + ((f * 3 + i / 3) * 3 + kh) * 3 + (i % 3), s);
+        else if (kh == 1) atomicAdd(dst + 108 + f, s);
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void pack3d_bwd_weight_kernel(P3Args a) {
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    __shared__ float sred[4 * 10];
+    const int kh = blockIdx.y;                           // one kernel row per grid.y slice
     const int cb = a.C >> 3;
     const int D = a.C * 4;
     const long nthreads = (long)gridDim.x * blockDim.x;   // grid.x only; grid.y = kh
     const long iters = (a.total + nthreads - 1) / nthreads;
-    for (long it = 0; it < iters; ++it) {
-        const long gid = it * nthreads + blockIdx.x * (long)blockDim.x + threadIdx.x;
-        const bool live = gid < a.total;
-        const long g = live ? gid : a.total - 1;
-        const int j = (int)(g % cb);
-        long pix = g / cb;
-        const int w = (int)(pix % W2); pix /= W2;
-        const int h = (int)(pix % H2);
-        const int b = (int)(pix / H2);
-        const int c0 = j * 8;
-        float go[4][32];
-        const T* src = (const T*)a.o + (((long)b * H2 + h) * W2 + w) * a.ldo + 4 * c0;
+    // one 3-D feature per sweep over this block's pixels: 10 accumulators + a 32-value gradient row live at a
+    // time (all four features at once needs > 256 VGPRs); the input window is re-read from L1/L2 on later sweeps
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+        float acc[10];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (long it = 0; it < iters; ++it) {
+            const long gid = it * nthreads + blockIdx.x * (long)blockDim.x + threadIdx.x;
+            const bool live = gid < a.total;
+            const long g = live ? gid : a.total - 1;
+            const int j = (int)(g % cb);
+            long pix = g / cb;
+            const int w = (int)(pix % W2); pix /= W2;
+            const int h = (int)(pix % H2);
+            const int b = (int)(pix / H2);
+            const int c0 = j * 8;
+            const T* src = (const T*)a.o + (((long)b * H2 + h) * W2 + w) * a.ldo + f * D + 4 * c0;
+            float go[32];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (live) load8<T>(src + f * D + 8 * k, &go[f][8 * k]);
+                if (live) load8<T>(src + 8 * k, &go[8 * k]);
                 else {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) go[f][8 * k + i] = 0.f;
+                    for (int i = 0; i < 8; ++i) go[8 * k + i] = 0.f;
                 }
             }
+            float sb = 0.f;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            float s = 0.f;
+            for (int i = 0; i < 32; ++i) sb += go[i];
+            acc[9] += sb;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) s += go[f][i];
-            acc[36 + f] += s;
-        }
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            float pv[34];
-            pack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int kw = 0; kw < 3; ++kw) {
+                float pv[34];
+                pack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
-                    float s = 0.f;
+                    float sacc = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) s = fmaf(go[f][i], pv[i + kd], s);
-                    acc[(f * 3 + kd) * 3 + kw] += s;
+                    for (int i = 0; i < 32; ++i) sacc = fmaf(go[i], pv[i + kd], sacc);
+                    acc[kd * 3 + kw] += sacc;
                 }
+            }
         }
+        block_reduce_atomic10(acc, f, kh, a.dw3, sred);
     }
-    block_reduce_atomic(acc, kh, a.dw3, sred);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -262,7 +289,7 @@ __device__ __forceinline__ void shuffled_ptrs(const P3Args& a, const void* base,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void unpack3d_fwd_kernel(P3Args a) {
+__global__ __launch_bounds__(256, 3) void unpack3d_fwd_kernel(P3Args a) {
     P3_THREAD_MAP(a.H, a.W);
     float acc[4][8];
 #pragma unroll
@@ -323,12 +350,11 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_kernel(P3Args a) {
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t)
+#pragma unroll 1
             for (int f = 0; f < 4; ++f) {
+                const int kh = t / 3, kw = t - 3 * kh;
                 float pv[10];
                 unpack_load_feat<T>(a, b, h - kh + 1, w - kw + 1, f, c0, j, cb, live, pv);
 #pragma unroll
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_kernel(P3Args a) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void unpack3d_bwd_weight_kernel(P3Args a) {
+__global__ __launch_bounds__(256, 3) void unpack3d_bwd_weight_kernel(P3Args a) {
     __shared__ float sred[4 * 40];
     float acc[40];
 #pragma unroll

@@ -109,6 +109,28 @@ class WeightPack:
     def __init__(self):
         self.key = None
         self.wf = self.wb = None
+        self.pf = self.pb = None        # fragment-block packs for the LDS-patch kernels (bf16, C_out <= 64)
+        self.pkey = None
+
+    def get_patch(self, w, which):
+        """which = 'f' (forward: N = Cout, K over Cin) or 'b' (data gradient: N = Cin_p, K over Cout)."""
+        wf, wb = self.get(w, torch.bfloat16, which == 'b')
+        if self.pkey != self.key:
+            self.pf = self.pb = None
+            self.pkey = self.key
+        cout, cin, kh, kw = w.shape
+        cin_p = round8(cin)
+        if which == 'f':
+            if self.pf is None:
+                n = lib.mte_conv2d_patch_pack_elems(cin_p, cout, kh, kw)
+                self.pf = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+                lib.mte_conv2d_patch_repack(wf.data_ptr(), self.pf.data_ptr(), cin_p, cout, kh, kw, _stream())
+            return self.pf
+        if self.pb is None:
+            n = lib.mte_conv2d_patch_pack_elems(cout, cin_p, kh, kw)
+            self.pb = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+            lib.mte_conv2d_patch_repack(wb.data_ptr(), self.pb.data_ptr(), cout, cin_p, kh, kw, _stream())
+        return self.pb
 
     def get(self, w, dtype, need_bwd):
         key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
@@ -123,13 +145,37 @@ class WeightPack:
         return self.wf, self.wb
 
 
-def conv_forward(x, wf, bias, cout, kh, kw, out=None):
+def _splitk_workspace(M, N, device):
+    """fp32 [M][N] scratch for split-K, offered only where the output has few 128x128 tiles (the library decides)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 384:
+        return None, 0
+    return torch.empty((M * N,), dtype=torch.float32, device=device), M * N
+
+
+_cfg = {"patch_kernels": True}
+
+
+def use_patch_kernels(flag):
+    """Enable/disable the LDS-patch conv kernels (tests compare them against the generic implicit GEMM)."""
+    _cfg["patch_kernels"] = bool(flag)
+
+
+def _patch_ok(W, cin_p, n, kh, kw, dtype):
+    return _cfg["patch_kernels"] and dtype == torch.bfloat16 and lib.mte_conv2d_patch_supported(W, cin_p, n, kh, kw, DT_BF16) == 1
+
+
+def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None):
     B, Cp, H, W = x.shape
     if out is None:
         out = new_act(B, cout, H, W, x.dtype, x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(out)
-    lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _stream())
+    if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
+        lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw, _stream())
+        return out
+    ws, ws_n = _splitk_workspace(B * H * W, cout, x.device)
+    lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _ptr(ws), ws_n, _stream())
     return out
 
 
@@ -143,16 +189,24 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True):
     dw = dbias = dx = None
     if need_dw:
         stage = torch.empty((cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
-        lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
+        if _patch_ok(W, Cp, cout, kh, kw, x.dtype):
+            lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, st)
+        else:
+            lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
         dw = torch.empty_like(w, dtype=torch.float32)
         lib.mte_unpack_conv_wgrad(stage.data_ptr(), dw.data_ptr(), cout, cin, kh, kw, Cp, st)
         dbias = torch.empty((cout,), dtype=torch.float32, device=x.device)
         lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
-    if need_dx:
+    if need_dx and _patch_ok(W, cout, Cp, kh, kw, x.dtype):
+        dx = new_act(B, Cp, H, W, x.dtype, x.device)
+        dxp, lddx = _pl(dx)
+        lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, st)
+    elif need_dx:
         _, wb = pack.get(w, x.dtype, True)
         dx = new_act(B, Cp, H, W, x.dtype, x.device)
         dxp, lddx = _pl(dx)
-        lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), st)
+        ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
+        lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, st)
     return dx, dw, dbias
 
 
@@ -198,7 +252,7 @@ class ConvGnEluFn(torch.autograd.Function):
     def forward(ctx, x, w, b, gamma, beta, pack):
         wf, _ = pack.get(w, x.dtype, False)
         cout, cin, kh, kw = w.shape
-        y = conv_forward(x, wf, b, cout, kh, kw)
+        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS)
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
@@ -219,7 +273,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, pack):
         wf, _ = pack.get(w, x.dtype, False)
         cout, cin, kh, kw = w.shape
-        y = conv_forward(x, wf, b, cout, kh, kw)
+        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
         ctx.save_for_backward(x, w)
         ctx.pack = pack
         return y

@@ -1,0 +1,62 @@
+"""GPU (-m gpu): the specialised conv kernels must agree with the generic implicit GEMM on identical bf16 inputs
+(same products, fp32 accumulation, only the summation order differs), and the generic kernel in fp32 mode must agree
+with torch's CPU fp32 convolution.  Shapes cover every (k, C_in, C_out) class of the PackNetSAN01 high-resolution
+layers, ragged heights (H % 8 != 0), channel-padded inputs and the split-K path."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # cin, cout, k, B, H, W
+    (32, 32, 7, 2, 16, 64), (512, 32, 5, 1, 12, 32), (3, 32, 5, 2, 20, 64), (65, 32, 3, 1, 9, 96), (64, 64, 3, 2, 16, 32),
+    (32, 64, 1, 2, 8, 64), (97, 64, 3, 1, 24, 32), (1024, 64, 3, 1, 8, 32), (64, 32, 3, 2, 10, 32), (16, 16, 3, 1, 8, 32),
+    (32, 64, 3, 1, 7, 64),
+]
+
+
+def _run(cin, cout, k, B, H, W, patch, dtype="bf16"):
+    from mindtheedge_amd import kernels as K
+    K.set_compute_dtype(dtype)
+    K.use_patch_kernels(patch)
+    try:
+        g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + k)
+        w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda().requires_grad_(True)
+        b = (torch.rand(cout, generator=g) - 0.5).cuda().requires_grad_(True)
+        x = (torch.rand(B, cin, H, W, generator=g) * 2 - 1)
+        G = (torch.rand(B, cout, H, W, generator=g) * 2 - 1)
+        xa = K.image_to_act(x.cuda()).detach().requires_grad_(True)
+        pack = K.WeightPack()
+        y = K.ConvFn.apply(xa, w, b, pack)
+        (y.float() * G.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        return dict(y=y.float().cpu(), dx=xa.grad.float().cpu()[:, :cin], dw=w.grad.cpu(), db=b.grad.cpu(), x=x, G=G,
+                    w=w.detach().cpu(), b=b.detach().cpu())
+    finally:
+        K.use_patch_kernels(True)
+        K.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_patch_kernels_match_generic_igemm(shape):
+    a = _run(*shape, patch=True)
+    r = _run(*shape, patch=False)
+    assert rel_err(a["y"], r["y"]) < 8e-3          # both round the same fp32 sums to bf16: at most 1 bf16 ulp apart
+    assert rel_err(a["dx"], r["dx"]) < 8e-3
+    assert rel_err(a["dw"], r["dw"]) < 2e-4        # fp32 outputs: summation order only
+    assert rel_err(a["db"], r["db"]) < 1e-5
+
+
+@pytest.mark.parametrize("shape", SHAPES[:6] + [(512, 512, 3, 2, 4, 8), (256, 8, 3, 1, 6, 10)])
+def test_generic_igemm_fp32_matches_torch_cpu(shape):
+    r = _run(*shape, patch=False, dtype="fp32")
+    x = r["x"].clone().requires_grad_(True)
+    w = r["w"].clone().requires_grad_(True)
+    b = r["b"].clone().requires_grad_(True)
+    y = torch.nn.functional.conv2d(x, w, b, padding=shape[2] // 2)
+    (y * r["G"]).sum().backward()
+    assert rel_err(r["y"], y) < 2e-5
+    assert rel_err(r["dx"], x.grad) < 2e-5
+    assert rel_err(r["dw"], w.grad) < 5e-5
+    assert rel_err(r["db"], b.grad) < 2e-5
