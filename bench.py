@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=1280)
@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--dump-conv", type=str, default="", help="write per-launch conv timings (shape, ms, TFLOP/s) to this file")
     return ap.parse_args()
 
 
@@ -50,7 +51,7 @@ class ConvTimer:
         self.K, self.records, self.enabled = K, [], False
         lib = K.lib
         self._orig = {}
-        for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad"):
+        for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad"):
             self._orig[name] = getattr(lib, name)
 
     def install(self):
@@ -69,17 +70,20 @@ class ConvTimer:
                     fn(*args)
                     e1.record()
                     if name == "mte_conv2d_igemm":
-                        B, H, W, Cin_p, N, KH, KW = args[7:14]           # (x, ldx, w, bias, y, ldy, out_f32, B, H, W, ...)
+                        shp = args[7:14]           # (x, ldx, w, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, ...)
+                    elif name == "mte_conv2d_patch_fwd":
+                        shp = args[6:13]           # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, KH, KW, stream)
                     else:
-                        B, H, W, Cin_p, N, KH, KW = args[5:12]
-                    outer.records.append((name, e0, e1, 2.0 * B * H * W * Cin_p * N * KH * KW))
+                        shp = args[5:12]           # (x, ldx, dy, lddy, dw, B, H, W, Cin_p, N, KH, KW, ...)
+                    B, H, W, Cin_p, N, KH, KW = shp
+                    outer.records.append((name, e0, e1, 2.0 * B * H * W * Cin_p * N * KH * KW, tuple(shp)))
                 return timed
         self._lib = K.lib
         K.lib = Proxy()
 
     def summary(self):
         out = {}
-        for name, e0, e1, fl in self.records:
+        for name, e0, e1, fl, _ in self.records:
             d = out.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1) * 1e-3
@@ -262,6 +266,11 @@ def main():
         passes = 3.0 if args.mode == "train" else 1.0
         step_flops = conv_flops_per_image(H, W) * B * passes
         res["mfma_fraction_of_step"] = step_flops / (ms * 1e-3) / (BF16_DENSE_PEAK_TFLOPS * 1e12)
+        if timer and args.dump_conv:
+            rows = [(e0.elapsed_time(e1), name, shp, fl) for name, e0, e1, fl, shp in timer.records[:len(timer.records) // max(ksteps, 1)]]
+            with open(args.dump_conv, "w") as f:
+                for ms_, name, shp, fl in sorted(rows, reverse=True):
+                    f.write("%8.3f ms %7.1f TF  %-24s B,H,W,Cin_p,N,KH,KW=%s\n" % (ms_, fl / ms_ / 1e9, name, shp))
         if timer:
             s = timer.summary()
             tot_t = sum(v[1] for v in s.values())

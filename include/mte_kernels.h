@@ -39,6 +39,8 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
                      float* workspace, long workspace_elems, mte_stream_t stream);
+/* development knob (A/B experiments): key 0 = igemm tile loader, 1 = LDS-DMA (default), 0 = register staging */
+int mte_debug_set(int key, int value);
 /* weight gradient of the same conv: dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) */
 int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
@@ -70,7 +72,7 @@ int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const flo
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
 int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
                    const double* stats, const float* gamma, const float* beta, float* red,
-                   void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta,
+                   void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
 
 /* ---- 3-D packing / unpacking stencils: packing + nn.Conv3d(1,4,3,pad 1) (+ view / PixelShuffle)

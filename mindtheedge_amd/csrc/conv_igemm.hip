@@ -50,15 +50,20 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 64 + ((kc ^ ((row >> 2) & 3)) << 4); }
 
-template <typename T, int WM, int WN, int TM, int TN>
+__device__ u32x4_t g_zero16 = {0u, 0u, 0u, 0u};      // source of zero chunks for the LDS-DMA loader (image border / K tail)
+
+// DMA = true: tiles are staged global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write); the
+// LDS image is lane-linear per wave instruction, so the XOR swizzle is applied to the per-lane SOURCE chunk instead.
+template <typename T, int WM, int WN, int TM, int TN, bool DMA>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int A_CH = BM * 4 / 256;                 // 16-B chunks of the A tile per thread
     constexpr int B_CH = (BN * 4 + 255) / 256;         // (BN = 32: only threads < 128 load)
+    constexpr int ST = DMA ? 4 : 2;                    // LDS ring depth
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                                   // [2][BM*64]
-    char* sB = smem + 2 * BM * 64;                     // [2][BN*64]
+    char* sA = smem;                                   // [ST][BM*64]
+    char* sB = smem + ST * BM * 64;                    // [ST][BN*64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (a.N + BN - 1) / BN;
@@ -81,8 +86,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const T* __restrict__ xp = (const T*)a.x;
     const T* __restrict__ wp = (const T*)a.w;
 
-    // ---- per-thread loader state: all chunks of a thread share kc = tid & 3
-    const int kc = tid & 3;
+    // ---- per-thread loader state: all chunks of a thread share the K-chunk index kc.  Register staging: kc = tid&3 and
+    // the swizzle is applied when writing LDS.  DMA: LDS slot (tid&3) of row r must hold source chunk (tid&3) ^ swz(r),
+    // and swz(r) = (r>>2)&3 = (tid>>4)&3 for every row this thread touches.
+    const int kc = DMA ? ((tid & 3) ^ ((tid >> 4) & 3)) : (tid & 3);
     int c, ty, tx;                                     // chunk-in-tap, tap row/col of global chunk q = 4*s + kc
     {
         const int q0 = 4 * s_begin + kc, tap0 = q0 / cpt;
@@ -126,6 +133,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         c += 4;
         while (c >= cpt) { c -= cpt; if (++tx == a.KW) { tx = 0; ++ty; } }
     };
+    auto dma_step = [&](int s, int buf) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const bool tap_ok = ty < a.KH;
+        const int dy = ty - pad_h, dx = tx - pad_w;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+            const bool ok = a_ok[i] && tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const void* src = ok ? (const void*)(xp + (a_pix[i] + (long)dy * a.W + dx) * a.ldx + c * PER16) : (const void*)&g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * BM * 64 + (wv * 16 + i * 64) * 64), 16, 0, 0);
+        }
+        const int q = 4 * s + kc;
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            if (wv * 64 + i * 256 < BN * 4) {                       // wave-uniform (BN*4 is a multiple of 64)
+                const int row = (tid + i * 256) >> 2, n = n0 + row;
+                const void* src = (n < a.N && q < total_chunks) ? (const void*)(wp + (long)n * Kp + (long)q * PER16) : (const void*)&g_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + buf * BN * 64 + (wv * 16 + i * 64) * 64), 16, 0, 0);
+            }
+        }
+        c += 4;
+        while (c >= cpt) { c -= cpt; if (++tx == a.KW) { tx = 0; ++ty; } }
+    };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
@@ -150,17 +182,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
-    if (s_begin < s_end) {
-    load_step(s_begin);
-    store_step(0);
-    __syncthreads();
-    }
-    for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        const int ksteps = s_end;
-        if (s + 1 < ksteps) load_step(s + 1);
-        const char* pA = sA + buf * BM * 64;
-        const char* pB = sB + buf * BN * 64;
+    auto compute = [&](int slot) {
+        const char* pA = sA + slot * BM * 64;
+        const char* pB = sB + slot * BN * 64;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             u32x4_t fa[TM], fb[TN];
@@ -173,8 +197,72 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
-        if (s + 1 < ksteps) store_step(buf ^ 1);
-        __syncthreads();
+    };
+    if constexpr (DMA) {
+        // 4-slot LDS ring filled by LDS-DMA three K-steps ahead.  vmcnt is COUNTED (two younger stages stay in
+        // flight across the barrier): the only wait per K-step is for the stage about to be consumed, so HBM/L2
+        // latency (1-2k cycles under load) is covered by three K-steps of MFMA work instead of one.
+        static_assert((BN * 4) % 256 == 0, "every wave must issue the same number of DMA instructions per stage");
+        constexpr int LPS = A_CH + B_CH;
+        const int nst = s_end - s_begin;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (p < nst) dma_step(s_begin + p, p);
+        for (int i = 0; i < nst; ++i) {
+            const int rem = nst - 1 - i;
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (i + 3 < nst) dma_step(s_begin + i + 3, (i + 3) & 3);
+            compute(i & 3);
+        }
+    } else {
+        if (s_begin < s_end) {
+            load_step(s_begin); store_step(0);
+            __syncthreads();
+        }
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            if (s + 1 < s_end) load_step(s + 1);
+            compute(buf);
+            if (s + 1 < s_end) store_step(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    if constexpr (DMA) {
+        if (a.splits == 1 && !a.out_f32) {
+            // ---- epilogue through LDS: [BM][BN] tile in T, then 16-byte row-contiguous stores
+            constexpr int ES = (int)sizeof(T);
+            static_assert(BM * BN * ES <= ST * (BM + BN) * 64, "output tile must fit the ring");
+            __syncthreads();                              // every wave is done reading the ring
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wn * TN + j) * 32 + r;
+                const int n = n0 + col;
+                const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        Elem<T>::st((T*)(smem + (row * BN + col) * ES), acc[i][j][e] + bv);
+                    }
+            }
+            __syncthreads();
+            constexpr int CPR = BN / PER16;                // 16-B chunks per tile row
+            const int cvalid = (a.N - n0) / PER16;         // chunks of this tile inside N (N % 8 == 0)
+#pragma unroll
+            for (int it = 0; it < BM * CPR / 256; ++it) {
+                const int idx = tid + it * 256;
+                const int row = idx / CPR, cc = idx - row * CPR;
+                const long m = m0 + row;
+                if (m < a.M && cc < cvalid)
+                    *(u32x4_t*)((T*)a.y + m * a.ldy + n0 + cc * PER16) = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
+            }
+            return;
+        }
     }
 
     // ---- epilogue: D[row][col]: col = lane&31 (channel n), row = (e&3) + 8*(e>>2) + 4*h (pixel m)
@@ -198,6 +286,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 }
+
+int g_igemm_dma = 1;                                 // development knob (mte_debug_set(0, v))
 
 // y = T(ws + bias) after a split-K launch
 template <typename T>
@@ -227,8 +317,15 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
     const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
     a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems) : 1;
     if (a.splits > 1 && hipMemsetAsync(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
-    const size_t lds = 2 * (BM + BN) * 64;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds, st, a);
+    if constexpr ((BN * 4) % 256 == 0) {
+        if (g_igemm_dma) {
+            const size_t lds4 = 4 * (BM + BN) * 64;
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds4, st, a);
+            goto launched;
+        }
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false>), dim3((unsigned)(tiles * a.splits)), dim3(256), 2 * (BM + BN) * 64, st, a);
+launched:
     if (a.splits > 1) {
         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
         hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, a.ws, a.bias, (T*)a.y, a.ldy, a.M, a.N);
@@ -530,6 +627,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, lo
 }  // namespace
 
 extern "C" {
+
+// development knob: key 0 = igemm tile loader (1 = LDS-DMA, 0 = register staging).  Not part of the product contract.
+int mte_debug_set(int key, int value) {
+    if (key == 0) { g_igemm_dma = value; return MTE_OK; }
+    return MTE_ERR_ARG;
+}
 
 // y[B,H,W,(ldy)] = conv(x[B,H,W,(ldx)], wpack[N][KH*KW][Cin_p]) + bias; stride 1, zero pad k/2.
 // workspace (nullable): fp32 scratch of workspace_elems >= B*H*W*N elements enables split-K for small-M / huge-K shapes.

@@ -33,7 +33,7 @@ struct PatchArgs {
 
 // ---- forward / dgrad --------------------------------------------------------------------------------------
 template <int K, int NT>
-__global__ __launch_bounds__(256) void conv_patch_fwd_kernel(PatchArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int PCH = PH * PW * 4;                               // 16-B chunks per patch slice
     constexpr int NCH = (PCH + 255) / 256;
@@ -91,35 +91,43 @@ __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(PatchArgs a) {
         const char* P = smem + (s & 1) * PBYTES;
         if (s + 1 < nslices) load_patch(s + 1);
         const u32x4_t* wsl = wl + (long)s * TAPS * 2 * NT * 64;
-        u32x4_t bn[2][NT];
+        // weight fragments come straight from L2 (hundreds of cycles): keep PD taps in flight in a register ring
+        constexpr int PD = TAPS < 4 ? TAPS : 4;
+        u32x4_t bq[PD][2][NT];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bn[kk][n] = wsl[(kk * NT + n) * 64];
-#pragma unroll 1
-        for (int t = 0; t < TAPS; ++t) {
-            u32x4_t bc[2][NT];
+        for (int d = 0; d < PD; ++d)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bc[kk][n] = bn[kk][n];
-            if (t + 1 < TAPS) {
+                for (int n = 0; n < NT; ++n) bq[d][kk][n] = wsl[((d * 2 + kk) * NT + n) * 64];
+#pragma unroll 1
+        for (int t0 = 0; t0 < TAPS; t0 += PD) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+            for (int d = 0; d < PD; ++d) {
+                const int t = t0 + d;
+                if (t < TAPS) {                                    // wave-uniform
+                    const int dy = t / K, dx = t - dy * K;
+                    u32x4_t fa[2][2];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) bn[kk][n] = wsl[(((t + 1) * 2 + kk) * NT + n) * 64];
-            }
-            const int dy = t / K, dx = t - dy * K;
+                    for (int m = 0; m < 2; ++m) {
+                        const int p = (wave * 2 + m + dy) * PW + dx + r;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int p = (wave * 2 + m + dy) * PW + dx + r;
+                        for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
+                    }
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const u32x4_t fa = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
+                    for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa),
-                                                                            __builtin_bit_cast(bf16x8_t, bc[kk][n]), acc[m][n], 0, 0, 0);
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]),
+                                                                                    __builtin_bit_cast(bf16x8_t, bq[d][kk][n]), acc[m][n], 0, 0, 0);
+                    if (t + PD < TAPS) {
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) bq[d][kk][n] = wsl[(((t + PD) * 2 + kk) * NT + n) * 64];
+                    }
                 }
             }
         }

@@ -27,6 +27,7 @@ struct GnArgs {
     float* red;                        // [B][C][2]  (sum dyhat, sum dyhat*xhat)
     void* d1; long ldd1;               // backward outputs
     void* d2; long ldd2;
+    float* dbias;                      // optional [C]: per-channel sum of d1 (= gradient of the conv bias in front of the norm)
     int B, HW, C;
     float eps;
     int blocks_per_sample;
@@ -157,6 +158,14 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
     GN_THREAD_MAP();
+    extern __shared__ float s_db[];                       // [C] when a.dbias
+    if (a.dbias) {
+        for (int i = threadIdx.x; i < a.C; i += 256) s_db[i] = 0.f;
+        __syncthreads();
+    }
+    float db[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) db[i] = 0.f;
     float mean[P], rstd[P], gm[P], bt[P], s1[P], s2[P], sc[P];
     const float inv_n = 1.f / ((float)a.HW * gs);
 #pragma unroll
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
             const float u = fmaf(xh, gm[i], bt[i]);
             const float dyh = g[i] * (u > 0.f ? 1.f : __expf(u));
             v[i] = rstd[i] * (dyh * gm[i] - (s1[i] + xh * s2[i]));
+            db[i] += v[i];
         }
         *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
         if (a.d2) {
@@ -194,6 +204,12 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
             for (int i = 0; i < P; ++i) v[i] *= sc[i];
             *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
         }
+    }
+    if (a.dbias) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) atomicAdd(&s_db[ch0 + i], db[i]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.C; i += 256) atomicAdd(&a.dbias[i], s_db[i]);
     }
 }
 
@@ -255,15 +271,16 @@ int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const flo
 }
 
 // Backward of z = ELU(GN(y1 + scale2*y2)).  red[B][C][2] is scratch (zeroed here).  Writes d1 (grad of y1),
-// optionally d2 (grad of y2 = scale2 * d1), and dgamma/dbeta [C] (overwritten).
+// optionally d2 (grad of y2 = scale2 * d1), dgamma/dbeta [C] (overwritten) and, if non-null, dbias [C] = column sums of d1.
 int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
                    const double* stats, const float* gamma, const float* beta, float* red,
-                   void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta,
+                   void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,
                    int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dz || !y1 || !stats || !gamma || !beta || !red || !d1 || !dgamma || !dbeta || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     if (hipMemsetAsync(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
+    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    GnArgs a{}; a.dbias = dbias; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
     a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;
     a.B = B; a.HW = HW; a.C = C; a.eps = eps;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
@@ -272,10 +289,10 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
     const size_t lds = sizeof(float) * C * 2;
     if (dtype == MTE_DT_BF16) {
         hipLaunchKernelGGL(gn_elu_bwd_reduce_kernel<bf16_t>, grid, dim3(256), lds, stream, a);
-        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<bf16_t>, grid, dim3(256), dbias ? sizeof(float) * C : 0, stream, a);
     } else {
         hipLaunchKernelGGL(gn_elu_bwd_reduce_kernel<float>, grid, dim3(256), lds, stream, a);
-        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<float>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<float>, grid, dim3(256), dbias ? sizeof(float) * C : 0, stream, a);
     }
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, B, C);
     return mte_check_launch();

@@ -38,35 +38,53 @@ struct P3Args {
 };
 
 // ------------------------------------------------------------------------------------------------
-// PACK.  Volume pixel (h,w) in [H/2, W/2]; thread block of 8 x-channels c0.. -> 32 packed depths d = 4c+s.
-// pv[1 + 4*ci + s] = x[b, 2h'+(s>>1), 2w'+(s&1), c0+ci];  pv[0] = depth 4*c0-1, pv[33] = depth 4*c0+32.
+// PACK.  Volume pixel (h,w) in [H/2, W/2]; a thread owns CPT x-channels c0.. -> DB = 4*CPT packed depths d = 4c+s.
+// pv[1 + 4*ci + s] = x[b, 2h'+(s>>1), 2w'+(s&1), c0+ci];  pv[0] = depth 4*c0-1, pv[DB+1] = depth 4*c0+DB.
+// CPT = 4 (8-byte loads, 16 depths, all four 3-D features in one pass) is used when C/4 <= 64 lanes so the depth
+// halo stays a wave shuffle; CPT = 8 otherwise (C = 512).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int CPT> __device__ __forceinline__ void loadc(const T* p, float* v);
+template <> __device__ __forceinline__ void loadc<bf16_t, 8>(const bf16_t* p, float* v) { load8<bf16_t>(p, v); }
+template <> __device__ __forceinline__ void loadc<float, 8>(const float* p, float* v) { load8<float>(p, v); }
+template <> __device__ __forceinline__ void loadc<bf16_t, 4>(const bf16_t* p, float* v) {
+    const uint2 c = *(const uint2*)p;
+    v[0] = __uint_as_float(c.x << 16); v[1] = __uint_as_float(c.x & 0xffff0000u);
+    v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void loadc<float, 4>(const float* p, float* v) { unpack16<float>(*(const u32x4_t*)p, v); }
+template <typename T, int CPT> __device__ __forceinline__ void storec(T* p, const float* v);
+template <> __device__ __forceinline__ void storec<bf16_t, 8>(bf16_t* p, const float* v) { store8<bf16_t>(p, v); }
+template <> __device__ __forceinline__ void storec<float, 8>(float* p, const float* v) { store8<float>(p, v); }
+template <> __device__ __forceinline__ void storec<bf16_t, 4>(bf16_t* p, const float* v) { *(uint2*)p = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])); }
+template <> __device__ __forceinline__ void storec<float, 4>(float* p, const float* v) { *(u32x4_t*)p = pack16<float>(v); }
+
+template <typename T, int CPT>
 __device__ __forceinline__ void pack_load_window(const P3Args& a, int b, int hh, int ww, int c0, int j, int cb, bool live, float* pv) {
+    constexpr int DB = 4 * CPT;
     const int H2 = a.H >> 1, W2 = a.W >> 1;
     const bool in = live && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2;
     float last3 = 0.f, first0 = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        float v[8];
-        if (in) load8<T>((const T*)a.x + (((long)b * a.H + 2 * hh + (s >> 1)) * a.W + 2 * ww + (s & 1)) * a.ldx + c0, v);
+        float v[CPT];
+        if (in) loadc<T, CPT>((const T*)a.x + (((long)b * a.H + 2 * hh + (s >> 1)) * a.W + 2 * ww + (s & 1)) * a.ldx + c0, v);
         else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+            for (int i = 0; i < CPT; ++i) v[i] = 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pv[1 + 4 * i + s] = v[i];
-        if (s == 3) last3 = v[7];
+        for (int i = 0; i < CPT; ++i) pv[1 + 4 * i + s] = v[i];
+        if (s == 3) last3 = v[CPT - 1];
         if (s == 0) first0 = v[0];
     }
     const float lo = __shfl_up(last3, 1, 64), hi = __shfl_down(first0, 1, 64);
     pv[0] = j > 0 ? lo : 0.f;
-    pv[33] = j < cb - 1 ? hi : 0.f;
+    pv[DB + 1] = j < cb - 1 ? hi : 0.f;
 }
 
-#define P3_THREAD_MAP(HV, WV)                                                  \
+#define P3_THREAD_MAP_N(HV, WV, CPT_)                                          \
     const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;              \
-    const int cb = a.C >> 3;                                                   \
+    const int cb = a.C / (CPT_);                                               \
     const bool live = gid < a.total;                                           \
     const long g = live ? gid : a.total - 1;                                   \
     const int j = (int)(g % cb);                                               \
@@ -74,98 +92,181 @@ __device__ __forceinline__ void pack_load_window(const P3Args& a, int b, int hh,
     const int w = (int)(pix % (WV)); pix /= (WV);                              \
     const int h = (int)(pix % (HV));                                           \
     const int b = (int)(pix / (HV));                                           \
-    const int c0 = j * 8;
+    const int c0 = j * (CPT_);
+#define P3_THREAD_MAP(HV, WV) P3_THREAD_MAP_N(HV, WV, 8)
 
-template <typename T>
+template <typename T, int CPT>
 __global__ __launch_bounds__(256, 3) void pack3d_fwd_kernel(P3Args a) {
+    constexpr int DB = 4 * CPT, FP = CPT == 8 ? 2 : 4;           // features per pass (register budget)
     const int H2 = a.H >> 1, W2 = a.W >> 1;
-    P3_THREAD_MAP(H2, W2);
+    P3_THREAD_MAP_N(H2, W2, CPT);
     const int D = a.C * 4;
     T* op = (T*)a.dst + (((long)b * H2 + h) * W2 + w) * a.lddst;
-    // two of the four 3-D features per pass: 64 accumulators instead of 128 keeps 4 waves/SIMD resident; the
-    // input window is re-read from L1 on the second pass
 #pragma unroll 1
-    for (int fp = 0; fp < 2; ++fp) {
-        float acc[2][32];
+    for (int f0 = 0; f0 < 4; f0 += FP) {
+        float acc[FP][DB];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const float bv = a.b3[2 * fp + f];
+        for (int f = 0; f < FP; ++f) {
+            const float bv = a.b3[f0 + f];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) acc[f][i] = bv;
+            for (int i = 0; i < DB; ++i) acc[f][i] = bv;
         }
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
             const int kh = t / 3, kw = t - 3 * kh;
-            float pv[34];
-            pack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
+            float pv[DB + 2];
+            pack_load_window<T, CPT>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
 #pragma unroll
-            for (int f = 0; f < 2; ++f)
+            for (int f = 0; f < FP; ++f)
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
-                    const float wv = a.w3[(((2 * fp + f) * 3 + kd) * 3 + kh) * 3 + kw];
+                    const float wv = a.w3[(((f0 + f) * 3 + kd) * 3 + kh) * 3 + kw];
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) acc[f][i] = fmaf(wv, pv[i + kd], acc[f][i]);
+                    for (int i = 0; i < DB; ++i) acc[f][i] = fmaf(wv, pv[i + kd], acc[f][i]);
                 }
         }
         if (live) {
 #pragma unroll
-            for (int f = 0; f < 2; ++f)
+            for (int f = 0; f < FP; ++f)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) store8<T>(op + (2 * fp + f) * D + 4 * c0 + 8 * k, &acc[f][8 * k]);
+                for (int k = 0; k < DB / 8; ++k) store8<T>(op + (f0 + f) * D + 4 * c0 + 8 * k, &acc[f][8 * k]);
         }
     }
 }
 
 // dP(d,h,w) = sum_f sum_taps w3[f][kd][kh][kw] * dO[f][d-kd+1][h-kh+1][w-kw+1];  scatter back to x layout
-template <typename T>
+template <typename T, int CPT>
 __global__ __launch_bounds__(256) void pack3d_bwd_data_kernel(P3Args a) {
+    constexpr int DB = 4 * CPT;
     const int H2 = a.H >> 1, W2 = a.W >> 1;
-    P3_THREAD_MAP(H2, W2);
+    P3_THREAD_MAP_N(H2, W2, CPT);
     const int D = a.C * 4;
-    float acc[32];
+    float acc[DB];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    for (int i = 0; i < DB; ++i) acc[i] = 0.f;
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
-            const int kh = t / 3, kw = t - 3 * kh;
-            const int hh = h - kh + 1, ww = w - kw + 1;
-            const bool in = live && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2;
-#pragma unroll 1
-            for (int f = 0; f < 4; ++f) {
-                float pv[34];
-                const T* src = (const T*)a.o + (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + 4 * c0;
+        const int kh = t / 3, kw = t - 3 * kh;
+        const int hh = h - kh + 1, ww = w - kw + 1;
+        const bool in = live && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2;
+#pragma unroll 2
+        for (int f = 0; f < 4; ++f) {
+            float pv[DB + 2];
+            const T* src = (const T*)a.o + (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + 4 * c0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (in) load8<T>(src + 8 * k, &pv[1 + 8 * k]);
-                    else {
+            for (int k = 0; k < DB / 8; ++k) {
+                if (in) load8<T>(src + 8 * k, &pv[1 + 8 * k]);
+                else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) pv[1 + 8 * k + i] = 0.f;
-                    }
-                }
-                const float lo = __shfl_up(pv[32], 1, 64), hi = __shfl_down(pv[1], 1, 64);
-                pv[0] = j > 0 ? lo : 0.f;
-                pv[33] = j < cb - 1 ? hi : 0.f;
-#pragma unroll
-                for (int kd = 0; kd < 3; ++kd) {
-                    const float wv = a.w3[((f * 3 + kd) * 3 + kh) * 3 + kw];
-                    // dP[d] += w[kd] * dO[d - kd + 1]  -> window index (i + 1) - kd + 1 = i + 2 - kd
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) acc[i] = fmaf(wv, pv[i + 2 - kd], acc[i]);
+                    for (int i = 0; i < 8; ++i) pv[1 + 8 * k + i] = 0.f;
                 }
             }
+            const float lo = __shfl_up(pv[DB], 1, 64), hi = __shfl_down(pv[1], 1, 64);
+            pv[0] = j > 0 ? lo : 0.f;
+            pv[DB + 1] = j < cb - 1 ? hi : 0.f;
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float wv = a.w3[((f * 3 + kd) * 3 + kh) * 3 + kw];
+                // dP[d] += w[kd] * dO[d - kd + 1]  -> window index (i + 1) - kd + 1 = i + 2 - kd
+#pragma unroll
+                for (int i = 0; i < DB; ++i) acc[i] = fmaf(wv, pv[i + 2 - kd], acc[i]);
+            }
         }
+    }
     if (!live) return;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        float v[8];
+        float v[CPT];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = acc[4 * i + s];
-        store8<T>((T*)a.dst + (((long)b * a.H + 2 * h + (s >> 1)) * a.W + 2 * w + (s & 1)) * a.lddst + c0, v);
+        for (int i = 0; i < CPT; ++i) v[i] = acc[4 * i + s];
+        storec<T, CPT>((T*)a.dst + (((long)b * a.H + 2 * h + (s >> 1)) * a.W + 2 * w + (s & 1)) * a.lddst + c0, v);
+    }
+}
+
+// vals[FS*10]: per feature [kd*3+kw] for fixed kh, [9] = bias sum -> wave sums -> LDS -> one atomic per value per block
+template <int FS>
+__device__ __forceinline__ void block_reduce_atomic_fs(float (&vals)[FS * 10], int f0, int kh, float* dst, float* sred) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < FS * 10; ++i) {
+        const float s = wave_sum(vals[i]);
+        if (lane == 0) sred[wave * FS * 10 + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < FS * 10) {
+        const int f = f0 + threadIdx.x / 10, i = threadIdx.x % 10;
+        float s = 0.f;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += sred[wv * FS * 10 + threadIdx.x];
+        if (i < 9) atomicAdd(dst + ((f * 3 + i / 3) * 3 + kh) * 3 + (i % 3), s);
+        else if (kh == 1) atomicAdd(dst + 108 + f, s);
+    }
+    __syncthreads();
+}
+
+// dw3[f][kd][kh][kw] = sum dO[f][d][h][w] * P(d+kd-1, h+kh-1, w+kw-1);  db3[f] = sum dO[f].  grid.y = kh.
+template <typename T, int CPT>
+__global__ __launch_bounds__(256, 3) void pack3d_bwd_weight_kernel(P3Args a) {
+    constexpr int DB = 4 * CPT, FS = CPT == 8 ? 1 : 2;             // features per sweep over the pixels (register budget)
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    __shared__ float sred[4 * FS * 10];
+    const int kh = blockIdx.y;
+    const int cb = a.C / CPT;
+    const int D = a.C * 4;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    const long iters = (a.total + nthreads - 1) / nthreads;
+#pragma unroll 1
+    for (int f0 = 0; f0 < 4; f0 += FS) {
+        float acc[FS * 10];
+#pragma unroll
+        for (int i = 0; i < FS * 10; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (long it = 0; it < iters; ++it) {
+            const long gid = it * nthreads + blockIdx.x * (long)blockDim.x + threadIdx.x;
+            const bool live = gid < a.total;
+            const long g = live ? gid : a.total - 1;
+            const int j = (int)(g % cb);
+            long pix = g / cb;
+            const int w = (int)(pix % W2); pix /= W2;
+            const int h = (int)(pix % H2);
+            const int b = (int)(pix / H2);
+            const int c0 = j * CPT;
+            const T* src = (const T*)a.o + (((long)b * H2 + h) * W2 + w) * a.ldo + 4 * c0;
+            float go[FS][DB];
+#pragma unroll
+            for (int f = 0; f < FS; ++f) {
+#pragma unroll
+                for (int k = 0; k < DB / 8; ++k) {
+                    if (live) load8<T>(src + (f0 + f) * D + 8 * k, &go[f][8 * k]);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) go[f][8 * k + i] = 0.f;
+                    }
+                }
+                float sb = 0.f;
+#pragma unroll
+                for (int i = 0; i < DB; ++i) sb += go[f][i];
+                acc[f * 10 + 9] += sb;
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                float pv[DB + 2];
+                pack_load_window<T, CPT>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
+#pragma unroll
+                for (int f = 0; f < FS; ++f)
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int i = 0; i < DB; ++i) sacc = fmaf(go[f][i], pv[i + kd], sacc);
+                        acc[f * 10 + kd * 3 + kw] += sacc;
+                    }
+            }
+        }
+        block_reduce_atomic_fs<FS>(acc, f0, kh, a.dw3, sred);
     }
 }
 
 // vals[40] per thread: [0..35] = dw3[f][kd][kh fixed][kw] at i = (f*3+kd)*3+kw, [36..39] = db3[f] (kh == 1 blocks only)
-// -> wave sums -> LDS -> one atomic per value per block into dwb[112]
 __device__ __forceinline__ void block_reduce_atomic(float (&vals)[40], int kh, float* dst, float* sred) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -180,84 +281,6 @@ __device__ __forceinline__ void block_reduce_atomic(float (&vals)[40], int kh, f
         for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += sred[wv * 40 + i];
         if (i < 36) atomicAdd(dst + (i / 3) * 9 + kh * 3 + (i % 3), s);
         else if (kh == 1) atomicAdd(dst + 108 + (i - 36), s);
-    }
-}
-
-// dw3[f][kd][kh][kw] = sum dO[f][d][h][w] * P(d+kd-1, h+kh-1, w+kw-1);  db3[f] = sum dO[f]
-// vals[10]: [kd*3+kw] for fixed (f, kh), [9] = bias sum -> wave sums -> LDS -> one atomic per value per block
-__device__ __forceinline__ void block_reduce_atomic10(float (&vals)[10], int f, int kh, float* dst, float* sred) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const float s = wave_sum(vals[i]);
-        if (lane == 0) sred[wave * 10 + i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 10) {
-        const int i = threadIdx.x;
-        float s = 0.f;
-        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += sred[wv * 10 + i];
-        if (i < 9) atomicAdd(dst + ((f * 3 + i / 3) * 3 + kh) * 3 + (i % 3), s);
-        else if (kh == 1) atomicAdd(dst + 108 + f, s);
-    }
-    __syncthreads();
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void pack3d_bwd_weight_kernel(P3Args a) {
-    const int H2 = a.H >> 1, W2 = a.W >> 1;
-    __shared__ float sred[4 * 10];
-    const int kh = blockIdx.y;                           // one kernel row per grid.y slice
-    const int cb = a.C >> 3;
-    const int D = a.C * 4;
-    const long nthreads = (long)gridDim.x * blockDim.x;   // grid.x only; grid.y = kh
-    const long iters = (a.total + nthreads - 1) / nthreads;
-    // one 3-D feature per sweep over this block's pixels: 10 accumulators + a 32-value gradient row live at a
-    // time (all four features at once needs > 256 VGPRs); the input window is re-read from L1/L2 on later sweeps
-#pragma unroll 1
-    for (int f = 0; f < 4; ++f) {
-        float acc[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-#pragma unroll 1
-        for (long it = 0; it < iters; ++it) {
-            const long gid = it * nthreads + blockIdx.x * (long)blockDim.x + threadIdx.x;
-            const bool live = gid < a.total;
-            const long g = live ? gid : a.total - 1;
-            const int j = (int)(g % cb);
-            long pix = g / cb;
-            const int w = (int)(pix % W2); pix /= W2;
-            const int h = (int)(pix % H2);
-            const int b = (int)(pix / H2);
-            const int c0 = j * 8;
-            const T* src = (const T*)a.o + (((long)b * H2 + h) * W2 + w) * a.ldo + f * D + 4 * c0;
-            float go[32];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (live) load8<T>(src + 8 * k, &go[8 * k]);
-                else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) go[8 * k + i] = 0.f;
-                }
-            }
-            float sb = 0.f;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) sb += go[i];
-            acc[9] += sb;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                float pv[34];
-                pack_load_window<T>(a, b, h + kh - 1, w + kw - 1, c0, j, cb, live, pv);
-#pragma unroll
-                for (int kd = 0; kd < 3; ++kd) {
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) sacc = fmaf(go[i], pv[i + kd], sacc);
-                    acc[kd * 3 + kw] += sacc;
-                }
-            }
-        }
-        block_reduce_atomic10(acc, f, kh, a.dw3, sred);
     }
 }
 
@@ -321,8 +344,8 @@ __global__ __launch_bounds__(256, 3) void unpack3d_fwd_kernel(P3Args a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {       // q = q0 + i: position s = i&3, channel (q0>>2) + (i>>2)
             T* d = (T*)p[s];
-            Elem<T>::st(d, acc[f][s]);
-            Elem<T>::st(d + 1, acc[f][4 + s]);
+            if constexpr (sizeof(T) == 2) *(unsigned*)d = pack2bf(acc[f][s], acc[f][4 + s]);
+            else *(float2*)d = make_float2(acc[f][s], acc[f][4 + s]);
         }
     }
 }
@@ -334,7 +357,15 @@ __device__ __forceinline__ void unpack_load_feat(const P3Args& a, int b, int hh,
         const T* p[4];
         shuffled_ptrs<T>(a, a.o, a.ldo, b, hh, ww, f, c0, p);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { pv[1 + s] = Elem<T>::ld(p[s]); pv[1 + 4 + s] = Elem<T>::ld(p[s] + 1); }
+        for (int s = 0; s < 4; ++s) {                 // two adjacent channels per shuffled position: one 4-byte (bf16) load
+            if constexpr (sizeof(T) == 2) {
+                const unsigned u = *(const unsigned*)p[s];
+                pv[1 + s] = __uint_as_float(u << 16); pv[1 + 4 + s] = __uint_as_float(u & 0xffff0000u);
+            } else {
+                const float2 u = *(const float2*)p[s];
+                pv[1 + s] = u.x; pv[1 + 4 + s] = u.y;
+            }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) pv[1 + i] = 0.f;
@@ -438,7 +469,8 @@ int mte_pack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, vo
     if (!x || !w3 || !b3 || !out || !p3_ok(C) || (H & 1) || (W & 1)) return MTE_ERR_ARG;
     P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    return launch_p3(dtype, pack3d_fwd_kernel<bf16_t>, pack3d_fwd_kernel<float>, a, a.total, stream);
+    if (C <= 256) { a.total *= 2; return launch_p3(dtype, pack3d_fwd_kernel<bf16_t, 4>, pack3d_fwd_kernel<float, 4>, a, a.total, stream); }
+    return launch_p3(dtype, pack3d_fwd_kernel<bf16_t, 8>, pack3d_fwd_kernel<float, 8>, a, a.total, stream);
 }
 int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, long lddx,
                         int B, int H, int W, int C, int dtype, hipStream_t stream) {
@@ -446,7 +478,8 @@ int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, l
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    return launch_p3(dtype, pack3d_bwd_data_kernel<bf16_t>, pack3d_bwd_data_kernel<float>, a, a.total, stream);
+    if (C <= 256) { a.total *= 2; return launch_p3(dtype, pack3d_bwd_data_kernel<bf16_t, 4>, pack3d_bwd_data_kernel<float, 4>, a, a.total, stream); }
+    return launch_p3(dtype, pack3d_bwd_data_kernel<bf16_t, 8>, pack3d_bwd_data_kernel<float, 8>, a, a.total, stream);
 }
 // dwb[112] (fp32, zeroed here): [0..107] = dw3, [108..111] = db3
 int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
@@ -456,8 +489,10 @@ int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, f
     if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (C <= 256) a.total *= 2;
     long threads = a.total < 256L * 1024 ? a.total : 256L * 1024;
-    return launch_p3(dtype, pack3d_bwd_weight_kernel<bf16_t>, pack3d_bwd_weight_kernel<float>, a, threads, stream, 3);
+    if (C <= 256) return launch_p3(dtype, pack3d_bwd_weight_kernel<bf16_t, 4>, pack3d_bwd_weight_kernel<float, 4>, a, threads, stream, 3);
+    return launch_p3(dtype, pack3d_bwd_weight_kernel<bf16_t, 8>, pack3d_bwd_weight_kernel<float, 8>, a, threads, stream, 3);
 }
 
 // out[B,2H,2W,C] = pixel_shuffle(conv3d(x[B,H,W,C]))                   (UnpackLayerConv3d after its Conv2D)

@@ -179,7 +179,7 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None):
     return out
 
 
-def conv_backward(x, dy, w, pack, need_dx, need_dw=True):
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True):
     """-> (dx or None, dw (OIHW fp32) or None, dbias fp32)"""
     cout, cin, kh, kw = w.shape
     B, Cp, H, W = x.shape
@@ -195,8 +195,9 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True):
             lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
         dw = torch.empty_like(w, dtype=torch.float32)
         lib.mte_unpack_conv_wgrad(stage.data_ptr(), dw.data_ptr(), cout, cin, kh, kw, Cp, st)
-        dbias = torch.empty((cout,), dtype=torch.float32, device=x.device)
-        lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
+        if need_dbias:
+            dbias = torch.empty((cout,), dtype=torch.float32, device=x.device)
+            lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
     if need_dx and _patch_ok(W, cout, Cp, kh, kw, x.dtype):
         dx = new_act(B, Cp, H, W, x.dtype, x.device)
         dxp, lddx = _pl(dx)
@@ -224,7 +225,7 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
     return z, stats
 
 
-def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2):
+def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbias=False):
     B, C, H, W = y1.shape
     dz = as_act(dz, y1.dtype)
     red = torch.empty((B, C, 2), dtype=torch.float32, device=y1.device)
@@ -232,13 +233,16 @@ def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2):
     d2 = new_act(B, C, H, W, y1.dtype, y1.device) if need_d2 else None
     dgamma = torch.empty((C,), dtype=torch.float32, device=y1.device)
     dbeta = torch.empty((C,), dtype=torch.float32, device=y1.device)
+    dbias = torch.empty((C,), dtype=torch.float32, device=y1.device) if want_dbias else None
     pz, lz = _pl(dz)
     p1, l1 = _pl(y1)
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     pd1, ld1 = _pl(d1)
     pd2, ld2 = _pl(d2) if d2 is not None else (0, 0)
     lib.mte_gn_elu_bwd(pz, lz, p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
-                       pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C, eps, _dt(y1), _stream())
+                       pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), B, H * W, C, eps, _dt(y1), _stream())
+    if want_dbias:
+        return d1, d2, dgamma, dbeta, dbias
     return d1, d2, dgamma, dbeta
 
 
@@ -261,8 +265,8 @@ class ConvGnEluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         x, w, y, stats, gamma, beta = ctx.saved_tensors
-        dy, _, dgamma, dbeta = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False)
-        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0])
+        dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True)
+        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False)
         return dx, dw, db, dgamma, dbeta, None
 
 
