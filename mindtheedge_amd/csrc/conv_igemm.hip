@@ -628,9 +628,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, lo
 
 extern "C" {
 
-// development knob: key 0 = igemm tile loader (1 = LDS-DMA, 0 = register staging).  Not part of the product contract.
+// development knobs: key 0 = igemm tile loader (1 = LDS-DMA ring, 0 = register staging); key 1 = conv3d pack stencils
+// (1 = LDS-tiled, 0 = gather).  Not part of the product contract.
+extern "C" int mtei_set_pack3d_lds(int value);
 int mte_debug_set(int key, int value) {
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
+    if (key == 1) return mtei_set_pack3d_lds(value);
     return MTE_ERR_ARG;
 }
 

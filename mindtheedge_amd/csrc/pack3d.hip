@@ -460,6 +460,266 @@ bool p3_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <=
 
 }  // namespace
 
+// =====================================================================================================
+// LDS-tiled PACK stencils (bf16).  The gather versions above re-fetch every input 9x (fwd) / 36x (bwd) through
+// L1/L2 and run at ~10 % of the fp32-VALU roof; here a workgroup stages the (TH+2)x(TW+2) halo tile of the
+// PACKED volume (all D = 4C depths, depth-contiguous) in LDS once, so each tap is one ds_read_b128 + two 2-byte
+// halo reads, and HBM sees every tensor element about once.  Tile area is chosen so that TH*TW*C = 4096.
+// =====================================================================================================
+namespace {
+
+struct P3Tile { int TH, TW; };
+inline P3Tile p3_tile(int C) {
+    if (C <= 32) return {8, 16};
+    if (C <= 64) return {4, 16};
+    if (C <= 128) return {4, 8};
+    if (C <= 256) return {2, 8};
+    return {2, 4};
+}
+inline size_t p3_lds_bytes(int C) { P3Tile t = p3_tile(C); return (size_t)(t.TH + 2) * (t.TW + 2) * 4 * C * 2; }
+
+struct P3LArgs {
+    const bf16_t* x; long ldx;         // un-packed side [B,H,W,C]
+    const bf16_t* o; long ldo;         // feature side [B,H/2,W/2,16C]
+    bf16_t* dst; long lddst;
+    const float* w3; const float* b3;
+    float* dwb;                        // [112]
+    int B, H, W, C, TH, TW;
+    int tiles_h, tiles_w, ntiles;
+};
+
+// stage packed P tile: tile[(ph)][(pw)][d], d = 4c + s, origin (h0-1, w0-1), zero outside the image
+__device__ __forceinline__ void stage_packed_tile(const P3LArgs& a, bf16_t* tile, int b, int h0, int w0) {
+    const int PHu = 2 * (a.TH + 2), PWu = 2 * (a.TW + 2), cpp = a.C >> 3, D = 4 * a.C;
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    const int total = PHu * PWu * cpp;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int cc = idx % cpp; int t = idx / cpp;
+        const int px = t % PWu, py = t / PWu;
+        const int hh = h0 - 1 + (py >> 1), ww = w0 - 1 + (px >> 1);
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if ((unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2)
+            v = *(const u32x4_t*)(a.x + (((long)b * a.H + 2 * hh + (py & 1)) * a.W + 2 * ww + (px & 1)) * a.ldx + cc * 8);
+        bf16_t* dstp = tile + ((py >> 1) * (a.TW + 2) + (px >> 1)) * D + 32 * cc + ((py & 1) * 2 + (px & 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dstp[8 * i] = (bf16_t)(v[i] & 0xffffu); dstp[8 * i + 4] = (bf16_t)(v[i] >> 16); }
+    }
+}
+
+// window of NB*8 depths + 1 halo each side at tile pixel `pix`, depth d0 -> pv[0 .. NB*8+1]
+template <int NB>
+__device__ __forceinline__ void lds_window(const bf16_t* tile, int pix, int D, int d0, float* pv) {
+    const bf16_t* p = tile + pix * D + d0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) unpack16<bf16_t>(*(const u32x4_t*)(p + 8 * k), &pv[1 + 8 * k]);
+    pv[0] = d0 > 0 ? bf2f(p[-1]) : 0.f;
+    pv[NB * 8 + 1] = d0 + NB * 8 < D ? bf2f(p[NB * 8]) : 0.f;
+}
+
+__device__ __forceinline__ void tile_coords(const P3LArgs& a, int tile, int& b, int& h0, int& w0) {
+    const int tw = tile % a.tiles_w; int t = tile / a.tiles_w;
+    const int th = t % a.tiles_h; b = t / a.tiles_h;
+    h0 = th * a.TH; w0 = tw * a.TW;
+}
+
+__global__ __launch_bounds__(256, 4) void pack3d_fwd_lds_kernel(P3LArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)smem_;
+    __shared__ float sw[112];
+    if (threadIdx.x < 108) sw[threadIdx.x] = a.w3[threadIdx.x];
+    if (threadIdx.x < 4) sw[108 + threadIdx.x] = a.b3[threadIdx.x];
+    int b, h0, w0;
+    tile_coords(a, blockIdx.x, b, h0, w0);
+    stage_packed_tile(a, tile, b, h0, w0);
+    __syncthreads();
+    const int D = 4 * a.C, dbs = D >> 3, H2 = a.H >> 1, W2 = a.W >> 1;
+    const int items = a.TH * a.TW * dbs;
+#pragma unroll 1
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int db = it % dbs; const int p = it / dbs;
+        const int pw = p % a.TW, ph = p / a.TW;
+        const int d0 = db * 8;
+        float acc[4][8];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[f][i] = sw[108 + f];
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {                      // runtime tap loop: the 12 weights of a tap are LDS broadcasts
+            const int kh = t / 3, kw = t - 3 * kh;
+            float pv[10];
+            lds_window<1>(tile, (ph + kh) * (a.TW + 2) + pw + kw, D, d0, pv);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float wv = sw[(f * 3 + kd) * 9 + t];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[f][i] = fmaf(wv, pv[i + kd], acc[f][i]);
+                }
+        }
+        const int h = h0 + ph, w = w0 + pw;
+        if (h < H2 && w < W2) {
+            bf16_t* op = a.dst + (((long)b * H2 + h) * W2 + w) * a.lddst + d0;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) *(u32x4_t*)(op + f * D) = pack16<bf16_t>(acc[f]);
+        }
+    }
+}
+
+// dx (un-packed) = conv3d^T(dO); one feature plane of dO in LDS at a time, 2 items (pixel, 32 depths) per thread
+__global__ __launch_bounds__(256) void pack3d_bwd_data_lds_kernel(P3LArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)smem_;
+    __shared__ float sw[108];
+    if (threadIdx.x < 108) sw[threadIdx.x] = a.w3[threadIdx.x];
+    int b, h0, w0;
+    tile_coords(a, blockIdx.x, b, h0, w0);
+    const int D = 4 * a.C, H2 = a.H >> 1, W2 = a.W >> 1, cbs = a.C >> 3;
+    const int PW = a.TW + 2, npix = (a.TH + 2) * PW, cpp = D >> 3;
+    float acc[2][32];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[k][i] = 0.f;
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+        __syncthreads();                                   // previous plane fully consumed
+        for (int idx = threadIdx.x; idx < npix * cpp; idx += 256) {
+            const int dc = idx % cpp; const int p = idx / cpp;
+            const int hh = h0 - 1 + p / PW, ww = w0 - 1 + p % PW;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if ((unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2)
+                v = *(const u32x4_t*)(a.o + (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + dc * 8);
+            *(u32x4_t*)(tile + p * D + dc * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int it = threadIdx.x + k * 256;           // TH*TW*C/8 == 512 items (fewer for C < 32)
+            const int cb = it % cbs; const int p = it / cbs;
+            const int pw = p % a.TW, ph = p / a.TW;
+            if (ph >= a.TH) continue;
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t - 3 * kh;
+                float pv[34];
+                lds_window<4>(tile, (ph + 2 - kh) * PW + pw + 2 - kw, D, 32 * cb, pv);
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float wv = sw[((f * 3 + kd) * 3 + kh) * 3 + kw];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[k][i] = fmaf(wv, pv[i + 2 - kd], acc[k][i]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int it = threadIdx.x + k * 256;
+        const int cb = it % cbs; const int p = it / cbs;
+        const int pw = p % a.TW, ph = p / a.TW;
+        const int h = h0 + ph, w = w0 + pw;
+        if (ph < a.TH && h < H2 && w < W2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = acc[k][4 * i + s];
+                *(u32x4_t*)(a.dst + (((long)b * a.H + 2 * h + (s >> 1)) * a.W + 2 * w + (s & 1)) * a.lddst + cb * 8) = pack16<bf16_t>(v);
+            }
+        }
+    }
+}
+
+// dw3/db3: persistent over tiles; all 27 taps x 4 features accumulate in registers
+__global__ __launch_bounds__(256) void pack3d_bwd_weight_lds_kernel(P3LArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)smem_;
+    __shared__ float sred[4 * 112];
+    const int D = 4 * a.C, dbs = D >> 3, H2 = a.H >> 1, W2 = a.W >> 1;
+    const int items = a.TH * a.TW * dbs;
+    float acc[112];
+#pragma unroll
+    for (int i = 0; i < 112; ++i) acc[i] = 0.f;
+    for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+        int b, h0, w0;
+        tile_coords(a, tl, b, h0, w0);
+        __syncthreads();
+        stage_packed_tile(a, tile, b, h0, w0);
+        __syncthreads();
+#pragma unroll 1
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int db = it % dbs; const int p = it / dbs;
+            const int pw = p % a.TW, ph = p / a.TW;
+            const int h = h0 + ph, w = w0 + pw;
+            if (h >= H2 || w >= W2) continue;
+            const int d0 = db * 8;
+            const bf16_t* src = a.o + (((long)b * H2 + h) * W2 + w) * a.ldo + d0;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {                  // one feature's 8 gradient values live at a time
+                float go[8];
+                unpack16<bf16_t>(*(const u32x4_t*)(src + f * D), go);
+                float sb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sb += go[i];
+                acc[108 + f] += sb;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        float pv[10];
+                        lds_window<1>(tile, (ph + kh) * (a.TW + 2) + pw + kw, D, d0, pv);
+#pragma unroll
+                        for (int kd = 0; kd < 3; ++kd) {
+                            float sacc = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) sacc = fmaf(go[i], pv[i + kd], sacc);
+                            acc[((f * 3 + kd) * 3 + kh) * 3 + kw] += sacc;
+                        }
+                        asm volatile("" ::: "memory");   // keep window reads from being hoisted together (VGPR budget)
+                    }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 112; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) sred[wave * 112 + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 112)
+        atomicAdd(a.dwb + threadIdx.x, sred[threadIdx.x] + sred[112 + threadIdx.x] + sred[224 + threadIdx.x] + sred[336 + threadIdx.x]);
+}
+
+template <typename KF> int launch_p3l(KF kf, P3LArgs a, int grid, hipStream_t st) {
+    const size_t lds = p3_lds_bytes(a.C);
+    static const void* done[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool seen = false;
+    for (int i = 0; i < 4; ++i) seen = seen || done[i] == (const void*)kf;
+    if (!seen) {
+        if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess) return MTE_ERR_LAUNCH;
+        for (int i = 0; i < 4; ++i) if (!done[i]) { done[i] = (const void*)kf; break; }
+    }
+    hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);
+    return mte_check_launch();
+}
+
+inline P3LArgs p3l_args(int B, int H, int W, int C) {
+    P3LArgs a{}; a.B = B; a.H = H; a.W = W; a.C = C;
+    const P3Tile t = p3_tile(C); a.TH = t.TH; a.TW = t.TW;
+    a.tiles_h = (H / 2 + t.TH - 1) / t.TH; a.tiles_w = (W / 2 + t.TW - 1) / t.TW; a.ntiles = a.tiles_h * a.tiles_w * B;
+    return a;
+}
+
+int g_p3_lds = 1;                                   // development knob (mte_debug_set(1, v))
+
+}  // namespace
+
+extern "C" int mtei_set_pack3d_lds(int value) { g_p3_lds = value; return MTE_OK; }
+
+
 extern "C" {
 
 // out[B,H/2,W/2,16C] = conv3d(pixel_unshuffle(x[B,H,W,C]))            (PackLayerConv3d up to its Conv2D)
@@ -469,6 +729,10 @@ int mte_pack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, vo
     if (!x || !w3 || !b3 || !out || !p3_ok(C) || (H & 1) || (W & 1)) return MTE_ERR_ARG;
     P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
+        P3LArgs l = p3l_args(B, H, W, C); l.x = (const bf16_t*)x; l.ldx = ldx; l.dst = (bf16_t*)out; l.lddst = ldo; l.w3 = w3; l.b3 = b3;
+        return launch_p3l(pack3d_fwd_lds_kernel, l, l.ntiles, stream);
+    }
     if (C <= 256) { a.total *= 2; return launch_p3(dtype, pack3d_fwd_kernel<bf16_t, 4>, pack3d_fwd_kernel<float, 4>, a, a.total, stream); }
     return launch_p3(dtype, pack3d_fwd_kernel<bf16_t, 8>, pack3d_fwd_kernel<float, 8>, a, a.total, stream);
 }
@@ -478,6 +742,10 @@ int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, l
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
+        P3LArgs l = p3l_args(B, H, W, C); l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
+        return launch_p3l(pack3d_bwd_data_lds_kernel, l, l.ntiles, stream);
+    }
     if (C <= 256) { a.total *= 2; return launch_p3(dtype, pack3d_bwd_data_kernel<bf16_t, 4>, pack3d_bwd_data_kernel<float, 4>, a, a.total, stream); }
     return launch_p3(dtype, pack3d_bwd_data_kernel<bf16_t, 8>, pack3d_bwd_data_kernel<float, 8>, a, a.total, stream);
 }
@@ -489,6 +757,10 @@ int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, f
     if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
+        P3LArgs l = p3l_args(B, H, W, C); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;
+        return launch_p3l(pack3d_bwd_weight_lds_kernel, l, l.ntiles < 512 ? l.ntiles : 512, stream);
+    }
     if (C <= 256) a.total *= 2;
     long threads = a.total < 256L * 1024 ? a.total : 256L * 1024;
     if (C <= 256) return launch_p3(dtype, pack3d_bwd_weight_kernel<bf16_t, 4>, pack3d_bwd_weight_kernel<float, 4>, a, threads, stream, 3);
