@@ -37,6 +37,54 @@ def weights_epoch():
     return _state["weights_epoch"]
 
 
+class GradSink:
+    """Lets backward kernels write parameter gradients straight into pre-allocated storage (the flat gradient buffer
+    of trainers.data_parallel.FlatParameters) instead of returning fresh tensors that autograd then adds into .grad:
+    every parameter on this path receives exactly one gradient per backward, so a plain store into the zeroed buffer
+    IS the accumulation.  ``ready(p)`` replaces the post-accumulate-grad hook (bucketed all-reduce trigger)."""
+
+    def __init__(self):
+        self.views = {}          # param.data_ptr() -> flat fp32 gradient view
+        self.on_ready = None
+
+    def register(self, p, view):
+        self.views[p.data_ptr()] = view
+
+    def lookup(self, p):
+        v = self.views.get(p.data_ptr())
+        if v is not None and p.grad is not None and p.grad.data_ptr() == v.data_ptr() and v.shape == p.shape:
+            return v
+        return None
+
+    def ready(self, p):
+        if self.on_ready is not None:
+            self.on_ready(p)
+
+
+_sink = {"active": None}
+
+
+def set_grad_sink(sink):
+    _sink["active"] = sink
+
+
+def _grad_dst(p):
+    """(tensor to write the gradient of `p` into, True if it is the sink's storage)."""
+    sk = _sink["active"]
+    if sk is not None:
+        v = sk.lookup(p)
+        if v is not None:
+            return v, True
+    return torch.empty(p.shape, dtype=torch.float32, device=p.device), False
+
+
+def _grad_ret(p, t, sunk):
+    if sunk:
+        _sink["active"].ready(p)
+        return None
+    return t
+
+
 def _dt(t):
     if t.dtype == torch.bfloat16:
         return DT_BF16
@@ -179,8 +227,8 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None):
     return out
 
 
-def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True):
-    """-> (dx or None, dw (OIHW fp32) or None, dbias fp32)"""
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None):
+    """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations"""
     cout, cin, kh, kw = w.shape
     B, Cp, H, W = x.shape
     dyp, lddy = _pl(dy)
@@ -193,10 +241,10 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True):
             lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, st)
         else:
             lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
-        dw = torch.empty_like(w, dtype=torch.float32)
+        dw = dw_out if dw_out is not None else torch.empty_like(w, dtype=torch.float32)
         lib.mte_unpack_conv_wgrad(stage.data_ptr(), dw.data_ptr(), cout, cin, kh, kw, Cp, st)
         if need_dbias:
-            dbias = torch.empty((cout,), dtype=torch.float32, device=x.device)
+            dbias = dbias_out if dbias_out is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
             lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
     if need_dx and _patch_ok(W, cout, Cp, kh, kw, x.dtype):
         dx = new_act(B, Cp, H, W, x.dtype, x.device)
@@ -225,15 +273,16 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
     return z, stats
 
 
-def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbias=False):
+def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbias=False, dgamma=None, dbeta=None, dbias=None):
     B, C, H, W = y1.shape
     dz = as_act(dz, y1.dtype)
     red = torch.empty((B, C, 2), dtype=torch.float32, device=y1.device)
     d1 = new_act(B, C, H, W, y1.dtype, y1.device)
     d2 = new_act(B, C, H, W, y1.dtype, y1.device) if need_d2 else None
-    dgamma = torch.empty((C,), dtype=torch.float32, device=y1.device)
-    dbeta = torch.empty((C,), dtype=torch.float32, device=y1.device)
-    dbias = torch.empty((C,), dtype=torch.float32, device=y1.device) if want_dbias else None
+    dgamma = dgamma if dgamma is not None else torch.empty((C,), dtype=torch.float32, device=y1.device)
+    dbeta = dbeta if dbeta is not None else torch.empty((C,), dtype=torch.float32, device=y1.device)
+    if want_dbias and dbias is None:
+        dbias = torch.empty((C,), dtype=torch.float32, device=y1.device)
     pz, lz = _pl(dz)
     p1, l1 = _pl(y1)
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
@@ -260,14 +309,21 @@ class ConvGnEluFn(torch.autograd.Function):
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS)
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
+        ctx.bias = b
         return z
 
     @staticmethod
     def backward(ctx, dz):
         x, w, y, stats, gamma, beta = ctx.saved_tensors
-        dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True)
-        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False)
-        return dx, dw, db, dgamma, dbeta, None
+        b = ctx.bias
+        gg, sg = _grad_dst(gamma)
+        gb, sb = _grad_dst(beta)
+        gbias, sbias = _grad_dst(b)
+        gw, sw = _grad_dst(w)
+        dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
+                                                dgamma=gg, dbeta=gb, dbias=gbias)
+        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw)
+        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None
 
 
 class ConvFn(torch.autograd.Function):
@@ -280,14 +336,18 @@ class ConvFn(torch.autograd.Function):
         y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
         ctx.save_for_backward(x, w)
         ctx.pack = pack
+        ctx.bias = b
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        b = ctx.bias
         dy = as_act(dy, x.dtype)
-        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0])
-        return dx, dw, db, None
+        gw, sw = _grad_dst(w)
+        gbias, sbias = _grad_dst(b)
+        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias)
+        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None
 
 
 class ResidualTailFn(torch.autograd.Function):
@@ -303,8 +363,10 @@ class ResidualTailFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         a, s, stats, gamma, beta = ctx.saved_tensors
-        da, ds, dgamma, dbeta = _gn_backward(dz, a, s, ctx.scale, stats, gamma, beta, GN_EPS, True)
-        return da, ds, None, dgamma, dbeta
+        gg, sg = _grad_dst(gamma)
+        gb, sb = _grad_dst(beta)
+        da, ds, dgamma, dbeta = _gn_backward(dz, a, s, ctx.scale, stats, gamma, beta, GN_EPS, True, dgamma=gg, dbeta=gb)
+        return da, ds, None, _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb)
 
 
 class Pack3dFn(torch.autograd.Function):

@@ -38,6 +38,14 @@ class FlatParameters:
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.sink = None
+        if dev.type == "cuda":
+            # backward kernels store conv / GroupNorm parameter gradients straight into self.grad (no per-tensor add)
+            from .. import kernels as K
+            self.sink = K.GradSink()
+            for p in order:
+                self.sink.register(p, p.grad)
+            K.set_grad_sink(self.sink)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -68,6 +76,8 @@ class BucketedAllReduce:
         if self.world > 1:
             for p in flat.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+            if getattr(flat, "sink", None) is not None:
+                flat.sink.on_ready = self._on_grad_ready      # gradients written in place never reach AccumulateGrad
 
     def _on_grad_ready(self, p):
         b = self.bucket_of[id(p)]
