@@ -90,6 +90,16 @@ int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx,
 int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, float* dwb,
                             int B, int H, int W, int C, int dtype, mte_stream_t stream);
 
+/* ---- conv3d folded into the pack convolution (see csrc/pack_fold.hip): exact away from the border; kernels.PackFoldedConvFn
+ *      recomputes the k/2-pixel border bands with the unfolded kernels.  (layers01.py:241-247) */
+int mte_fold_pack_weights(const float* W, const float* K3, const float* b, const float* b3, float* Wf, float* bf,
+                          int Co, int D, int k, mte_stream_t stream);
+int mte_unfold_pack_wgrad(const float* dWf, const float* dbf, const float* W, const float* K3, const float* b3,
+                          float* dW, float* dk3b, int Co, int D, int k, int accumulate, mte_stream_t stream);
+int mte_pixel_shuffle(const void* src, long lds_, void* dst, long ldd, int B, int H, int W, int C, int dir, int dtype, mte_stream_t stream);
+int mte_copy_rect(const void* src, long lds_, int Hs, int Ws, int sy, int sx, void* dst, long ldd, int Hd, int Wd, int dy, int dx,
+                  int B, int h, int w, int C, int mode, int dtype, mte_stream_t stream);
+
 /* ---- InvDepth head: sigmoid(conv3x3(x) + b) / min_depth  (layers01.py:99-123) */
 int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,
                      int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
     float s[P], q[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) { s[i] = 0.f; q[i] = 0.f; }
+#pragma unroll 4
     for (int p = p_begin + prow; p < p_end; p += rstep) {
         float v[P];
         load_v<T>(a, (long)b * a.HW + p, b, ch0, v);
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void gn_elu_fwd_kernel(GnArgs a) {
         ka[i] = rstd * gm;
         kb[i] = a.beta[ch0 + i] - mean * rstd * gm;
     }
+#pragma unroll 4
     for (int p = p_begin + prow; p < p_end; p += rstep) {
         const long pix = (long)b * a.HW + p;
         float v[P];
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
         gm[i] = a.gamma[ch0 + i]; bt[i] = a.beta[ch0 + i];
         r1[i] = 0.f; r2[i] = 0.f;
     }
+#pragma unroll 2
     for (int p = p_begin + prow; p < p_end; p += rstep) {
         const long pix = (long)b * a.HW + p;
         float v[P], g[P];
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
             s1[i] = t1 * inv_n; s2[i] = t2 * inv_n;
         }
     }
+#pragma unroll 2
     for (int p = p_begin + prow; p < p_end; p += rstep) {
         const long pix = (long)b * a.HW + p;
         float v[P], g[P];

@@ -201,7 +201,16 @@ def _splitk_workspace(M, N, device):
     return torch.empty((M * N,), dtype=torch.float32, device=device), M * N
 
 
-_cfg = {"patch_kernels": True}
+_cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30}
+
+
+def use_pack_folding(flag):
+    """Enable/disable folding conv3d into the pack convolution (tests compare both formulations)."""
+    _cfg["pack_folding"] = bool(flag)
+
+
+def pack_folding_enabled():
+    return _cfg["pack_folding"]
 
 
 def use_patch_kernels(flag):
@@ -429,6 +438,143 @@ class Unpack3dFn(torch.autograd.Function):
         dxp, lddx = _pl(dx)
         lib.mte_unpack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), st)
         return dx, dwb[:108].view(4, 1, 3, 3, 3), dwb[108:112]
+
+
+def _rect(src, sy, sx, dst, dy, dx, h, w, mode=0):
+    """copy (0) / add (1) / zero (2) a [h x w] pixel rectangle between NHWC activations of equal batch and channels."""
+    B, C, Hd, Wd = dst.shape
+    dp, ldd = _pl(dst)
+    if mode == 2:
+        lib.mte_copy_rect(0, 0, 0, 0, 0, 0, dp, ldd, Hd, Wd, dy, dx, B, h, w, C, 2, _dt(dst), _stream())
+        return
+    sp, lds_ = _pl(src)
+    lib.mte_copy_rect(sp, lds_, src.shape[2], src.shape[3], sy, sx, dp, ldd, Hd, Wd, dy, dx, B, h, w, C, mode, _dt(dst), _stream())
+
+
+def _deliver(p, t):
+    """hand a finished parameter gradient to the sink (flat buffer) or back to autograd"""
+    sk = _sink["active"]
+    if sk is not None:
+        v = sk.lookup(p)
+        if v is not None:
+            v.copy_(t.view(v.shape))
+            sk.ready(p)
+            return None
+    return t
+
+
+def pack_fold_applicable(H2, W2, k):
+    """Fold only when the exact-border bands are a small part of the image."""
+    hb = 2 * (k // 2) + 1
+    return H2 > 2 * hb and W2 > 2 * hb and (2.0 * hb / H2 + 2.0 * hb / W2) <= _cfg["pack_fold_max_overhead"]
+
+
+class PackFoldedConvGnEluFn(torch.autograd.Function):
+    """PackLayerConv3d as ONE (k+2)x(k+2) convolution over the packed tensor: conv3d(1->4) is folded into the k x k conv
+    weights (csrc/pack_fold.hip), halving the MACs of pack1 and removing the 16C-channel intermediate.  The k/2-pixel
+    border, where zero padding sits between the two reference ops (layers01.py:237-238 vs :31), is recomputed exactly
+    with the unfolded kernels on four thin bands and pasted over the folded result; backward mirrors it."""
+
+    @staticmethod
+    def forward(ctx, x, w3, b3, w, b, gamma, beta, pack_unf, pack_fold):
+        B, C, H, W = x.shape
+        H2, W2 = H // 2, W // 2
+        co, _, k, _ = w.shape
+        pad, hb = k // 2, 2 * (k // 2) + 1
+        dt, dev, st = _dt(x), x.device, _stream()
+        w3c, b3c = w3.detach().contiguous().float(), b3.detach().contiguous().float()
+        # folded weights + interior result
+        P = new_act(B, 4 * C, H2, W2, x.dtype, dev)
+        xp, ldx = _pl(x)
+        pp, ldp = _pl(P)
+        lib.mte_pixel_shuffle(xp, ldx, pp, ldp, B, H, W, C, 0, dt, st)
+        Wf = torch.empty((co, 4 * C, k + 2, k + 2), dtype=torch.float32, device=dev)
+        bf = torch.empty((co,), dtype=torch.float32, device=dev)
+        lib.mte_fold_pack_weights(w.detach().data_ptr(), w3c.data_ptr(), b.detach().data_ptr(), b3c.data_ptr(), Wf.data_ptr(), bf.data_ptr(),
+                                  co, 4 * C, k, st)
+        pack_fold.key = None
+        wfp, _ = pack_fold.get(Wf, x.dtype, False)
+        y = conv_forward(P, wfp, bf, co, k + 2, k + 2, pack=pack_fold, w=Wf)
+        # exact border bands: group 1 = top/bottom rows, group 2 = left/right columns (rows pad .. H2-pad)
+        wu, _ = pack_unf.get(w, x.dtype, False)
+        xb1 = new_act(2 * B, C, 2 * hb, W, x.dtype, dev)
+        _rect(x, 0, 0, xb1[:B], 0, 0, 2 * hb, W)
+        _rect(x, H - 2 * hb, 0, xb1[B:], 0, 0, 2 * hb, W)
+        xb2 = new_act(2 * B, C, H, 2 * hb, x.dtype, dev)
+        _rect(x, 0, 0, xb2[:B], 0, 0, H, 2 * hb)
+        _rect(x, 0, W - 2 * hb, xb2[B:], 0, 0, H, 2 * hb)
+        Tb = []
+        for xb, (hh, ww) in ((xb1, (hb, W2)), (xb2, (H2, hb))):
+            T = new_act(2 * B, 16 * C, hh, ww, x.dtype, dev)
+            sp, lds_ = _pl(xb)
+            tp, ldt = _pl(T)
+            lib.mte_pack3d_fwd(sp, lds_, w3c.data_ptr(), b3c.data_ptr(), tp, ldt, 2 * B, xb.shape[2], xb.shape[3], C, dt, st)
+            Tb.append(T)
+        yb1 = conv_forward(Tb[0], wu, b, co, k, k, pack=pack_unf, w=w)
+        yb2 = conv_forward(Tb[1], wu, b, co, k, k, pack=pack_unf, w=w)
+        _rect(yb1[:B], 0, 0, y, 0, 0, pad, W2)
+        _rect(yb1[B:], hb - pad, 0, y, H2 - pad, 0, pad, W2)
+        _rect(yb2[:B], pad, 0, y, pad, 0, H2 - 2 * pad, pad)
+        _rect(yb2[B:], pad, hb - pad, y, pad, W2 - pad, H2 - 2 * pad, pad)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS)
+        ctx.save_for_backward(P, xb1, xb2, Tb[0], Tb[1], y, stats, w, w3c, b3c, gamma, beta, Wf)
+        ctx.params = (w3, b3, b)
+        ctx.packs = (pack_unf, pack_fold)
+        ctx.geom = (B, C, H, W, co, k)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        P, xb1, xb2, T1, T2, y, stats, w, w3c, b3c, gamma, beta, Wf = ctx.saved_tensors
+        w3, b3, b = ctx.params
+        pack_unf, pack_fold = ctx.packs
+        B, C, H, W, co, k = ctx.geom
+        H2, W2, pad, hb = H // 2, W // 2, k // 2, 2 * (k // 2) + 1
+        dt, dev, st = _dt(P), P.device, _stream()
+        dy, _, dgamma, dbeta = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False)
+        # ---- band paths (unfolded, exact)
+        dyb1 = torch.zeros((2 * B, hb, W2, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
+        _rect(dy, 0, 0, dyb1[:B], 0, 0, pad, W2)
+        _rect(dy, H2 - pad, 0, dyb1[B:], hb - pad, 0, pad, W2)
+        dyb2 = torch.zeros((2 * B, H2, hb, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
+        _rect(dy, pad, 0, dyb2[:B], pad, 0, H2 - 2 * pad, pad)
+        _rect(dy, pad, W2 - pad, dyb2[B:], pad, hb - pad, H2 - 2 * pad, pad)
+        dw_band = db_band = None
+        dk3b = torch.zeros((112,), dtype=torch.float32, device=dev)
+        dxb = []
+        for xb, T, dyb in ((xb1, T1, dyb1), (xb2, T2, dyb2)):
+            dT, dwi, dbi = conv_backward(T, dyb, w, pack_unf, True)
+            dw_band = dwi if dw_band is None else dw_band.add_(dwi)
+            db_band = dbi if db_band is None else db_band.add_(dbi)
+            Bb, _, hx, wx = xb.shape
+            tmp = torch.empty((112,), dtype=torch.float32, device=dev)
+            sp, lds_ = _pl(xb)
+            tp, ldt = _pl(dT)
+            lib.mte_pack3d_bwd_weight(sp, lds_, tp, ldt, tmp.data_ptr(), Bb, hx, wx, C, dt, st)
+            dk3b.add_(tmp)
+            dxi = new_act(Bb, C, hx, wx, P.dtype, dev)
+            dp_, ldd = _pl(dxi)
+            lib.mte_pack3d_bwd_data(tp, ldt, w3c.data_ptr(), dp_, ldd, Bb, hx, wx, C, dt, st)
+            dxb.append(dxi)
+        # ---- interior path (folded): band pixels carry no gradient here
+        _rect(None, 0, 0, dy, 0, 0, pad, W2, mode=2)
+        _rect(None, 0, 0, dy, H2 - pad, 0, pad, W2, mode=2)
+        _rect(None, 0, 0, dy, pad, 0, H2 - 2 * pad, pad, mode=2)
+        _rect(None, 0, 0, dy, pad, W2 - pad, H2 - 2 * pad, pad, mode=2)
+        dP, dWf, dbf = conv_backward(P, dy, Wf, pack_fold, True)
+        lib.mte_unfold_pack_wgrad(dWf.data_ptr(), dbf.data_ptr(), w.detach().data_ptr(), w3c.data_ptr(), b3c.data_ptr(),
+                                  dw_band.data_ptr(), dk3b.data_ptr(), co, 4 * C, k, 1, st)
+        db = dbf.add_(db_band)
+        dx = new_act(B, C, H, W, P.dtype, dev)
+        sp, lds_ = _pl(dP)
+        dp_, ldd = _pl(dx)
+        lib.mte_pixel_shuffle(sp, lds_, dp_, ldd, B, H, W, C, 1, dt, st)
+        _rect(dxb[0][:B], 0, 0, dx, 0, 0, 2 * hb, W, mode=1)
+        _rect(dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, mode=1)
+        _rect(dxb[1][:B], 0, 0, dx, 0, 0, H, 2 * hb, mode=1)
+        _rect(dxb[1][B:], 0, 0, dx, 0, W - 2 * hb, H, 2 * hb, mode=1)
+        return (dx, _deliver(w3, dk3b[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dk3b[108:112]), _deliver(w, dw_band), _deliver(b, db),
+                _deliver(gamma, dgamma), _deliver(beta, dbeta), None, None)
 
 
 class InvDepthFn(torch.autograd.Function):

@@ -148,9 +148,15 @@ class PackLayerConv3d(nn.Module):
         self.in_channels = in_channels
         self.conv = Conv2D(in_channels * (r ** 2) * d, in_channels, kernel_size, 1)
         self.conv3d = _Conv3dParams(d)
+        self.fold_pack = K.WeightPack()       # packs of the conv3d-folded (k+2)x(k+2) weights
 
     def forward(self, x):
         x = _enter(x, self.in_channels)
+        k = self.conv.kernel_size
+        if K.pack_folding_enabled() and self.in_channels % 8 == 0 and K.pack_fold_applicable(x.shape[2] // 2, x.shape[3] // 2, k):
+            cb, gn = self.conv.conv_base, self.conv.normalize
+            return K.PackFoldedConvGnEluFn.apply(x, self.conv3d.weight, self.conv3d.bias, cb.weight, cb.bias, gn.weight, gn.bias,
+                                                 cb.pack, self.fold_pack)
         return self.conv(K.Pack3dFn.apply(x, self.conv3d.weight, self.conv3d.bias))
 
 

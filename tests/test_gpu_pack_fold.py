@@ -1,0 +1,66 @@
+"""GPU (-m gpu): PackLayerConv3d computed as ONE folded (k+2)x(k+2) convolution + exact border bands must equal the
+reference formulation (conv3d then k x k conv with zero padding between them) -- outputs and every gradient."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(C, k, B, H, W, fold, dtype):
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.layers.packnet.layers01 import PackLayerConv3d
+    from oracle import packnet_oracle as po
+    K.set_compute_dtype(dtype)
+    K.use_pack_folding(fold)
+    old = K._cfg["pack_fold_max_overhead"]
+    K._cfg["pack_fold_max_overhead"] = 100.0
+    try:
+        spec = po._conv2d_block_spec("m.conv", C * 16, C, k) + [("m.conv3d.weight", (4, 1, 3, 3, 3)), ("m.conv3d.bias", (4,))]
+        P = po.fixture_params(spec, salt=C * 10 + k, bias_scale=0.2)
+        m = PackLayerConv3d(C, k, d=4)
+        m.load_state_dict({n[2:]: v for n, v in P.items()})
+        m = m.cuda()
+        g = torch.Generator().manual_seed(5 * C + k)
+        x = (torch.rand(B, C, H, W, generator=g) * 2 - 1)
+        xa = K.image_to_act(x.cuda()).detach().requires_grad_(True)
+        y = m(xa)
+        G = (torch.rand(y.shape, generator=g) * 2 - 1)
+        (y.float() * G.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        out = {"y": y.float().cpu(), "dx": xa.grad.float().cpu()}
+        out.update({"g." + n: p.grad.cpu() for n, p in m.named_parameters()})
+        return out, x, G, P
+    finally:
+        K._cfg["pack_fold_max_overhead"] = old
+        K.use_pack_folding(True)
+        K.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("C,k,B,H,W", [(16, 5, 2, 28, 36), (32, 3, 1, 16, 24), (32, 5, 1, 24, 64), (64, 3, 2, 14, 20)])
+def test_folded_pack_equals_unfolded_fp32(C, k, B, H, W):
+    a, x, G, P = _run(C, k, B, H, W, True, "fp32")
+    r, _, _, _ = _run(C, k, B, H, W, False, "fp32")
+    for key in r:
+        err = rel_err(a[key], r[key])
+        assert err < 3e-4 or float((a[key] - r[key]).abs().max()) < 1e-4, (key, err)
+    # and against the CPU oracle (pinned to the reference)
+    from oracle import packnet_oracle as po
+    Pc = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    xc = x.clone().requires_grad_(True)
+    yo = po.pack_conv3d(xc, Pc, "m")
+    (yo * G).sum().backward()
+    assert rel_err(a["y"], yo) < 3e-4
+    assert rel_err(a["dx"], xc.grad) < 1e-3
+    assert rel_err(a["g.conv3d.weight"], Pc["m.conv3d.weight"].grad) < 1e-3
+    assert rel_err(a["g.conv.conv_base.weight"], Pc["m.conv.conv_base.weight"].grad) < 1e-3
+
+
+@pytest.mark.parametrize("C,k,B,H,W", [(32, 5, 1, 24, 64), (64, 3, 2, 14, 20)])
+def test_folded_pack_bf16(C, k, B, H, W):
+    a, _, _, _ = _run(C, k, B, H, W, True, "bf16")
+    r, _, _, _ = _run(C, k, B, H, W, False, "fp32")
+    for key in r:
+        err = rel_err(a[key], r[key])
+        assert err < 6e-2 or float((a[key] - r[key]).abs().max()) < 1e-1, (key, err)
