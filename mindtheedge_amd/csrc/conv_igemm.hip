@@ -54,8 +54,14 @@ __device__ u32x4_t g_zero16 = {0u, 0u, 0u, 0u};      // source of zero chunks fo
 
 // DMA = true: tiles are staged global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write); the
 // LDS image is lane-linear per wave instruction, so the XOR swizzle is applied to the per-lane SOURCE chunk instead.
-template <typename T, int WM, int WN, int TM, int TN, bool DMA>
+// LD selects the tile loader: 0 = register staging (2 LDS buffers), 1 = LDS-DMA with per-lane global pointers (any shape),
+// 2 = LDS-DMA through buffer descriptors (Cin_p % 32 == 0, tensors < 2 GiB): the per-lane byte offset is constant per
+// filter tap and the K advance is a wave-uniform SGPR offset, so a K-step costs ~4 VALU instead of ~130 -- the loader's
+// address arithmetic, not HBM or LDS, was what held the MFMA pipe at ~25 %.  Out-of-image taps use an out-of-range offset
+// (the buffer bounds check returns zeros).
+template <typename T, int WM, int WN, int TM, int TN, int LD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr bool DMA = LD != 0;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int A_CH = BM * 4 / 256;                 // 16-B chunks of the A tile per thread
@@ -158,6 +164,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         c += 4;
         while (c >= cpt) { c -= cpt; if (++tx == a.KW) { tx = 0; ++ty; } }
     };
+    // ---- LD == 2: buffer-descriptor DMA loader state
+    constexpr unsigned OOB = 0xfffffff0u;
+    constexpr int ES = (int)sizeof(T);
+    unsigned voffA[A_CH], voffT[A_CH], voffB[B_CH];
+    int f_ty = 0, f_tx = 0, f_cb = 0;                              // wave-uniform: tap row/col, chunk base inside the tap
+    auto set_tap = [&]() {
+        const int dy = f_ty - pad_h, dx = f_tx - pad_w;
+        const int delta = (dy * a.W + dx) * (int)a.ldx * ES;       // byte shift of this tap (may be negative)
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            voffT[i] = ok ? voffA[i] + (unsigned)delta : OOB;
+        }
+    };
+    if constexpr (LD == 2) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) voffA[i] = (unsigned)((a_pix[i] * a.ldx + kc * PER16) * ES);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int n = n0 + ((tid + i * 256) >> 2);
+            voffB[i] = n < a.N ? (unsigned)(((long)n * Kp + kc * PER16) * ES) : OOB;
+        }
+        const int q0 = 4 * s_begin, tap0 = q0 / cpt;
+        f_cb = q0 - tap0 * cpt; f_ty = tap0 / a.KW; f_tx = tap0 - f_ty * a.KW;
+        set_tap();
+    }
+    auto dma_fast = [&](int s, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass (the host pass just needs the stub)
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, (int)(((a.M - 1) * a.ldx + a.Cin_p) * ES), 0x00020000);
+        const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, (int)((long)a.N * Kp * ES), 0x00020000);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        if (f_cb == cpt) {                                         // next tap (wave-uniform)
+            f_cb = 0;
+            if (++f_tx == a.KW) { f_tx = 0; ++f_ty; }
+            set_tap();
+        }
+        const int soffA = f_cb * PER16 * ES, soffB = s * 64;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sA + slot * BM * 64 + (wv * 16 + i * 64) * 64), 16, voffT[i], soffA, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(sB + slot * BN * 64 + (wv * 16 + i * 64) * 64), 16, voffB[i], soffB, 0, 0);
+        f_cb += 4;
+#else
+        (void)s; (void)slot;
+#endif
+    };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
@@ -207,14 +263,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int nst = s_end - s_begin;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            if (p < nst) dma_step(s_begin + p, p);
+            if (p < nst) { if constexpr (LD == 2) dma_fast(s_begin + p, p); else dma_step(s_begin + p, p); }
         for (int i = 0; i < nst; ++i) {
             const int rem = nst - 1 - i;
             if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
             else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (i + 3 < nst) dma_step(s_begin + i + 3, (i + 3) & 3);
+            if (i + 3 < nst) { if constexpr (LD == 2) dma_fast(s_begin + i + 3, (i + 3) & 3); else dma_step(s_begin + i + 3, (i + 3) & 3); }
             compute(i & 3);
         }
     } else {
@@ -320,11 +376,15 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
     if constexpr ((BN * 4) % 256 == 0) {
         if (g_igemm_dma) {
             const size_t lds4 = 4 * (BM + BN) * 64;
-            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds4, st, a);
+            const long es = (long)sizeof(T);
+            const bool fast = g_igemm_dma == 1 && a.Cin_p % (4 * Elem<T>::PER16) == 0 &&
+                              ((a.M - 1) * a.ldx + a.Cin_p) * es < 0x7ff00000L && (long)a.N * a.KH * a.KW * a.Cin_p * es < 0x7ff00000L;
+            if (fast) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds4, st, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 1>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds4, st, a);
             goto launched;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false>), dim3((unsigned)(tiles * a.splits)), dim3(256), 2 * (BM + BN) * 64, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 0>), dim3((unsigned)(tiles * a.splits)), dim3(256), 2 * (BM + BN) * 64, st, a);
 launched:
     if (a.splits > 1) {
         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
@@ -628,7 +688,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, lo
 
 extern "C" {
 
-// development knobs: key 0 = igemm tile loader (1 = LDS-DMA ring, 0 = register staging); key 1 = conv3d pack stencils
+// development knobs: key 0 = igemm tile loader (1 = LDS-DMA ring with buffer descriptors where possible, 2 = pointer DMA only,
+// 0 = register staging); key 1 = conv3d pack stencils
 // (1 = LDS-tiled, 0 = gather).  Not part of the product contract.
 extern "C" int mtei_set_pack3d_lds(int value);
 int mte_debug_set(int key, int value) {
