@@ -47,6 +47,8 @@ int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* d
 /* OIHW fp32 master weights -> forward pack [Cout][taps][Cin_p] and (optional) dgrad pack [Cin_p][taps rot180][Cout_p] */
 int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout, int Cin, int KH, int KW,
                           int Cin_p, int Cout_p, int dtype, mte_stream_t stream);
+/* dgrad pack derived from an existing forward pack */
+int mte_pack_conv_weights_bwd(const void* wfwd, void* wbwd, int Cout, int KH, int KW, int Cin_p, int dtype, mte_stream_t stream);
 /* dw_stage -> OIHW fp32 gradient (drops channel padding) */
 int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, mte_stream_t stream);
 /* out[N] = column sums of y[M][N] (conv bias gradient) */

@@ -421,7 +421,10 @@ template <int BYTES> __device__ __forceinline__ int padded_row(void) {
     return (BYTES % 128 == 64) ? BYTES : BYTES + 64;
 }
 
-template <typename T, int WNO, int WC, int TNO, int TC>
+// FL = true: pixel blocks are 32-pixel segments of ONE image row, tiles are fetched with buffer loads whose per-lane byte
+// offset is a kernel-lifetime constant and whose row base is a wave-uniform SGPR offset (same idea as igemm LD = 2);
+// FL = false: generic flattened-pixel loader (any tensor size).
+template <typename T, int WNO, int WC, int TNO, int TC, bool FL>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int BNO = WNO * TNO * 32, BC = WC * TC * 32;          // cout x cin tile
     constexpr int PER16 = Elem<T>::PER16, ES = (int)sizeof(T);
@@ -448,7 +451,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const T* __restrict__ xp = (const T*)a.x;
     const T* __restrict__ yp = (const T*)a.dy;
 
-    const long nblk_total = (a.M + KB - 1) / KB;
+    const int bpr = (a.W + KB - 1) / KB;                 // FL: blocks per image row
+    const long nblk_total = FL ? (long)a.B * a.H * bpr : (a.M + KB - 1) / KB;
     const long blk0 = (long)split * a.blocks_per_split;
     long blk1 = blk0 + a.blocks_per_split; if (blk1 > nblk_total) blk1 = nblk_total;
 
@@ -489,6 +493,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             while (x_ox[i] >= a.W) { x_ox[i] -= a.W; if (++x_oy[i] == a.H) { x_oy[i] = 0; ++x_b[i]; } }
         }
     };
+    // ---- FL loader state: block (b, y, xb) is wave-uniform and advances incrementally
+    constexpr unsigned OOB = 0xfffffff0u;
+    const int padw = a.KW >> 1;
+    unsigned voffY[YCT], voffX[XCT];
+    int f_xb = 0, f_y = 0, f_b = 0;
+    if constexpr (FL) {
+        f_xb = (int)(blk0 % bpr); const long t = blk0 / bpr; f_y = (int)(t % a.H); f_b = (int)(t / a.H);
+#pragma unroll
+        for (int i = 0; i < YCT; ++i) {
+            const int n = n0 + y_cc[i] * PER16;
+            voffY[i] = ((YCH % 256 == 0 || tid + i * 256 < YCH) && n < a.N) ? (unsigned)((y_row[i] * a.ldy + n) * ES) : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < XCT; ++i) {
+            const int cc = c0 + x_cc[i] * PER16;
+            voffX[i] = ((XCH % 256 == 0 || tid + i * 256 < XCH) && cc < a.Cin_p) ? (unsigned)(((x_row[i] + dxo + padw) * a.ldx + cc) * ES) : OOB;
+        }
+    }
+    auto load_fast = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, (int)(((a.M - 1) * a.ldy + a.N) * ES), 0x00020000);
+        const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(xp - (long)padw * a.ldx), 0, (int)(((a.M - 1 + padw) * a.ldx + a.Cin_p) * ES), 0x00020000);
+        const int x0 = f_xb * KB, rem = a.W - x0;
+        const int yy = f_y + dyo;
+        const bool row_ok = (unsigned)yy < (unsigned)a.H;
+        const int soffY = (int)((((long)f_b * a.H + f_y) * a.W + x0) * a.ldy * ES);
+        const int soffX = (int)((((long)f_b * a.H + yy) * a.W + x0) * a.ldx * ES);
+#pragma unroll
+        for (int i = 0; i < YCT; ++i)
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, y_row[i] < rem ? voffY[i] : OOB, soffY, 0);
+#pragma unroll
+        for (int i = 0; i < XCT; ++i) {
+            const bool ok = row_ok && (unsigned)(x0 + x_row[i] + dxo) < (unsigned)a.W;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? voffX[i] : OOB, row_ok ? soffX : 0, 0);
+        }
+        if (++f_xb == bpr) { f_xb = 0; if (++f_y == a.H) { f_y = 0; ++f_b; } }
+#endif
+    };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < YCT; ++i)
@@ -510,12 +552,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int r = lane & 31, h = lane >> 5;
 
     if (blk0 < blk1) {
-        load_step(blk0);
+        if constexpr (FL) load_fast(); else load_step(blk0);
         store_step(0);
         __syncthreads();
         for (long blk = blk0; blk < blk1; ++blk) {
             const int buf = (int)((blk - blk0) & 1);
-            if (blk + 1 < blk1) load_step(blk + 1);
+            if (blk + 1 < blk1) { if constexpr (FL) load_fast(); else load_step(blk + 1); }
             const char* pY = sY + buf * KB * RS_Y;
             const char* pX = sX + buf * KB * RS_X;
             if constexpr (sizeof(T) == 2) {
@@ -598,7 +640,11 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
     a.tiles_n = (a.N + BNO - 1) / BNO;
     a.tiles_c = (a.Cin_p + BC - 1) / BC;
     const int taps = a.KH * a.KW;
-    const long nblk = (a.M + 31) / 32;
+    const long es = (long)sizeof(T);
+    // row-aligned 32-pixel blocks waste MFMA work when W is not a multiple of 32 (W = 40: 37 %): use them for wide rows only
+    const bool fl = (a.W % 32 == 0 || a.W >= 160) &&
+                    ((a.M + a.KW) * a.ldx + a.Cin_p) * es < 0x7ff00000L && ((a.M - 1) * a.ldy + a.N) * es < 0x7ff00000L;
+    const long nblk = fl ? (long)a.B * a.H * ((a.W + 31) / 32) : (a.M + 31) / 32;
     const long base_wgs = (long)a.tiles_n * a.tiles_c * taps;
     long splits = (1024 + base_wgs - 1) / base_wgs;            // aim for >= ~4 workgroups per CU
     const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
@@ -611,7 +657,8 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
         if (e != hipSuccess) return MTE_ERR_LAUNCH;
     }
     const size_t lds = 2 * 32 * (RS_Y + RS_X);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, WNO, WC, TNO, TC>), dim3((unsigned)(base_wgs * a.splits)), dim3(256), lds, st, a);
+    if (fl) hipLaunchKernelGGL((conv_wgrad_kernel<T, WNO, WC, TNO, TC, true>), dim3((unsigned)(base_wgs * a.splits)), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, WNO, WC, TNO, TC, false>), dim3((unsigned)(base_wgs * a.splits)), dim3(256), lds, st, a);
     return mte_check_launch();
 }
 
@@ -624,24 +671,44 @@ template <typename T> int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
     return launch_wgrad<T, 2, 2, 2, 2>(a, st);                              // cout 128 x cin 128
 }
 
-// ---- weight packing: OIHW fp32 master -> [N][taps][Cin_p] (forward) and [Cin_p8][taps flipped][Cout_p] (dgrad)
+// ---- weight packing: OIHW fp32 master -> [N][taps][Cin_p] (forward) and [Cin_p8][taps flipped][Cout_p] (dgrad).
+// Both passes go through LDS so that global reads AND writes are contiguous runs (the naive gather read the fp32
+// master with a taps*4-byte stride and cost 1.2 ms per step for the 77 M parameters).
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
-                                    int Cout, int Cin, int KH, int KW, int Cin_p, int Cout_p) {
-    const int taps = KH * KW;
-    const long nf = (long)Cout * taps * Cin_p;
-    const long nb = wb ? (long)Cin_p * taps * Cout_p : 0;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nf + nb; i += (long)gridDim.x * blockDim.x) {
-        if (i < nf) {
-            const int c = (int)(i % Cin_p); long t = i / Cin_p; const int tap = (int)(t % taps); const int n = (int)(t / taps);
-            const float v = c < Cin ? w[((long)n * Cin + c) * taps + tap] : 0.f;
-            Elem<T>::st(wf + i, v);
-        } else {
-            const long k = i - nf;
-            const int n = (int)(k % Cout_p); long t = k / Cout_p; const int tap = (int)(t % taps); const int c = (int)(t / taps);
-            // dgrad: dx[p][c] = sum_{tap', n} dy[p + tap' - pad][n] * w[n][c][taps-1-tap']
-            const float v = (c < Cin && n < Cout) ? w[((long)n * Cin + c) * taps + (taps - 1 - tap)] : 0.f;
-            Elem<T>::st(wb + k, v);
+__global__ __launch_bounds__(256) void pack_weights_fwd_kernel(const float* __restrict__ w, T* __restrict__ wf,
+                                                               int Cout, int Cin, int taps, int Cin_p) {
+    extern __shared__ float s_w[];                                   // [64 channels][taps]
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    const int nc = min(64, Cin - c0);                                // real channels in this chunk (may be <= 0)
+    const float* src = w + ((long)n * Cin + c0) * taps;
+    for (int i = threadIdx.x; i < nc * taps; i += 256) s_w[i] = src[i];
+    __syncthreads();
+    const int ncp = min(64, Cin_p - c0);                             // channels incl. zero padding
+    for (int i = threadIdx.x; i < taps * ncp; i += 256) {
+        const int tap = i / ncp, cl = i - tap * ncp;
+        Elem<T>::st(wf + ((long)n * taps + tap) * Cin_p + c0 + cl, cl < nc ? s_w[cl * taps + tap] : 0.f);
+    }
+}
+
+// wb[(c*taps + tb)*Cout_p + n] = wf[n*Kp + (taps-1-tb)*Cin_p + c]   (64 x 64 tiles through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_bwd_kernel(const T* __restrict__ wf, T* __restrict__ wb,
+                                                               int Cout, int taps, int Cin_p, int Cout_p) {
+    __shared__ T tile[64][64 + 2];
+    const int Kp = taps * Cin_p;
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, cidx = i & 63;
+        const int n = n0 + r, k = k0 + cidx;
+        tile[r][cidx] = (n < Cout && k < Kp) ? wf[(long)n * Kp + k] : (T)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int kk = i >> 6, nn = i & 63;
+        const int k = k0 + kk, n = n0 + nn;
+        if (k < Kp && n < Cout_p) {
+            const int tap = k / Cin_p, c = k - tap * Cin_p;
+            wb[((long)c * taps + (taps - 1 - tap)) * Cout_p + n] = n < Cout ? tile[nn][kk] : (T)0;
         }
     }
 }
@@ -729,12 +796,28 @@ int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout,
                           int Cin_p, int Cout_p, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!w_oihw || !wfwd) return MTE_ERR_ARG;
-    const long n = (long)Cout * KH * KW * Cin_p + (wbwd ? (long)Cin_p * KH * KW * Cout_p : 0);
-    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    if (dtype == MTE_DT_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, w_oihw, (bf16_t*)wfwd, (bf16_t*)wbwd, Cout, Cin, KH, KW, Cin_p, Cout_p);
-    else
-        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, stream, w_oihw, (float*)wfwd, (float*)wbwd, Cout, Cin, KH, KW, Cin_p, Cout_p);
+    const int taps = KH * KW;
+    if (Cout_p != Cout && wbwd) return MTE_ERR_ARG;
+    const dim3 gf(Cout, (Cin_p + 63) / 64), gb((Cout + 63) / 64, (taps * Cin_p + 63) / 64);
+    const size_t lds = sizeof(float) * 64 * taps;
+    if (dtype == MTE_DT_BF16) {
+        hipLaunchKernelGGL(pack_weights_fwd_kernel<bf16_t>, gf, dim3(256), lds, stream, w_oihw, (bf16_t*)wfwd, Cout, Cin, taps, Cin_p);
+        if (wbwd) hipLaunchKernelGGL(pack_weights_bwd_kernel<bf16_t>, gb, dim3(256), 0, stream, (const bf16_t*)wfwd, (bf16_t*)wbwd, Cout, taps, Cin_p, Cout_p);
+    } else {
+        hipLaunchKernelGGL(pack_weights_fwd_kernel<float>, gf, dim3(256), lds, stream, w_oihw, (float*)wfwd, Cout, Cin, taps, Cin_p);
+        if (wbwd) hipLaunchKernelGGL(pack_weights_bwd_kernel<float>, gb, dim3(256), 0, stream, (const float*)wfwd, (float*)wbwd, Cout, taps, Cin_p, Cout_p);
+    }
+    return mte_check_launch();
+}
+
+// dgrad pack from an existing forward pack (same dtype): wbwd[Cin_p][taps rot180][Cout] <- wfwd[Cout][taps][Cin_p]
+int mte_pack_conv_weights_bwd(const void* wfwd, void* wbwd, int Cout, int KH, int KW, int Cin_p, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!wfwd || !wbwd) return MTE_ERR_ARG;
+    const int taps = KH * KW;
+    const dim3 gb((Cout + 63) / 64, (taps * Cin_p + 63) / 64);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(pack_weights_bwd_kernel<bf16_t>, gb, dim3(256), 0, stream, (const bf16_t*)wfwd, (bf16_t*)wbwd, Cout, taps, Cin_p, Cout);
+    else hipLaunchKernelGGL(pack_weights_bwd_kernel<float>, gb, dim3(256), 0, stream, (const float*)wfwd, (float*)wbwd, Cout, taps, Cin_p, Cout);
     return mte_check_launch();
 }
 

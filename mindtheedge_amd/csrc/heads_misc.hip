@@ -78,21 +78,24 @@ __global__ void invdepth_dlogit_kernel(const float* __restrict__ dout, const flo
 
 // dx[p][c] = sum_t dlogit[p - t] * w[c][t];  dw[c][t] += sum_p dlogit[p] * x[p + t][c];  db += sum_p dlogit[p]
 template <typename T>
-__global__ __launch_bounds__(256) void invdepth_bwd_kernel(HeadArgs a) {
-    extern __shared__ float sdw[];                               // [C*9 + 1]
+__global__ __launch_bounds__(256, 3) void invdepth_bwd_kernel(HeadArgs a) {
+    extern __shared__ float sdw[];                               // [C*9 + 1] gradient accumulators, then [9][C] weights (tap-major)
+    float* swt = sdw + ((a.C * 9 + 4) & ~3);                     // 16-byte aligned
     for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) sdw[i] = 0.f;
+    for (int i = threadIdx.x; i < a.C * 9; i += 256) swt[(i % 9) * a.C + i / 9] = a.w[i];
     __syncthreads();
     const int cb = a.C >> 3;
     const int j = threadIdx.x % cb;
     const int c0 = j * 8;
-    float wr[9][8], gw[9][8];
+    float gw[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { wr[t][i] = a.w[(c0 + i) * 9 + t]; gw[t][i] = 0.f; }
+        for (int i = 0; i < 8; ++i) gw[t][i] = 0.f;
     float gb = 0.f;
     const long ppb = 256 / cb;
     const long iters = (a.npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
+#pragma unroll 1
     for (long it = 0; it < iters; ++it) {
         const long pix = (it * gridDim.x + blockIdx.x) * ppb + threadIdx.x / cb;
         if (pix >= a.npix) continue;
@@ -105,18 +108,17 @@ __global__ __launch_bounds__(256) void invdepth_bwd_kernel(HeadArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int oy = t / 3 - 1, ox = t % 3 - 1;
-            // weight gradient: x at p + t
-            if ((unsigned)(y + oy) < (unsigned)a.H && (unsigned)(x + ox) < (unsigned)a.W) {
+            if ((unsigned)(y + oy) < (unsigned)a.H && (unsigned)(x + ox) < (unsigned)a.W) {       // weight gradient: x at p + t
                 float v[8];
                 ld8<T>((const T*)a.x + (pix + (long)oy * a.W + ox) * a.ldx + c0, v);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(dl0, v[i], gw[t][i]);
             }
-            // data gradient: dlogit at p - t
-            if ((unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W) {
+            if ((unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W) {       // data gradient: dlogit at p - t
                 const float dl = a.dlogit[pix - (long)oy * a.W - ox];
+                const f32x4_t w0 = *(const f32x4_t*)(swt + t * a.C + c0), w1 = *(const f32x4_t*)(swt + t * a.C + c0 + 4);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dxv[i] = fmaf(dl, wr[t][i], dxv[i]);
+                for (int i = 0; i < 4; ++i) { dxv[i] = fmaf(dl, w0[i], dxv[i]); dxv[4 + i] = fmaf(dl, w1[i], dxv[4 + i]); }
             }
         }
         st8<T>((T*)a.dx + pix * a.lddx + c0, dxv);
@@ -235,8 +237,9 @@ int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_o
     HeadArgs a{}; a.x = x; a.ldx = ldx; a.w = w; a.dlogit = dlogit_scratch; a.dx = dx; a.lddx = lddx; a.dw = dwb;
     a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
     const int ppb = 256 / (C / 8);
-    long g = (npix + ppb * 16 - 1) / (ppb * 16); if (g > 2048) g = 2048; if (g < 1) g = 1;
-    const size_t lds = sizeof(float) * (C * 9 + 1);
+    // few, long-running blocks: every block ends with C*9+1 same-address global atomics (contended adds are ~14x slower)
+    long g = (npix + ppb * 8 - 1) / (ppb * 8); if (g > 768) g = 768; if (g < 1) g = 1;
+    const size_t lds = sizeof(float) * (C * 18 + 4);
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(invdepth_bwd_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, a);
     return mte_check_launch();

@@ -182,14 +182,18 @@ class WeightPack:
 
     def get(self, w, dtype, need_bwd):
         key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
-        if key != self.key or (need_bwd and self.wb is None):
-            cout, cin, kh, kw = w.shape
-            cin_p = round8(cin)
+        cout, cin, kh, kw = w.shape
+        cin_p = round8(cin)
+        dtc = DT_BF16 if dtype == torch.bfloat16 else DT_F32
+        if key != self.key:
             self.wf = torch.empty((cout, kh * kw, cin_p), dtype=dtype, device=w.device)
             self.wb = torch.empty((cin_p, kh * kw, cout), dtype=dtype, device=w.device) if need_bwd else None
             lib.mte_pack_conv_weights(w.detach().contiguous().data_ptr(), self.wf.data_ptr(), _ptr(self.wb), cout, cin, kh, kw,
-                                      cin_p, cout, DT_BF16 if dtype == torch.bfloat16 else DT_F32, _stream())
+                                      cin_p, cout, dtc, _stream())
             self.key = key
+        elif need_bwd and self.wb is None:
+            self.wb = torch.empty((cin_p, kh * kw, cout), dtype=dtype, device=w.device)
+            lib.mte_pack_conv_weights_bwd(self.wf.data_ptr(), self.wb.data_ptr(), cout, kh, kw, cin_p, dtc, _stream())
         return self.wf, self.wb
 
 
@@ -312,7 +316,7 @@ class ConvGnEluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, pack):
-        wf, _ = pack.get(w, x.dtype, False)
+        wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
         y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS)
@@ -340,7 +344,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, pack):
-        wf, _ = pack.get(w, x.dtype, False)
+        wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
         y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
         ctx.save_for_backward(x, w)
