@@ -185,20 +185,24 @@ struct PatchWgradArgs {
     int groups;                                    // workgroups per channel slice
 };
 
-template <int K, int NT>
+// SL = 32-channel input slices per workgroup (2 halves the dy re-reads and doubles the MFMA work per staged tile:
+// the 3x3 high-resolution layers are HBM-bound, ~9 k MAC per 128 B).  LDS is single-buffered: the next tile waits in
+// registers while the current one is consumed.
+template <int K, int NT, int SL>
 __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a) {
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int TPW = (TAPS + 3) / 4;                            // taps per wave
-    constexpr int XCH = PH * PW * 4, NXC = (XCH + 255) / 256;      // x patch chunks (64 B per pixel)
-    constexpr int YRS = NT == 1 ? 64 : 192;                        // dy row stride: odd multiple of 64 B (tr-read banks)
+    constexpr int XRS = SL == 1 ? 64 : 192;                        // x / dy pixel row strides: odd multiples of 64 B
+    constexpr int XCH = PH * PW * 4 * SL, NXC = (XCH + 255) / 256;
+    constexpr int YRS = NT == 1 ? 64 : 192;
     constexpr int YCH = TH * TW * NT * 4, NYC = YCH / 256;
-    constexpr int XBYTES = PH * PW * 64, YBYTES = TH * TW * YRS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][XBYTES] then [2][YBYTES]
-    char* sX = smem;
-    char* sY = smem + 2 * XBYTES;
+    constexpr int XBYTES = PH * PW * XRS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [XBYTES] then [TH*TW*YRS]
+    char* X = smem;
+    char* Y = smem + XBYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = blockIdx.y;
+    const int slice = blockIdx.y;                                  // group of SL 32-channel slices
     const int tiles_x = a.W / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * a.B;
     const int per = (ntiles + a.groups - 1) / a.groups;
@@ -214,10 +218,10 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
 #pragma unroll
         for (int i = 0; i < NXC; ++i) {
             const int idc = tid + i * 256;
-            const int p = idc >> 2, kc = idc & 3;
+            const int p = idc / (4 * SL), kc = idc - p * (4 * SL);
             const int py = p / PW, px = p - py * PW;
             const int iy = y0 + py - PAD, ix = x0 + px - PAD;
-            const int cc = slice * 4 + kc;
+            const int cc = slice * 4 * SL + kc;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if ((XCH % 256 == 0 || idc < XCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cpt)
                 v = *(const u32x4_t*)(a.x + (((long)b * a.H + iy) * a.W + ix) * a.ldx + cc * 8);
@@ -233,27 +237,30 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
             sy[i] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NXC; ++i) {
             const int idc = tid + i * 256;
-            if (XCH % 256 == 0 || idc < XCH) *(u32x4_t*)(sX + buf * XBYTES + idc * 16) = sx[i];      // plain [pixel][64 B]
+            const int p = idc / (4 * SL), kc = idc - p * (4 * SL);
+            if (XCH % 256 == 0 || idc < XCH) *(u32x4_t*)(X + p * XRS + kc * 16) = sx[i];
         }
 #pragma unroll
         for (int i = 0; i < NYC; ++i) {
             const int idc = tid + i * 256;
             const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
-            *(u32x4_t*)(sY + buf * YBYTES + pix * YRS + c * 16) = sy[i];
+            *(u32x4_t*)(Y + pix * YRS + c * 16) = sy[i];
         }
     };
 
-    f32x16_t acc[TPW][NT];
+    f32x16_t acc[TPW][SL][NT];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][sl][n][e] = 0.f;
 
     // transposing-read lane roles: 16-lane group g: channels 16*(g&1) + 4p.., pixels 8*(g>>1) + q (+4 for the 2nd read)
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
@@ -261,13 +268,11 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
 
     if (t_begin < t_end) {
         load_tile(t_begin);
-        store_tile(0);
-        __syncthreads();
         for (int tile = t_begin; tile < t_end; ++tile) {
-            const int buf = (tile - t_begin) & 1;
-            if (tile + 1 < t_end) load_tile(tile + 1);
-            const char* X = sX + buf * XBYTES;
-            const char* Y = sY + buf * YBYTES;
+            __syncthreads();                                       // previous tile fully consumed
+            store_tile();
+            __syncthreads();
+            if (tile + 1 < t_end) load_tile(tile + 1);             // in flight (registers) while this tile is multiplied
 #pragma unroll 1
             for (int ks = 0; ks < TH * 2; ++ks) {                  // 16 pixels of one tile row per k-step
                 const int row = ks >> 1, col0 = (ks & 1) * 16;
@@ -285,26 +290,29 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
                     const int tap = wave + 4 * i;
                     if (tap < TAPS) {
                         const int dyy = tap / K, dxx = tap - dyy * K;
-                        const char* base = X + ((row + dyy) * PW + col0 + dxx + pxb) * 64 + chb * 2;
-                        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
-                        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * 64));
-                        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                        const u32x4_t fx = u32x4_t{l2.x, l2.y, h2.x, h2.y};
 #pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[n]),
-                                                                               __builtin_bit_cast(bf16x8_t, fx), acc[i][n], 0, 0, 0);
+                        for (int sl = 0; sl < SL; ++sl) {
+                            const char* base = X + ((row + dyy) * PW + col0 + dxx + pxb) * XRS + sl * 64 + chb * 2;
+                            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * XRS));
+                            uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                            const u32x4_t fx = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[i][sl][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[n]),
+                                                                                       __builtin_bit_cast(bf16x8_t, fx), acc[i][sl][n], 0, 0, 0);
+                        }
                     }
                 }
             }
-            if (tile + 1 < t_end) store_tile(buf ^ 1);
-            __syncthreads();
         }
     }
     // D[row = cout][col = cin]: col = lane&31 -> contiguous fp32 in the stage
     const int r = lane & 31, h = lane >> 5;
-    const int cc = slice * 32 + r;
-    if (cc < a.Cin_p) {
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+        const int cc = (slice * SL + sl) * 32 + r;
+        if (cc >= a.Cin_p) continue;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int tap = wave + 4 * i;
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int co = n * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (co < a.N) atomicAdd(a.dw + ((long)co * TAPS + tap) * a.Cin_p + cc, acc[i][n][e]);
+                        if (co < a.N) atomicAdd(a.dw + ((long)co * TAPS + tap) * a.Cin_p + cc, acc[i][sl][n][e]);
                     }
             }
         }
@@ -336,24 +344,31 @@ template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
     return MTE_ERR_UNSUPPORTED;
 }
 
-template <int K, int NT> int launch_wgrad(PatchWgradArgs a, hipStream_t st) {
+template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream_t st) {
     constexpr int PH = TH + K - 1, PW = TW + K - 1;
-    constexpr int YRS = NT == 1 ? 64 : 192;
-    const size_t lds = 2 * (PH * PW * 64 + TH * TW * YRS);
-    const int nslices = (a.Cin_p + 31) / 32;
+    constexpr int XRS = SL == 1 ? 64 : 192, YRS = NT == 1 ? 64 : 192;
+    const size_t lds = PH * PW * XRS + TH * TW * YRS;
+    const int nslices = (a.Cin_p + 32 * SL - 1) / (32 * SL);
     const long ntiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
     long groups = (512 + nslices - 1) / nslices;                   // ~2 workgroups per CU in total
     if (groups > ntiles) groups = ntiles;
     a.groups = (int)groups;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_patch_wgrad_kernel<K, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_patch_wgrad_kernel<K, NT, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MTE_ERR_LAUNCH;
         attr_set = true;
     }
     if (hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT>), dim3((unsigned)groups, nslices), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT, SL>), dim3((unsigned)groups, nslices), dim3(256), lds, st, a);
     return mte_check_launch();
+}
+template <int K, int NT> int launch_wgrad(const PatchWgradArgs& a, hipStream_t st) {
+    // two slices per workgroup where the accumulators still fit (3x3 and 1x1; 5x5 with C_out <= 32) and there is more than one slice
+    if constexpr (K <= 3 || (K == 5 && NT == 1)) {
+        if (a.Cin_p > 32) return launch_wgrad_sl<K, NT, 2>(a, st);
+    }
+    return launch_wgrad_sl<K, NT, 1>(a, st);
 }
 template <int NT> int dispatch_wgrad(const PatchWgradArgs& a, int K, hipStream_t st) {
     switch (K) {
