@@ -71,6 +71,7 @@ class BucketedAllReduce:
                 self.buckets.append((start, end, count))
                 start, count = end, 0
         self._ready = [0] * len(self.buckets)
+        self._seen = set()          # a parameter may be announced by both the gradient sink and its autograd hook
         self._works = []
         self._hooks = []
         if self.world > 1:
@@ -80,6 +81,9 @@ class BucketedAllReduce:
                 flat.sink.on_ready = self._on_grad_ready      # gradients written in place never reach AccumulateGrad
 
     def _on_grad_ready(self, p):
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         b = self.bucket_of[id(p)]
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b][2]:
@@ -96,6 +100,7 @@ class BucketedAllReduce:
             for w in self._works:
                 w.wait()
         self._works, self._ready = [], [0] * len(self.buckets)
+        self._seen.clear()
         return 1.0 / self.world
 
 
