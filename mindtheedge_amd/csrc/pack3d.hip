@@ -693,14 +693,166 @@ __global__ __launch_bounds__(256) void pack3d_bwd_weight_lds_kernel(P3LArgs a) {
         atomicAdd(a.dwb + threadIdx.x, sred[threadIdx.x] + sred[112 + threadIdx.x] + sred[224 + threadIdx.x] + sred[336 + threadIdx.x]);
 }
 
-template <typename KF> int launch_p3l(KF kf, P3LArgs a, int grid, hipStream_t st) {
-    const size_t lds = p3_lds_bytes(a.C);
-    static const void* done[4] = {nullptr, nullptr, nullptr, nullptr};
+// ---- LDS-tiled UNPACK backward.  Volume = x [B,H,W,C] (depth = channel).  The feature side is the pixel-shuffled
+// gradient dout [B,2H,2W,C]: feature plane f of the volume is the space-to-depth of dout's channels [f*C/4, (f+1)*C/4),
+// so staging it is stage_packed_tile with (x := dout + f*C/4, C := C/4, H := 2H, W := 2W).
+inline P3Tile up_tile(int C) {                       // TH*TW*C = 16384 (2 items of 32 depths per thread)
+    if (C <= 32) return {16, 32};
+    if (C <= 64) return {8, 32};
+    if (C <= 128) return {8, 16};
+    if (C <= 256) return {4, 16};
+    return {4, 8};
+}
+inline size_t up_lds_bytes(int C) { P3Tile t = up_tile(C); return (size_t)(t.TH + 2) * (t.TW + 2) * C * 2; }
+
+__device__ __forceinline__ void up_tile_coords(const P3LArgs& a, int tile, int& b, int& h0, int& w0) {
+    const int tw = tile % a.tiles_w; int t = tile / a.tiles_w;
+    const int th = t % a.tiles_h; b = t / a.tiles_h;
+    h0 = th * a.TH; w0 = tw * a.TW;
+}
+
+__global__ __launch_bounds__(256) void unpack3d_bwd_data_lds_kernel(P3LArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)smem_;
+    __shared__ float sw[108];
+    if (threadIdx.x < 108) sw[threadIdx.x] = a.w3[threadIdx.x];
+    int b, h0, w0;
+    up_tile_coords(a, blockIdx.x, b, h0, w0);
+    const int D = a.C, cbs = a.C >> 5, PW = a.TW + 2;
+    P3LArgs t = a;                                      // plane staging view of dout
+    t.ldx = a.ldo; t.C = a.C >> 2; t.H = 2 * a.H; t.W = 2 * a.W;
+    float acc[2][32];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[k][i] = 0.f;
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+        __syncthreads();
+        t.x = a.o + f * (a.C >> 2);
+        stage_packed_tile(t, tile, b, h0, w0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int it = threadIdx.x + k * 256;
+            const int cb = it % cbs; const int p = it / cbs;
+            const int pw = p % a.TW, ph = p / a.TW;
+            if (ph >= a.TH) continue;
+#pragma unroll 1
+            for (int tp = 0; tp < 9; ++tp) {
+                const int kh = tp / 3, kw = tp - 3 * kh;
+                float pv[34];
+                lds_window<4>(tile, (ph + 2 - kh) * PW + pw + 2 - kw, D, 32 * cb, pv);
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float wv = sw[((f * 3 + kd) * 3 + kh) * 3 + kw];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[k][i] = fmaf(wv, pv[i + 2 - kd], acc[k][i]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int it = threadIdx.x + k * 256;
+        const int cb = it % cbs; const int p = it / cbs;
+        const int pw = p % a.TW, ph = p / a.TW;
+        const int h = h0 + ph, w = w0 + pw;
+        if (ph < a.TH && h < a.H && w < a.W) {
+            bf16_t* dp = a.dst + (((long)b * a.H + h) * a.W + w) * a.lddst + 32 * cb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(u32x4_t*)(dp + 8 * j) = pack16<bf16_t>(&acc[k][8 * j]);
+        }
+    }
+}
+
+// dw3/db3 for UNPACK: x tile staged directly; the 8 feature gradients of an item are gathered from the shuffled dout
+__global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)smem_;
+    __shared__ float sred[4 * 112];
+    const int D = a.C, dbs = D >> 3, PW = a.TW + 2, npix = (a.TH + 2) * PW;
+    const int items = a.TH * a.TW * dbs;
+    float acc[112];
+#pragma unroll
+    for (int i = 0; i < 112; ++i) acc[i] = 0.f;
+    for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+        int b, h0, w0;
+        up_tile_coords(a, tl, b, h0, w0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < npix * dbs; idx += 256) {
+            const int dc = idx % dbs; const int p = idx / dbs;
+            const int hh = h0 - 1 + p / PW, ww = w0 - 1 + p % PW;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W)
+                v = *(const u32x4_t*)(a.x + (((long)b * a.H + hh) * a.W + ww) * a.ldx + dc * 8);
+            *(u32x4_t*)(tile + p * D + dc * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int db = it % dbs; const int p = it / dbs;
+            const int pw = p % a.TW, ph = p / a.TW;
+            const int h = h0 + ph, w = w0 + pw;
+            if (h >= a.H || w >= a.W) continue;
+            const int d0 = db * 8;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float go[8];
+                const int q0 = f * a.C + d0;                           // multiple of 8: channels q0>>2, +1 at the 4 sub-pixel positions
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const unsigned u = *(const unsigned*)(a.o + (((long)b * 2 * a.H + 2 * h + (s4 >> 1)) * (2 * a.W) + 2 * w + (s4 & 1)) * a.ldo + (q0 >> 2));
+                    go[s4] = __uint_as_float(u << 16); go[4 + s4] = __uint_as_float(u & 0xffff0000u);
+                }
+                float sb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sb += go[i];
+                acc[108 + f] += sb;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        float pv[10];
+                        lds_window<1>(tile, (ph + kh) * PW + pw + kw, D, d0, pv);
+#pragma unroll
+                        for (int kd = 0; kd < 3; ++kd) {
+                            float sacc = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) sacc = fmaf(go[i], pv[i + kd], sacc);
+                            acc[((f * 3 + kd) * 3 + kh) * 3 + kw] += sacc;
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 112; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) sred[wave * 112 + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 112)
+        atomicAdd(a.dwb + threadIdx.x, sred[threadIdx.x] + sred[112 + threadIdx.x] + sred[224 + threadIdx.x] + sred[336 + threadIdx.x]);
+}
+
+inline P3LArgs upl_args(int B, int H, int W, int C) {
+    P3LArgs a{}; a.B = B; a.H = H; a.W = W; a.C = C;
+    const P3Tile t = up_tile(C); a.TH = t.TH; a.TW = t.TW;
+    a.tiles_h = (H + t.TH - 1) / t.TH; a.tiles_w = (W + t.TW - 1) / t.TW; a.ntiles = a.tiles_h * a.tiles_w * B;
+    return a;
+}
+
+template <typename KF> int launch_p3l(KF kf, P3LArgs a, int grid, hipStream_t st, size_t lds_override = 0) {
+    const size_t lds = lds_override ? lds_override : p3_lds_bytes(a.C);
+    static const void* done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool seen = false;
-    for (int i = 0; i < 4; ++i) seen = seen || done[i] == (const void*)kf;
+    for (int i = 0; i < 8; ++i) seen = seen || done[i] == (const void*)kf;
     if (!seen) {
         if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess) return MTE_ERR_LAUNCH;
-        for (int i = 0; i < 4; ++i) if (!done[i]) { done[i] = (const void*)kf; break; }
+        for (int i = 0; i < 8; ++i) if (!done[i]) { done[i] = (const void*)kf; break; }
     }
     hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);
     return mte_check_launch();
@@ -781,6 +933,10 @@ int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx,
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
+    if (dtype == MTE_DT_BF16 && g_p3_lds && C % 32 == 0 && C <= 512) {
+        P3LArgs l = upl_args(B, H, W, C); l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
+        return launch_p3l(unpack3d_bwd_data_lds_kernel, l, l.ntiles, stream, up_lds_bytes(C));
+    }
     a.total = (long)B * H * W * (C / 8);
     return launch_p3(dtype, unpack3d_bwd_data_kernel<bf16_t>, unpack3d_bwd_data_kernel<float>, a, a.total, stream);
 }
@@ -790,6 +946,10 @@ int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo,
     if (!x || !dout || !dwb || !p3_ok(C)) return MTE_ERR_ARG;
     if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
+    if (dtype == MTE_DT_BF16 && g_p3_lds && C % 32 == 0 && C <= 512) {
+        P3LArgs l = upl_args(B, H, W, C); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;
+        return launch_p3l(unpack3d_bwd_weight_lds_kernel, l, l.ntiles < 512 ? l.ntiles : 512, stream, up_lds_bytes(C));
+    }
     a.total = (long)B * H * W * (C / 8);
     long threads = a.total < 256L * 2048 ? a.total : 256L * 2048;
     return launch_p3(dtype, unpack3d_bwd_weight_kernel<bf16_t>, unpack3d_bwd_weight_kernel<float>, a, threads, stream, 3);

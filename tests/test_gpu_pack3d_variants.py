@@ -35,3 +35,31 @@ def test_lds_pack3d_matches_gather(C, B, H, W):
     assert rel_err(a[1], r[1]) < 8e-3
     assert rel_err(a[2], r[2]) < 5e-4
     assert rel_err(a[3], r[3]) < 5e-4
+
+
+def _run_unpack(C, B, H, W, lds):
+    from mindtheedge_amd import kernels as K
+    K.set_compute_dtype("bf16")
+    K.lib.mte_debug_set(1, 1 if lds else 0)
+    try:
+        g = torch.Generator().manual_seed(C * 3 + W)
+        x = K.image_to_act((torch.rand(B, C, H, W, generator=g) * 2 - 1).cuda()).detach().requires_grad_(True)
+        w3 = ((torch.rand(4, 1, 3, 3, 3, generator=g) - 0.5) * 0.8).cuda().requires_grad_(True)
+        b3 = ((torch.rand(4, generator=g) - 0.5) * 0.4).cuda().requires_grad_(True)
+        y = K.Unpack3dFn.apply(x, w3, b3)
+        G = (torch.rand(y.shape, generator=g) * 2 - 1).cuda()
+        (y.float() * G).sum().backward()
+        torch.cuda.synchronize()
+        return y.float().cpu(), x.grad.float().cpu(), w3.grad.cpu(), b3.grad.cpu()
+    finally:
+        K.lib.mte_debug_set(1, 1)
+
+
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 12, 20), (32, 1, 17, 33), (64, 1, 9, 40), (128, 1, 8, 16), (256, 1, 5, 16), (512, 1, 4, 8)])
+def test_lds_unpack3d_backward_matches_gather(C, B, H, W):
+    a = _run_unpack(C, B, H, W, True)
+    r = _run_unpack(C, B, H, W, False)
+    assert rel_err(a[0], r[0]) < 8e-3
+    assert rel_err(a[1], r[1]) < 8e-3
+    assert rel_err(a[2], r[2]) < 5e-4
+    assert rel_err(a[3], r[3]) < 5e-4
