@@ -35,10 +35,13 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
  * y = conv(x, wpack) + bias.  wpack = [N][KH*KW][Cin_p] in `dtype` (see mte_pack_conv_weights).
  * Also the data-gradient: call with the "backward" pack and x := dy.
  * workspace (nullable): fp32 scratch of >= B*H*W*N elements; when given, shapes with few output tiles and a long
- * reduction (pack4/pack5.conv at low resolution) are split along K over several workgroups. */
+ * reduction (pack4/pack5.conv at low resolution) are split along K over several workgroups.
+ * gn_stats (nullable, device, [B][16][2] doubles) + gn_stats_done (nullable, HOST int): when the launched variant can, the
+ * GroupNorm(16) sum / sum-of-squares of the stored outputs are accumulated in the epilogue and *gn_stats_done = 1;
+ * otherwise *gn_stats_done = 0 and the caller runs mte_gn_stats. */
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
-                     float* workspace, long workspace_elems, mte_stream_t stream);
+                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, mte_stream_t stream);
 /* development knob (A/B experiments): key 0 = igemm tile loader, 1 = LDS-DMA (default), 0 = register staging */
 int mte_debug_set(int key, int value);
 /* weight gradient of the same conv: dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) */
@@ -61,7 +64,7 @@ int mte_conv2d_patch_supported(int W, int Cin_p, int N, int KH, int KW, int dtyp
 long mte_conv2d_patch_pack_elems(int Cin_p, int N, int KH, int KW);
 int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
-                         int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, mte_stream_t stream);
 int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 

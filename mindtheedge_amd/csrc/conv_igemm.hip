@@ -32,6 +32,7 @@ struct ConvArgs {
     int B, H, W, Cin_p, N, KH, KW;
     long M;
     int splits; float* ws;          // split-K: partial sums are atomically added into ws[M][N] (fp32), finished separately
+    double* gn_stats; int gn_gs;    // optional fused GroupNorm statistics: stats[B][16][2] += (sum, sumsq) of the stored outputs
 };
 
 template <typename T> struct Mma;
@@ -293,6 +294,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             constexpr int ES = (int)sizeof(T);
             static_assert(BM * BN * ES <= ST * (BM + BN) * 64, "output tile must fit the ring");
             __syncthreads();                              // every wave is done reading the ring
+            float* s_gn = (float*)(smem + ST * (BM + BN) * 64);       // [2 samples][16 groups][2], extra 256 B of dynamic LDS
+            if (a.gn_stats && tid < 64) s_gn[tid] = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = (wn * TN + j) * 32 + r;
@@ -316,6 +319,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 const long m = m0 + row;
                 if (m < a.M && cc < cvalid)
                     *(u32x4_t*)((T*)a.y + m * a.ldy + n0 + cc * PER16) = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
+            }
+            if (a.gn_stats) {
+                // GroupNorm statistics of the tile as stored (rounded to T): column sums per sample -> groups -> fp64 atomics.
+                // A 128-pixel tile spans at most two samples (H*W >= 128 is checked on the host).
+                constexpr int TPC = 256 / BN, RPP = BM / TPC;          // threads per column, rows per thread
+                const int col = tid % BN, part = tid / BN;
+                const long hw = (long)a.H * a.W;
+                const int b0 = (int)(m0 / hw);
+                const long rsplit = (b0 + 1) * hw - m0;                 // tile rows < rsplit belong to sample b0
+                float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+                if (n0 + col < a.N) {
+                    for (int rr = part * RPP; rr < (part + 1) * RPP; ++rr) {
+                        if (m0 + rr < a.M) {
+                            const float v = Elem<T>::ld((const T*)(smem + (rr * BN + col) * ES));
+                            if (rr < rsplit) { s0 += v; q0 = fmaf(v, v, q0); } else { s1 += v; q1 = fmaf(v, v, q1); }
+                        }
+                    }
+                    const int g = (n0 + col) / a.gn_gs;
+                    atomicAdd(&s_gn[g * 2], s0); atomicAdd(&s_gn[g * 2 + 1], q0);
+                    atomicAdd(&s_gn[32 + g * 2], s1); atomicAdd(&s_gn[32 + g * 2 + 1], q1);
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    const int b = b0 + (tid >> 5);
+                    const float v = s_gn[tid];
+                    if (b < a.B && v != 0.f) atomicAdd(&a.gn_stats[(long)b * 32 + (tid & 31)], (double)v);
+                }
             }
             return;
         }
@@ -367,15 +397,21 @@ inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems) {
 }
 
 template <typename T, int WM, int WN, int TM, int TN>
-int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
+int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
     a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems) : 1;
+    // GroupNorm statistics can ride on the LDS-staged epilogue of the DMA kernels (not: split-K, fp32 output, the register-staged 128x32 configuration)
+    const bool fuse = a.gn_stats && (BN * 4) % 256 == 0 && g_igemm_dma && a.splits == 1 && !a.out_f32 && (long)a.H * a.W >= BM &&
+                      a.N % 16 == 0;
+    if (stats_done) *stats_done = fuse ? 1 : 0;
+    if (!fuse) a.gn_stats = nullptr;
+    else { a.gn_gs = a.N / 16; if (hipMemsetAsync(a.gn_stats, 0, sizeof(double) * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
     if (a.splits > 1 && hipMemsetAsync(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
     if constexpr ((BN * 4) % 256 == 0) {
         if (g_igemm_dma) {
-            const size_t lds4 = 4 * (BM + BN) * 64;
+            const size_t lds4 = 4 * (BM + BN) * 64 + 256;
             const long es = (long)sizeof(T);
             const bool fast = g_igemm_dma == 1 && a.Cin_p % (4 * Elem<T>::PER16) == 0 &&
                               ((a.M - 1) * a.ldx + a.Cin_p) * es < 0x7ff00000L && (long)a.N * a.KH * a.KW * a.Cin_p * es < 0x7ff00000L;
@@ -393,10 +429,10 @@ launched:
     return mte_check_launch();
 }
 
-template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st) {
-    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st);       // 128 x 32
-    if (a.N <= 64 || (a.N % 128 != 0 && a.N < 128)) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st);   // 128 x 64
-    return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st);                      // 128 x 128
+template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st, int* stats_done) {
+    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st, stats_done);       // 128 x 32
+    if (a.N <= 64 || (a.N % 128 != 0 && a.N < 128)) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st, stats_done);   // 128 x 64
+    return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st, stats_done);                      // 128 x 128
 }
 
 // =====================================================================================================
@@ -769,14 +805,15 @@ int mte_debug_set(int key, int value) {
 // workspace (nullable): fp32 scratch of workspace_elems >= B*H*W*N elements enables split-K for small-M / huge-K shapes.
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
-                     float* workspace, long workspace_elems, hipStream_t stream) {
+                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
-    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace};
-    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream);
-    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream);
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, gn_stats, 1};
+    if (gn_stats_done) *gn_stats_done = 0;
+    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream, gn_stats_done);
+    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream, gn_stats_done);
     return MTE_ERR_UNSUPPORTED;
 }
 

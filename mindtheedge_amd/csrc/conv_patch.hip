@@ -29,6 +29,7 @@ struct PatchArgs {
     const float* bias;
     bf16_t* y; long ldy;
     int B, H, W, Cin_p, N;
+    double* gn_stats;                              // optional [B][16][2] fused GroupNorm(16) statistics (pre-zeroed)
 };
 
 // ---- forward / dgrad --------------------------------------------------------------------------------------
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int NCH = (PCH + 255) / 256;
     constexpr int PBYTES = PH * PW * 64;
     constexpr int OBYTES = TH * TW * NT * 64;                      // output staging (bf16 [256 px][32*NT])
-    constexpr int LDS_BYTES = (2 * PBYTES > OBYTES) ? 2 * PBYTES : OBYTES;
+    constexpr int LDS_BYTES = ((2 * PBYTES > OBYTES) ? 2 * PBYTES : OBYTES) + 128;    // + [16 groups][2] statistics
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     }
     // ---- epilogue: stage the tile as bf16 [pixel][N] in LDS, then 16-byte coalesced stores
     constexpr int NB = NT * 64;                                    // bytes per pixel
+    float* s_gn = (float*)(smem + LDS_BYTES - 128);
+    if (a.gn_stats && tid < 32) s_gn[tid] = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int ch = n * 32 + r;
@@ -158,6 +161,23 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
         if (yy < a.H && c < cpp)
             *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * NB + c * 16);
+    }
+    if (a.gn_stats) {                                              // GroupNorm statistics of the stored (bf16-rounded) tile
+        constexpr int NC = NT * 32, TPC = 256 / NC;
+        const int col = tid % NC, part = tid / NC;
+        float s0 = 0.f, q0 = 0.f;
+        if (col < a.N) {
+            for (int pix = part; pix < TH * TW; pix += TPC) {
+                if (y0 + pix / TW < a.H) {
+                    const float v = bf2f(*(const bf16_t*)(smem + pix * NB + col * 2));
+                    s0 += v; q0 = fmaf(v, v, q0);
+                }
+            }
+            const int g = col / (a.N >> 4);
+            atomicAdd(&s_gn[g * 2], s0); atomicAdd(&s_gn[g * 2 + 1], q0);
+        }
+        __syncthreads();
+        if (tid < 32 && s_gn[tid] != 0.f) atomicAdd(&a.gn_stats[(long)b * 32 + tid], (double)s_gn[tid]);
     }
 }
 
@@ -411,10 +431,12 @@ int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N
 
 // y = conv(x, wpatch) + bias for C_out <= 64 (forward, or data-gradient with the backward pack); bf16 only.
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
-                         int B, int H, int W, int Cin_p, int N, int KH, int KW, hipStream_t stream) {
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N};
+    if (gn_stats && N % 16 != 0) return MTE_ERR_ARG;
+    if (gn_stats && hipMemsetAsync(gn_stats, 0, sizeof(double) * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, gn_stats};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
 }
 

@@ -6,6 +6,7 @@ fp32 in validation mode).  PyTorch is used for device memory, streams and the au
 arithmetic step of the hot path is a hand-written gfx950 kernel in libmte_hip.so.  There is no fallback
 path -- a missing library or an unsupported shape raises.
 """
+import ctypes
 import math
 
 import torch
@@ -226,18 +227,24 @@ def _patch_ok(W, cin_p, n, kh, kw, dtype):
     return _cfg["patch_kernels"] and dtype == torch.bfloat16 and lib.mte_conv2d_patch_supported(W, cin_p, n, kh, kw, DT_BF16) == 1
 
 
-def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None):
+def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stats=None):
+    """-> y, or (y, stats_fused) when `gn_stats` ([B,16,2] fp64) is offered: the conv epilogue accumulates the GroupNorm(16)
+    statistics of its own output when the launched kernel variant can (saves one full read of y)."""
     B, Cp, H, W = x.shape
     if out is None:
         out = new_act(B, cout, H, W, x.dtype, x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(out)
+    want = gn_stats is not None and cout % 16 == 0
     if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
-        lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw, _stream())
-        return out
+        lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw,
+                                 gn_stats.data_ptr() if want else 0, _stream())
+        return (out, want) if gn_stats is not None else out
     ws, ws_n = _splitk_workspace(B * H * W, cout, x.device)
-    lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _ptr(ws), ws_n, _stream())
-    return out
+    done = ctypes.c_int(0)
+    lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _ptr(ws), ws_n,
+                         gn_stats.data_ptr() if want else 0, ctypes.byref(done), _stream())
+    return (out, bool(done.value)) if gn_stats is not None else out
 
 
 def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None):
@@ -262,23 +269,25 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
     if need_dx and _patch_ok(W, cout, Cp, kh, kw, x.dtype):
         dx = new_act(B, Cp, H, W, x.dtype, x.device)
         dxp, lddx = _pl(dx)
-        lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, st)
+        lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, 0, st)
     elif need_dx:
         _, wb = pack.get(w, x.dtype, True)
         dx = new_act(B, Cp, H, W, x.dtype, x.device)
         dxp, lddx = _pl(dx)
         ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
-        lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, st)
+        lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, 0, 0, st)
     return dx, dw, dbias
 
 
-def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
+def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, stats=None):
+    """`stats`: statistics already accumulated by the producing conv's epilogue (skips the statistics pass)"""
     B, C, H, W = y1.shape
-    stats = torch.empty((B, 16, 2), dtype=torch.float64, device=y1.device)
     p1, l1 = _pl(y1)
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     st = _stream()
-    lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
+    if stats is None:
+        stats = torch.empty((B, 16, 2), dtype=torch.float64, device=y1.device)
+        lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
     zp, lz = _pl(z)
     lib.mte_gn_elu_fwd(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), zp, lz,
@@ -318,8 +327,9 @@ class ConvGnEluFn(torch.autograd.Function):
     def forward(ctx, x, w, b, gamma, beta, pack):
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
-        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
-        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS)
+        stats = torch.empty((x.shape[0], 16, 2), dtype=torch.float64, device=x.device)
+        y, fused = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w, gn_stats=stats)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, stats=stats if fused else None)
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
         ctx.bias = b

@@ -60,3 +60,48 @@ def test_generic_igemm_fp32_matches_torch_cpu(shape):
     assert rel_err(r["dx"], x.grad) < 2e-5
     assert rel_err(r["dw"], w.grad) < 5e-5
     assert rel_err(r["db"], b.grad) < 2e-5
+
+
+STAT_SHAPES = [  # cin, cout, k, B, H, W — tiles that straddle two samples, ragged last tile, all three generic tile widths
+    (32, 32, 3, 3, 10, 40), (64, 64, 3, 2, 9, 24), (96, 128, 3, 2, 13, 20), (24, 256, 1, 3, 16, 16), (40, 512, 1, 2, 12, 30),
+    (32, 32, 3, 2, 16, 64), (64, 64, 5, 2, 9, 32), (16, 16, 7, 2, 8, 32),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", STAT_SHAPES)
+def test_conv_epilogue_groupnorm_statistics(shape, dtype):
+    """GroupNorm statistics accumulated in the conv epilogues (generic DMA kernels and patch kernels) must equal the
+    stand-alone statistics pass over the stored conv output."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W = shape
+    K.set_compute_dtype(dtype)
+    try:
+        g = torch.Generator().manual_seed(7 + cin + cout)
+        w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+        b = (torch.rand(cout, generator=g) - 0.5).cuda()
+        xa = K.image_to_act(torch.rand(B, cin, H, W, generator=g).cuda() * 2 - 1)
+        pack = K.WeightPack()
+        wf, _ = pack.get(w, xa.dtype, False)
+        stats = torch.full((B, 16, 2), 123.0, dtype=torch.float64, device="cuda")
+        ws_fn, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)      # split-K launches do not fuse
+        try:
+            y, fused = K.conv_forward(xa, wf, b, cout, k, k, pack=pack, w=w, gn_stats=stats)
+        finally:
+            K._splitk_workspace = ws_fn
+        patch = dtype == "bf16" and W % 32 == 0 and cout <= 64
+        assert fused == (patch or cout > 32)           # the generic 128x32 configuration has no LDS-staged epilogue
+        if not fused:
+            return
+        ref = torch.empty_like(stats)
+        p, ld = K._pl(y)
+        K.lib.mte_gn_stats(p, ld, 0, 0, 0, ref.data_ptr(), B, H * W, cout, K._dt(y), K._stream())
+        torch.cuda.synchronize()
+        yf = y.float()[:, :cout].reshape(B, 16, -1).double()
+        exact = torch.stack([yf.sum(-1), (yf * yf).sum(-1)], -1)
+        n = yf.shape[-1]
+        # compare as (mean, E[x^2]); fp32 partial sums inside a tile, fp64 across tiles
+        assert torch.allclose(stats / n, exact / n, rtol=2e-5, atol=2e-6)
+        assert torch.allclose(ref / n, exact / n, rtol=2e-5, atol=2e-6)
+    finally:
+        K.set_compute_dtype("bf16")
