@@ -184,6 +184,9 @@ def main():
     import random
 
     K.set_compute_dtype(args.dtype)
+    for kv in filter(None, os.environ.get("MTE_DEBUG_KNOBS", "").split(",")):      # development A/B knobs, e.g. "2=8,3=4096"
+        k, v = kv.split("=")
+        K.lib.mte_debug_set(int(k), int(v))
     torch.manual_seed(42)                                # default_config.py:16 seed; xavier init per PackNetSAN01.init_weights
     net = PackNetSAN01(dropout=0.5, version="1A").to(dev)
     model = SemiSupEdgeModel(supervised_loss_weight=1.0, depth_edges_loss_weight=1.0, supervised_method="sparse-silog",

@@ -795,9 +795,11 @@ extern "C" {
 // 0 = register staging); key 1 = conv3d pack stencils
 // (1 = LDS-tiled, 0 = gather).  Not part of the product contract.
 extern "C" int mtei_set_pack3d_lds(int value);
+extern "C" int mtei_set_gn(int which, int value);
 int mte_debug_set(int key, int value) {
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
     if (key == 1) return mtei_set_pack3d_lds(value);
+    if (key == 2 || key == 3) return mtei_set_gn(key - 2, value);
     return MTE_ERR_ARG;
 }
 

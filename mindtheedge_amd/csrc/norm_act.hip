@@ -33,21 +33,34 @@ struct GnArgs {
     int blocks_per_sample;
 };
 
+// Pixel rows are processed in batches of GN_U: all 16-byte loads of a batch are issued before any of its stores, so a
+// wave keeps GN_U x (2..3) KiB in flight (the output pointers may alias the inputs as far as the compiler knows, which
+// otherwise serialises load -> store -> load and leaves these streams latency-bound).
+constexpr int GN_U = 4;
+
+template <typename T> struct RawRow { u32x4_t c1, c2; };
+
 template <typename T>
-__device__ __forceinline__ void load_v(const GnArgs& a, long pix, int b, int ch0, float* v) {
+__device__ __forceinline__ void load_raw(const GnArgs& a, long pix, int ch0, RawRow<T>& r) {
+    r.c1 = *(const u32x4_t*)((const T*)a.y1 + pix * a.ld1 + ch0);
+    if (a.y2) r.c2 = *(const u32x4_t*)((const T*)a.y2 + pix * a.ld2 + ch0);
+}
+// v = y1 + sc * y2 (sc = Dropout2d factor of this sample's channels, 1 when absent)
+template <typename T>
+__device__ __forceinline__ void finish_v(const GnArgs& a, const RawRow<T>& r, const float* sc, float* v) {
     constexpr int P = Elem<T>::PER16;
-    unpack16<T>(*(const u32x4_t*)((const T*)a.y1 + pix * a.ld1 + ch0), v);
+    unpack16<T>(r.c1, v);
     if (a.y2) {
         float w[P];
-        unpack16<T>(*(const u32x4_t*)((const T*)a.y2 + pix * a.ld2 + ch0), w);
-        if (a.scale2) {
+        unpack16<T>(r.c2, w);
 #pragma unroll
-            for (int i = 0; i < P; ++i) v[i] += w[i] * a.scale2[(long)b * a.C + ch0 + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < P; ++i) v[i] += w[i];
-        }
+        for (int i = 0; i < P; ++i) v[i] += w[i] * sc[i];            // product rounded first, like Dropout2d then add
     }
+}
+template <typename T>
+__device__ __forceinline__ void load_scale2(const GnArgs& a, int b, int ch0, float* sc) {
+#pragma unroll
+    for (int i = 0; i < Elem<T>::PER16; ++i) sc[i] = (a.y2 && a.scale2) ? a.scale2[(long)b * a.C + ch0 + i] : 1.f;
 }
 
 // thread -> (chunk column cc, pixel lane prow); block -> (pixel range of one sample)
@@ -71,12 +84,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
     float s[P], q[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) { s[i] = 0.f; q[i] = 0.f; }
-#pragma unroll 4
-    for (int p = p_begin + prow; p < p_end; p += rstep) {
-        float v[P];
-        load_v<T>(a, (long)b * a.HW + p, b, ch0, v);
+    float sc[P];
+    load_scale2<T>(a, b, ch0, sc);
+    for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
+        RawRow<T> raw[GN_U];
 #pragma unroll
-        for (int i = 0; i < P; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
+        for (int u = 0; u < GN_U; ++u)
+            if (p + u * rstep < p_end) load_raw<T>(a, (long)b * a.HW + p + u * rstep, ch0, raw[u]);
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            if (p + u * rstep >= p_end) break;
+            float v[P];
+            finish_v<T>(a, raw[u], sc, v);
+#pragma unroll
+            for (int i = 0; i < P; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
+        }
     }
     // combine channels of the same group held by this thread, then LDS atomics
 #pragma unroll
@@ -100,26 +122,47 @@ __device__ __forceinline__ void group_mean_rstd(const GnArgs& a, int b, int g, i
     rstd = (float)(1.0 / sqrt(var + (double)a.eps));
 }
 
+// The fp64 mean / rstd of the 16 groups of sample b are evaluated once per block (16 lanes) and shared through LDS:
+// per-thread evaluation (8 fp64 divisions + square roots per thread) used to dominate the short low-resolution launches.
+__device__ __forceinline__ void block_group_stats(const GnArgs& a, int b, int gs, float* s_mr) {
+    if (threadIdx.x < GN_GROUPS) {
+        float m, r;
+        group_mean_rstd(a, b, threadIdx.x, gs, m, r);
+        s_mr[2 * threadIdx.x] = m; s_mr[2 * threadIdx.x + 1] = r;
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_elu_fwd_kernel(GnArgs a) {
     GN_THREAD_MAP();
+    __shared__ float s_mr[GN_GROUPS * 2];
+    block_group_stats(a, b, gs, s_mr);
     float ka[P], kb[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        float mean, rstd;
-        group_mean_rstd(a, b, (ch0 + i) / gs, gs, mean, rstd);
+        const int g = (ch0 + i) / gs;
+        const float mean = s_mr[2 * g], rstd = s_mr[2 * g + 1];
         const float gm = a.gamma[ch0 + i];
         ka[i] = rstd * gm;
         kb[i] = a.beta[ch0 + i] - mean * rstd * gm;
     }
-#pragma unroll 4
-    for (int p = p_begin + prow; p < p_end; p += rstep) {
-        const long pix = (long)b * a.HW + p;
-        float v[P];
-        load_v<T>(a, pix, b, ch0, v);
+    float sc[P];
+    load_scale2<T>(a, b, ch0, sc);
+    for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
+        RawRow<T> raw[GN_U];
 #pragma unroll
-        for (int i = 0; i < P; ++i) v[i] = elu1(fmaf(v[i], ka[i], kb[i]));
-        *(u32x4_t*)((T*)a.z + pix * a.ldz + ch0) = pack16<T>(v);
+        for (int u = 0; u < GN_U; ++u)
+            if (p + u * rstep < p_end) load_raw<T>(a, (long)b * a.HW + p + u * rstep, ch0, raw[u]);
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            if (p + u * rstep >= p_end) break;
+            float v[P];
+            finish_v<T>(a, raw[u], sc, v);
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] = elu1(fmaf(v[i], ka[i], kb[i]));
+            *(u32x4_t*)((T*)a.z + ((long)b * a.HW + p + u * rstep) * a.ldz + ch0) = pack16<T>(v);
+        }
     }
 }
 
@@ -128,27 +171,41 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
     GN_THREAD_MAP();
     extern __shared__ float s_red[];                      // [C][2]
+    __shared__ float s_mr[GN_GROUPS * 2];
     for (int i = threadIdx.x; i < a.C * 2; i += 256) s_red[i] = 0.f;
-    __syncthreads();
+    block_group_stats(a, b, gs, s_mr);
     float mean[P], rstd[P], gm[P], bt[P], r1[P], r2[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        group_mean_rstd(a, b, (ch0 + i) / gs, gs, mean[i], rstd[i]);
+        mean[i] = s_mr[2 * ((ch0 + i) / gs)]; rstd[i] = s_mr[2 * ((ch0 + i) / gs) + 1];
         gm[i] = a.gamma[ch0 + i]; bt[i] = a.beta[ch0 + i];
         r1[i] = 0.f; r2[i] = 0.f;
     }
-#pragma unroll 2
-    for (int p = p_begin + prow; p < p_end; p += rstep) {
-        const long pix = (long)b * a.HW + p;
-        float v[P], g[P];
-        load_v<T>(a, pix, b, ch0, v);
-        unpack16<T>(*(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0), g);
+    float sc[P];
+    load_scale2<T>(a, b, ch0, sc);
+    for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
+        RawRow<T> raw[GN_U];
+        u32x4_t gr[GN_U];
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const float xh = (v[i] - mean[i]) * rstd[i];
-            const float u = fmaf(xh, gm[i], bt[i]);
-            const float dyh = g[i] * (u > 0.f ? 1.f : __expf(u));
-            r1[i] += dyh; r2[i] = fmaf(dyh, xh, r2[i]);
+        for (int u = 0; u < GN_U; ++u)
+            if (p + u * rstep < p_end) {
+                const long pix = (long)b * a.HW + p + u * rstep;
+                load_raw<T>(a, pix, ch0, raw[u]);
+                gr[u] = *(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0);
+            }
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            if (p + u * rstep >= p_end) break;
+            float v[P], g[P];
+            finish_v<T>(a, raw[u], sc, v);
+            unpack16<T>(gr[u], g);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const float xh = (v[i] - mean[i]) * rstd[i];
+                const float uu = fmaf(xh, gm[i], bt[i]);
+                const float dyh = g[i] * (uu > 0.f ? 1.f : __expf(uu));
+                r1[i] += dyh; r2[i] = fmaf(dyh, xh, r2[i]);
+            }
         }
     }
 #pragma unroll
@@ -162,10 +219,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
     GN_THREAD_MAP();
     extern __shared__ float s_db[];                       // [C] when a.dbias
-    if (a.dbias) {
+    __shared__ float s_mr[GN_GROUPS * 2], s_S[GN_GROUPS * 2];
+    if (a.dbias)
         for (int i = threadIdx.x; i < a.C; i += 256) s_db[i] = 0.f;
-        __syncthreads();
+    if (threadIdx.x < GN_GROUPS * 2) s_S[threadIdx.x] = 0.f;
+    block_group_stats(a, b, gs, s_mr);
+    // S1_g = sum_{c in g} gamma_c r1_c, S2_g likewise: one pass of the block over the C channels of this sample
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        const float gc = a.gamma[c];
+        const float2 r = *(const float2*)(a.red + ((long)b * a.C + c) * 2);
+        atomicAdd(&s_S[2 * (c / gs)], gc * r.x); atomicAdd(&s_S[2 * (c / gs) + 1], gc * r.y);
     }
+    __syncthreads();
     float db[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) db[i] = 0.f;
@@ -174,39 +239,42 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int g = (ch0 + i) / gs;
-        group_mean_rstd(a, b, g, gs, mean[i], rstd[i]);
+        mean[i] = s_mr[2 * g]; rstd[i] = s_mr[2 * g + 1];
         gm[i] = a.gamma[ch0 + i]; bt[i] = a.beta[ch0 + i];
         sc[i] = (a.y2 && a.scale2) ? a.scale2[(long)b * a.C + ch0 + i] : 1.f;
-        if (i > 0 && (ch0 + i - 1) / gs == g) { s1[i] = s1[i - 1]; s2[i] = s2[i - 1]; }
-        else {
-            float t1 = 0.f, t2 = 0.f;
-            for (int c = g * gs; c < (g + 1) * gs; ++c) {
-                const float gc = a.gamma[c];
-                t1 = fmaf(gc, a.red[((long)b * a.C + c) * 2], t1);
-                t2 = fmaf(gc, a.red[((long)b * a.C + c) * 2 + 1], t2);
-            }
-            s1[i] = t1 * inv_n; s2[i] = t2 * inv_n;
-        }
+        s1[i] = s_S[2 * g] * inv_n; s2[i] = s_S[2 * g + 1] * inv_n;
     }
-#pragma unroll 2
-    for (int p = p_begin + prow; p < p_end; p += rstep) {
-        const long pix = (long)b * a.HW + p;
-        float v[P], g[P];
-        load_v<T>(a, pix, b, ch0, v);
-        unpack16<T>(*(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0), g);
+    for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
+        RawRow<T> raw[GN_U];
+        u32x4_t gr[GN_U];
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const float xh = (v[i] - mean[i]) * rstd[i];
-            const float u = fmaf(xh, gm[i], bt[i]);
-            const float dyh = g[i] * (u > 0.f ? 1.f : __expf(u));
-            v[i] = rstd[i] * (dyh * gm[i] - (s1[i] + xh * s2[i]));
-            db[i] += v[i];
-        }
-        *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
-        if (a.d2) {
+        for (int u = 0; u < GN_U; ++u)
+            if (p + u * rstep < p_end) {
+                const long pix = (long)b * a.HW + p + u * rstep;
+                load_raw<T>(a, pix, ch0, raw[u]);
+                gr[u] = *(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0);
+            }
 #pragma unroll
-            for (int i = 0; i < P; ++i) v[i] *= sc[i];
-            *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
+        for (int u = 0; u < GN_U; ++u) {
+            if (p + u * rstep >= p_end) break;
+            const long pix = (long)b * a.HW + p + u * rstep;
+            float v[P], g[P];
+            finish_v<T>(a, raw[u], sc, v);
+            unpack16<T>(gr[u], g);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const float xh = (v[i] - mean[i]) * rstd[i];
+                const float uu = fmaf(xh, gm[i], bt[i]);
+                const float dyh = g[i] * (uu > 0.f ? 1.f : __expf(uu));
+                v[i] = rstd[i] * (dyh * gm[i] - (s1[i] + xh * s2[i]));
+                db[i] += v[i];
+            }
+            *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
+            if (a.d2) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) v[i] *= sc[i];
+                *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
+            }
         }
     }
     if (a.dbias) {
@@ -225,10 +293,12 @@ __global__ void gn_param_grad_kernel(const float* __restrict__ red, float* __res
     dgamma[c] = g; dbeta[c] = bt;
 }
 
+int g_gn_min_rows = 32, g_gn_target = 2048;         // development knobs (mte_debug_set(2 / 3, v))
+
 int gn_blocks(int B, int HW, int rstep) {
-    // ~8 workgroups per CU across the batch, at least 32 pixels per thread row
-    long want = (2048 + B - 1) / B;
-    long maxb = ((long)HW + 32L * rstep - 1) / (32L * rstep);
+    // ~8 workgroups per CU across the batch, at least g_gn_min_rows pixels per thread row
+    long want = (g_gn_target + B - 1) / B;
+    long maxb = ((long)HW + (long)g_gn_min_rows * rstep - 1) / ((long)g_gn_min_rows * rstep);
     if (want > maxb) want = maxb;
     return (int)(want < 1 ? 1 : want);
 }
@@ -241,6 +311,12 @@ bool gn_shape_ok(int C, int dtype) {
 }
 
 }  // namespace
+
+extern "C" int mtei_set_gn(int which, int value) {
+    if (value < 1) return MTE_ERR_ARG;
+    if (which == 0) g_gn_min_rows = value; else g_gn_target = value;
+    return MTE_OK;
+}
 
 extern "C" {
 
