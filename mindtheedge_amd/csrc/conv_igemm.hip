@@ -668,6 +668,268 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---- bf16 wgrad with an LDS-DMA ring (the generic kernel above stays for fp32 validation mode and > 2 GiB tensors).
+// Same work decomposition (n tile x one tap x c tile x pixel split) and the same transposing-read MFMA feed, but the
+// [32 pixels][channels] tiles are written straight into a 4-slot LDS ring by buffer_load ... lds (no register staging,
+// three stages in flight, one counted vmcnt + one barrier per 32-pixel step -- the igemm LD = 2 pipeline).  LDS-DMA
+// writes 64 consecutive 16-byte slots per wave instruction, so rows cannot be padded; instead the 16-byte chunk index
+// is XOR-swizzled on the global side (chunk' = chunk ^ swz(row)) such that the 32 lanes of a ds_read_b64_tr_b16 half
+// (4 pixel rows x 2 channel groups x 32 B) cover all 64 banks:  256-byte rows: swz = 4*(row&3); 128-byte rows (two rows
+// per bank sweep): swz = 4*((row>>1)&1).
+// FL = true: 32-pixel blocks are segments of one image row (wave-uniform SGPR offsets, lane offsets constant);
+// FL = false: flattened pixels, each lane tracks the image coordinates of its tile rows incrementally.
+template <int OFF> __device__ __forceinline__ unsigned long long lds_tr16(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    unsigned long long v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ bf16x8_t tr_operand(unsigned long long lo, unsigned long long hi) {
+    const u32x4_t c{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    return __builtin_bit_cast(bf16x8_t, c);
+}
+template <int CPRW> __device__ __forceinline__ int wg_swz(int row) { return CPRW == 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
+
+template <int TNO, int TC, bool FL>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a) {
+    typedef bf16_t T;
+    constexpr int BNO = 2 * TNO * 32, BC = 2 * TC * 32;               // cout x cin tile, waves 2 x 2
+    constexpr int KB = 32, ES = 2;
+    constexpr int CPR_Y = BNO / 8, CPR_X = BC / 8;                    // 16-byte chunks per tile row (8 or 16)
+    constexpr int ROWB_Y = BNO * ES, ROWB_X = BC * ES;
+    constexpr int YB = KB * ROWB_Y, XB = KB * ROWB_X, STAGE = YB + XB;
+    constexpr int YI = YB / 1024 / 4, XI = XB / 1024 / 4;              // DMA instructions per wave and stage
+    static_assert(YI >= 1 && XI >= 1, "tile too small for one DMA instruction per wave");
+    constexpr int LPS = YI + XI;
+    constexpr int ST = 4;
+    constexpr unsigned OOB = 0xfffffff0u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int taps = a.KH * a.KW;
+    const int tile_c = id % a.tiles_c; id /= a.tiles_c;
+    const int tap = id % taps; id /= taps;
+    const int tile_n = id % a.tiles_n; id /= a.tiles_n;
+    const int split = id;
+    const int ty = tap / a.KW, tx = tap % a.KW;
+    const int dyo = ty - (a.KH >> 1), dxo = tx - (a.KW >> 1), padw = a.KW >> 1;
+    const int n0 = tile_n * BNO, c0 = tile_c * BC;
+    const T* xp = (const T*)a.x;
+    const T* yp = (const T*)a.dy;
+
+    const int bpr = (a.W + KB - 1) / KB;
+    const long nblk_total = FL ? (long)a.B * a.H * bpr : (a.M + KB - 1) / KB;
+    const long blk0 = (long)split * a.blocks_per_split;
+    long blk1 = blk0 + a.blocks_per_split; if (blk1 > nblk_total) blk1 = nblk_total;
+    const int nst = (int)(blk1 - blk0);
+
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // lane constants of the DMA side: tile row inside the instruction and the (swizzled) source chunk
+    int rowY[YI], rowX[XI];
+    unsigned voffY[YI], voffX[XI];
+    int x_oy[XI], x_ox[XI];                                           // !FL: image coordinates of this lane's tile rows
+#pragma unroll
+    for (int i = 0; i < YI; ++i) {
+        rowY[i] = (wv * YI + i) * (64 / CPR_Y) + lane / CPR_Y;
+        const int n = n0 + ((lane % CPR_Y) ^ wg_swz<CPR_Y>(rowY[i])) * 8;
+        voffY[i] = n < a.N ? (unsigned)((rowY[i] * a.ldy + n) * ES) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        rowX[i] = (wv * XI + i) * (64 / CPR_X) + lane / CPR_X;
+        const int cc = c0 + ((lane % CPR_X) ^ wg_swz<CPR_X>(rowX[i])) * 8;
+        if constexpr (FL) voffX[i] = cc < a.Cin_p ? (unsigned)(((rowX[i] + dxo + padw) * a.ldx + cc) * ES) : OOB;
+        else {
+            voffX[i] = cc < a.Cin_p ? (unsigned)(cc * ES) : OOB;
+            const long m = blk0 * KB + rowX[i];
+            const long hw = (long)a.H * a.W;
+            const int rem = (int)(m % hw);
+            x_oy[i] = rem / a.W; x_ox[i] = rem - x_oy[i] * a.W;
+        }
+    }
+    int f_xb = 0, f_y = 0, f_b = 0;
+    long f_blk = blk0;
+    if constexpr (FL) { f_xb = (int)(blk0 % bpr); const long t = blk0 / bpr; f_y = (int)(t % a.H); f_b = (int)(t / a.H); }
+
+    auto dma_stage = [&](int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        char* sY = smem + slot * STAGE;
+        char* sX = sY + YB;
+        const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, (int)(((a.M - 1) * a.ldy + a.N) * ES), 0x00020000);
+        if constexpr (FL) {
+            const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(xp - (long)padw * a.ldx), 0,
+                                                               (int)(((a.M - 1 + padw) * a.ldx + a.Cin_p) * ES), 0x00020000);
+            const int x0 = f_xb * KB, rem = a.W - x0;
+            const int yy = f_y + dyo;
+            const bool row_ok = (unsigned)yy < (unsigned)a.H;
+            const int soffY = (int)((((long)f_b * a.H + f_y) * a.W + x0) * a.ldy * ES);
+            const int soffX = row_ok ? (int)((((long)f_b * a.H + yy) * a.W + x0) * a.ldx * ES) : 0;
+#pragma unroll
+            for (int i = 0; i < YI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lptr_t)(sY + (wv * YI + i) * 1024), 16,
+                                                         rowY[i] < rem ? voffY[i] : OOB, soffY, 0, 0);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bool ok = row_ok && rowX[i] < rem && (unsigned)(x0 + rowX[i] + dxo) < (unsigned)a.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(sX + (wv * XI + i) * 1024), 16, ok ? voffX[i] : OOB, soffX, 0, 0);
+            }
+            if (++f_xb == bpr) { f_xb = 0; if (++f_y == a.H) { f_y = 0; ++f_b; } }
+        } else {
+            const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, (int)(((a.M - 1) * a.ldx + a.Cin_p) * ES), 0x00020000);
+            const int soffY = (int)(f_blk * KB * a.ldy * ES);
+#pragma unroll
+            for (int i = 0; i < YI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lptr_t)(sY + (wv * YI + i) * 1024), 16,
+                                                         f_blk * KB + rowY[i] < a.M ? voffY[i] : OOB, soffY, 0, 0);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const long m = f_blk * KB + rowX[i];
+                const int iy = x_oy[i] + dyo, ix = x_ox[i] + dxo;
+                const bool ok = m < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned off = voffX[i] == OOB ? OOB : voffX[i] + (unsigned)((m + (long)dyo * a.W + dxo) * a.ldx * ES);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(sX + (wv * XI + i) * 1024), 16, ok ? off : OOB, 0, 0, 0);
+                x_ox[i] += KB;
+                while (x_ox[i] >= a.W) { x_ox[i] -= a.W; if (++x_oy[i] == a.H) x_oy[i] = 0; }
+            }
+            ++f_blk;
+        }
+#else
+        (void)slot;
+#endif
+    };
+
+    f32x16_t acc[TNO][TC];
+#pragma unroll
+    for (int i = 0; i < TNO; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wno = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    // transposing-read lane constants: 16-lane group g covers channels 16*(g&1).., pixels 8*(g>>1) + q (+4 for the high half)
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int prow = 8 * (g >> 1) + q;
+    int offY[TNO], offX[TC];
+#pragma unroll
+    for (int i = 0; i < TNO; ++i)
+        offY[i] = prow * ROWB_Y + ((((wno * TNO + i) * 4 + 2 * (g & 1) + (pp >> 1)) ^ wg_swz<CPR_Y>(prow)) * 16) + (pp & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < TC; ++j)
+        offX[j] = prow * ROWB_X + ((((wc * TC + j) * 4 + 2 * (g & 1) + (pp >> 1)) ^ wg_swz<CPR_X>(prow)) * 16) + (pp & 1) * 8;
+
+    // The transposing reads are issued through inline asm: the compiler does not know which LDS bytes the intrinsic form
+    // touches and would fence it with s_waitcnt vmcnt(0) against the LDS-DMA writes still in flight for the NEXT stages,
+    // serialising the ring.  The asm results are tied to hand-placed s_waitcnt lgkmcnt (LDS returns in order).
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto compute = [&](int slot) {
+        unsigned long long y0[TNO][2], y1[TNO][2], x0[TC][2], x1[TC][2];      // [operand][lo/hi pixel quad], k16 step 0 / 1
+        const unsigned sb = lds0 + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < TNO; ++i) {
+            const unsigned ad = sb + offY[i];
+            y0[i][0] = lds_tr16<0>(ad); y0[i][1] = lds_tr16<4 * ROWB_Y>(ad);
+        }
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            const unsigned ad = sb + YB + offX[j];
+            x0[j][0] = lds_tr16<0>(ad); x0[j][1] = lds_tr16<4 * ROWB_X>(ad);
+        }
+#pragma unroll
+        for (int i = 0; i < TNO; ++i) {
+            const unsigned ad = sb + offY[i];
+            y1[i][0] = lds_tr16<16 * ROWB_Y>(ad); y1[i][1] = lds_tr16<20 * ROWB_Y>(ad);
+        }
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            const unsigned ad = sb + YB + offX[j];
+            x1[j][0] = lds_tr16<16 * ROWB_X>(ad); x1[j][1] = lds_tr16<20 * ROWB_X>(ad);
+        }
+        if constexpr (TNO == 2)
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(y0[0][0]), "+v"(y0[0][1]), "+v"(y0[TNO - 1][0]), "+v"(y0[TNO - 1][1]),
+                         "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]), "+v"(x0[1][1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(y0[0][0]), "+v"(y0[0][1]), "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]), "+v"(x0[1][1]));
+#pragma unroll
+        for (int i = 0; i < TNO; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(y0[i][0], y0[i][1]), tr_operand(x0[j][0], x0[j][1]), acc[i][j], 0, 0, 0);
+        if constexpr (TNO == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y1[0][0]), "+v"(y1[0][1]), "+v"(y1[TNO - 1][0]), "+v"(y1[TNO - 1][1]),
+                         "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y1[0][0]), "+v"(y1[0][1]), "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]));
+#pragma unroll
+        for (int i = 0; i < TNO; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(y1[i][0], y1[i][1]), tr_operand(x1[j][0], x1[j][1]), acc[i][j], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        if (p < nst) dma_stage(p);
+    for (int i = 0; i < nst; ++i) {
+        const int rem = nst - 1 - i;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + 3 < nst) dma_stage((i + 3) & 3);
+        compute(i & 3);
+    }
+
+    // ---- epilogue: D[row = cout][col = cin]; col = lane&31 -> contiguous fp32 in the staging buffer
+    const long Kp = (long)taps * a.Cin_p;
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+        const int cc = c0 + (wc * TC + j) * 32 + r;
+        if (cc >= a.Cin_p) continue;
+#pragma unroll
+        for (int i = 0; i < TNO; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + (wno * TNO + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < a.N) {
+                    float* dst = a.dw + (long)n * Kp + (long)tap * a.Cin_p + cc;
+                    if (a.splits > 1) atomicAdd(dst, acc[i][j][e]);
+                    else *dst = acc[i][j][e];
+                }
+            }
+        }
+    }
+}
+
+int g_wgrad_dma = 1;                                 // development knob (mte_debug_set(4, v))
+
+template <int TNO, int TC>
+int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
+    constexpr int BNO = 2 * TNO * 32, BC = 2 * TC * 32;
+    a.tiles_n = (a.N + BNO - 1) / BNO;
+    a.tiles_c = (a.Cin_p + BC - 1) / BC;
+    const int taps = a.KH * a.KW;
+    // row-aligned 32-pixel blocks waste MFMA work when W is not a multiple of 32 (W = 40: 37 %): use them for wide rows only
+    const bool fl = a.W % 32 == 0 || a.W >= 160;
+    const long nblk = fl ? (long)a.B * a.H * ((a.W + 31) / 32) : (a.M + 31) / 32;
+    const long base_wgs = (long)a.tiles_n * a.tiles_c * taps;
+    long splits = (1024 + base_wgs - 1) / base_wgs;            // aim for >= ~4 workgroups per CU
+    const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.blocks_per_split = (int)((nblk + splits - 1) / splits);
+    a.splits = (int)((nblk + a.blocks_per_split - 1) / a.blocks_per_split);
+    if (a.splits > 1 && hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+    const size_t lds = 4 * 32 * (BNO + BC) * 2;
+    const dim3 grid((unsigned)(base_wgs * a.splits));
+    if (fl) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TNO, TC, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<TNO, TC, false>), grid, dim3(256), lds, st, a);
+    return mte_check_launch();
+}
+
 template <typename T, int WNO, int WC, int TNO, int TC>
 int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int BNO = WNO * TNO * 32, BC = WC * TC * 32, ES = (int)sizeof(T);
@@ -699,6 +961,11 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
 }
 
 template <typename T> int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        const bool fits = ((a.M + a.KW) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((a.M - 1) * a.ldy + a.N) * 2 < 0x7ff00000L;
+        if (g_wgrad_dma && fits && a.N > 32 && a.Cin_p > 32)
+            return a.N <= 64 ? launch_wgrad_dma<1, 2>(a, st) : launch_wgrad_dma<2, 2>(a, st);
+    }
     if (a.N <= 32) {
         if (a.Cin_p <= 32) return launch_wgrad<T, 1, 4, 1, 1>(a, st);      // 32 x 128 would waste: 32 x (4*32)
         return launch_wgrad<T, 1, 4, 1, 1>(a, st);                          // cout 32 x cin 128
@@ -800,6 +1067,7 @@ int mte_debug_set(int key, int value) {
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
     if (key == 1) return mtei_set_pack3d_lds(value);
     if (key == 2 || key == 3) return mtei_set_gn(key - 2, value);
+    if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     return MTE_ERR_ARG;
 }
 

@@ -76,9 +76,11 @@ __global__ void invdepth_dlogit_kernel(const float* __restrict__ dout, const flo
     }
 }
 
-// dx[p][c] = sum_t dlogit[p - t] * w[c][t];  dw[c][t] += sum_p dlogit[p] * x[p + t][c];  db += sum_p dlogit[p]
+// dx[q][c] = sum_t dlogit[q - t] * w[c][t];  dw[c][t] += sum_q dlogit[q - t] * x[q][c];  db += sum_q dlogit[q]
+// Both sums are driven by the x pixel q: one 16-byte load of x[q] and the 3x3 neighbourhood of the (fp32, one float per
+// pixel) logit gradient feed 72 weight-gradient and 72 data-gradient FMAs, so x is read exactly once.
 template <typename T>
-__global__ __launch_bounds__(256, 3) void invdepth_bwd_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, 2) void invdepth_bwd_kernel(HeadArgs a) {
     extern __shared__ float sdw[];                               // [C*9 + 1] gradient accumulators, then [9][C] weights (tap-major)
     float* swt = sdw + ((a.C * 9 + 4) & ~3);                     // 16-byte aligned
     for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) sdw[i] = 0.f;
@@ -94,34 +96,47 @@ __global__ __launch_bounds__(256, 3) void invdepth_bwd_kernel(HeadArgs a) {
         for (int i = 0; i < 8; ++i) gw[t][i] = 0.f;
     float gb = 0.f;
     const long ppb = 256 / cb;
-    const long iters = (a.npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
+    const long stride = (long)gridDim.x * ppb;
+    constexpr int U = 2;                                         // pixels in flight per thread
 #pragma unroll 1
-    for (long it = 0; it < iters; ++it) {
-        const long pix = (it * gridDim.x + blockIdx.x) * ppb + threadIdx.x / cb;
-        if (pix >= a.npix) continue;
-        const int x = (int)(pix % a.W); const long t2 = pix / a.W; const int y = (int)(t2 % a.H);
-        const float dl0 = a.dlogit[pix];
-        if (j == 0) gb += dl0;
-        float dxv[8];
+    for (long base = blockIdx.x * ppb + threadIdx.x / cb; base < a.npix; base += stride * U) {
+        u32x4_t xr[U];
+        float dl[U][9];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dxv[i] = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const long pix = base + u * stride;
+            if (pix < a.npix) {
+                if constexpr (sizeof(T) == 2) xr[u] = *(const u32x4_t*)((const T*)a.x + pix * a.ldx + c0);
+                const int x = (int)(pix % a.W); const int y = (int)((pix / a.W) % a.H);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int oy = t / 3 - 1, ox = t % 3 - 1;
-            if ((unsigned)(y + oy) < (unsigned)a.H && (unsigned)(x + ox) < (unsigned)a.W) {       // weight gradient: x at p + t
-                float v[8];
-                ld8<T>((const T*)a.x + (pix + (long)oy * a.W + ox) * a.ldx + c0, v);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(dl0, v[i], gw[t][i]);
-            }
-            if ((unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W) {       // data gradient: dlogit at p - t
-                const float dl = a.dlogit[pix - (long)oy * a.W - ox];
-                const f32x4_t w0 = *(const f32x4_t*)(swt + t * a.C + c0), w1 = *(const f32x4_t*)(swt + t * a.C + c0 + 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { dxv[i] = fmaf(dl, w0[i], dxv[i]); dxv[4 + i] = fmaf(dl, w1[i], dxv[4 + i]); }
+                for (int t = 0; t < 9; ++t) {
+                    const int oy = t / 3 - 1, ox = t % 3 - 1;
+                    const bool ok = (unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W;
+                    dl[u][t] = ok ? a.dlogit[pix - (long)oy * a.W - ox] : 0.f;
+                }
             }
         }
-        st8<T>((T*)a.dx + pix * a.lddx + c0, dxv);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = base + u * stride;
+            if (pix >= a.npix) break;
+            float v[8], dxv[8];
+            if constexpr (sizeof(T) == 2) unpack16<T>(xr[u], v);
+            else ld8<T>((const T*)a.x + pix * a.ldx + c0, v);            // fp32 validation mode: 8 channels = two chunks
+            if (j == 0) gb += dl[u][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dxv[i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float d = dl[u][t];
+                const f32x4_t w0 = *(const f32x4_t*)(swt + t * a.C + c0), w1 = *(const f32x4_t*)(swt + t * a.C + c0 + 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(d, v[i], gw[t][i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { dxv[i] = fmaf(d, w0[i], dxv[i]); dxv[4 + i] = fmaf(d, w1[i], dxv[4 + i]); }
+            }
+            st8<T>((T*)a.dx + pix * a.lddx + c0, dxv);
+        }
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -238,7 +253,9 @@ int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_o
     a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
     const int ppb = 256 / (C / 8);
     // few, long-running blocks: every block ends with C*9+1 same-address global atomics (contended adds are ~14x slower)
-    long g = (npix + ppb * 8 - 1) / (ppb * 8); if (g > 768) g = 768; if (g < 1) g = 1;
+    // (each block should stream >= ~4x more 16-byte chunks than it issues atomics: npix * C/8 / g >= 4 * 9C)
+    long g = npix / 288; if (g > 768) g = 768; if (g < 64) g = 64;
+    if (g > (npix + ppb - 1) / ppb) g = (npix + ppb - 1) / ppb;
     const size_t lds = sizeof(float) * (C * 18 + 4);
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(invdepth_bwd_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, a);

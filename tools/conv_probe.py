@@ -11,6 +11,9 @@ def main():
     K.use_patch_kernels(patch)
     if os.environ.get('MTE_IGEMM_DMA') is not None:
         K.lib.mte_debug_set(0, int(os.environ['MTE_IGEMM_DMA']))
+    for kv in filter(None, os.environ.get("MTE_DEBUG_KNOBS", "").split(",")):
+        kk, vv = kv.split("=")
+        K.lib.mte_debug_set(int(kk), int(vv))
     x = K.new_act(B, K.round8(cin), H, W); x.normal_()
     w = (torch.randn(cout, cin, k, k, device="cuda") * 0.05).requires_grad_(True)
     b = torch.zeros(cout, device="cuda", requires_grad=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # development aid: PMC counters for one conv shape.  usage: pmc_conv.sh B H W cin cout k
-mkdir -p gpurun_out
+mkdir -p gpurun_out; rm -rf gpurun_out/pmc1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
   --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc1 -- python3 $GRAFT_REPO_ROOT/tools/conv_probe.py "$@" 3 nopatch > $GRAFT_REPO_ROOT/gpurun_out/pmc1.txt 2>&1
@@ -17,7 +17,7 @@ for r in rows:
     agg[n][r['Counter_Name']]+=float(r['Counter_Value'])
     if r['Counter_Name']=='SQ_WAVE_CYCLES': cnt[n]+=1
 for n,c in agg.items():
-    if 'conv' not in n: continue
+    if 'conv' not in n or 'pack' in n: continue
     print(n, 'dispatches',cnt[n])
     for k,v in sorted(c.items()): print('    %-28s %.4g'%(k,v/max(cnt[n],1)))
 PY
