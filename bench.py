@@ -187,6 +187,8 @@ def main():
     for kv in filter(None, os.environ.get("MTE_DEBUG_KNOBS", "").split(",")):      # development A/B knobs, e.g. "2=8,3=4096"
         k, v = kv.split("=")
         K.lib.mte_debug_set(int(k), int(v))
+    if os.environ.get("MTE_NO_SIDE_STREAM"):
+        K.use_wgrad_side_stream(False)
     torch.manual_seed(42)                                # default_config.py:16 seed; xavier init per PackNetSAN01.init_weights
     net = PackNetSAN01(dropout=0.5, version="1A").to(dev)
     model = SemiSupEdgeModel(supervised_loss_weight=1.0, depth_edges_loss_weight=1.0, supervised_method="sparse-silog",

@@ -247,6 +247,77 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stat
     return (out, bool(done.value)) if gn_stats is not None else out
 
 
+# ---- weight-gradient side stream --------------------------------------------------------------------------------
+# dW of a layer depends only on (x, dy); the backward chain continues through dx.  When the gradient goes straight into
+# the flat gradient buffer (GradSink) nothing on the main stream consumes it before the optimizer, so the wgrad kernels
+# (+ their staging memset / OIHW unpack / bias column sums) are queued on a second HIP stream and fill the CUs that the
+# many short, latency-bound kernels of the main chain (GroupNorm passes, low-resolution layers) leave idle.  The main
+# stream re-joins at the end of the autograd pass (engine callback) and wherever gradients are consumed earlier
+# (bucketed all-reduce).
+_side = {"enabled": True, "stream": None, "keep": [], "keep_bytes": 0, "callback_queued": False, "dirty": False}
+_SIDE_KEEP_LIMIT = 24 << 30          # bytes of (x, dy) kept alive for the side stream before a forced join
+
+
+def use_wgrad_side_stream(flag):
+    _side["enabled"] = bool(flag)
+
+
+def join_side_stream():
+    """Make the current stream wait for every weight-gradient kernel queued on the side stream so far."""
+    if _side["dirty"]:
+        ev = torch.cuda.Event()
+        ev.record(_side["stream"])
+        torch.cuda.current_stream().wait_event(ev)
+        _side["dirty"] = False
+    _side["keep"].clear()
+    _side["keep_bytes"] = 0
+
+
+def _side_join_callback():
+    _side["callback_queued"] = False
+    join_side_stream()
+
+
+def _side_stream_for(*tensors):
+    """-> side stream (after making it wait for the work queued so far on the current stream), keeping `tensors` alive
+    until the next join (their memory must not be recycled by main-stream allocations while the side stream reads it)."""
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record()
+    _side["stream"].wait_event(ev)
+    _side["keep"].append(tensors)
+    _side["keep_bytes"] += sum(t.numel() * t.element_size() for t in tensors)
+    _side["dirty"] = True
+    if not _side["callback_queued"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_side_join_callback)
+            _side["callback_queued"] = True
+        except RuntimeError:          # not inside a backward pass: the caller joins explicitly
+            pass
+    return _side["stream"]
+
+
+def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
+    cout, cin, kh, kw = w.shape
+    B, Cp, H, W = x.shape
+    dyp, lddy = _pl(dy)
+    xp, ldx = _pl(x)
+    st = _stream()
+    dbias = None
+    stage = torch.empty((cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
+    if _patch_ok(W, Cp, cout, kh, kw, x.dtype):
+        lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, st)
+    else:
+        lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
+    dw = dw_out if dw_out is not None else torch.empty_like(w, dtype=torch.float32)
+    lib.mte_unpack_conv_wgrad(stage.data_ptr(), dw.data_ptr(), cout, cin, kh, kw, Cp, st)
+    if need_dbias:
+        dbias = dbias_out if dbias_out is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
+        lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
+    return dw, dbias
+
+
 def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None):
     """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations"""
     cout, cin, kh, kw = w.shape
@@ -256,16 +327,14 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
     st = _stream()
     dw = dbias = dx = None
     if need_dw:
-        stage = torch.empty((cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
-        if _patch_ok(W, Cp, cout, kh, kw, x.dtype):
-            lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, st)
+        sunk = dw_out is not None and (dbias_out is not None or not need_dbias) and _sink["active"] is not None
+        if sunk and _side["enabled"] and need_dx:
+            if _side["keep_bytes"] > _SIDE_KEEP_LIMIT:
+                join_side_stream()
+            with torch.cuda.stream(_side_stream_for(x, dy)):
+                dw, dbias = _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
         else:
-            lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
-        dw = dw_out if dw_out is not None else torch.empty_like(w, dtype=torch.float32)
-        lib.mte_unpack_conv_wgrad(stage.data_ptr(), dw.data_ptr(), cout, cin, kh, kw, Cp, st)
-        if need_dbias:
-            dbias = dbias_out if dbias_out is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
-            lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
+            dw, dbias = _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
     if need_dx and _patch_ok(W, cout, Cp, kh, kw, x.dtype):
         dx = new_act(B, Cp, H, W, x.dtype, x.device)
         dxp, lddx = _pl(dx)

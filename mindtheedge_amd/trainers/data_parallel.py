@@ -48,6 +48,9 @@ class FlatParameters:
             K.set_grad_sink(self.sink)
 
     def zero_grad(self):
+        if self.grad.is_cuda:
+            from .. import kernels as K
+            K.join_side_stream()
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):          # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
@@ -88,11 +91,17 @@ class BucketedAllReduce:
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b][2]:
             s, e, _ = self.buckets[b]
+            if self.flat.grad.is_cuda:
+                from .. import kernels as K
+                K.join_side_stream()                        # weight gradients of this bucket may still be on the side stream
             self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Wait for every launched collective; reduce buckets whose hooks never completed (unused parameters).
         Returns the factor that turns the summed gradient into the average (1/world)."""
+        if self.flat.grad.is_cuda:
+            from .. import kernels as K
+            K.join_side_stream()
         if self.world > 1:
             for b, (s, e, n) in enumerate(self.buckets):
                 if self._ready[b] != n:
@@ -122,6 +131,8 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         from .. import kernels as K
+        if self.flatp.grad.is_cuda:
+            K.join_side_stream()
         gscale = self.reducer.finish() if self.reducer is not None else 1.0
         g = self.param_groups[0]
         self.steps += 1
