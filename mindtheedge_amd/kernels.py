@@ -473,6 +473,7 @@ class Pack3dFn(torch.autograd.Function):
         w3c, b3c = w3.detach().contiguous().float(), b3.detach().contiguous().float()
         lib.mte_pack3d_fwd(xp, ldx, w3c.data_ptr(), b3c.data_ptr(), op, ldo, B, H, W, C, _dt(x), _stream())
         ctx.save_for_backward(x, w3c)
+        ctx.params = (w3, b3)
         return out
 
     @staticmethod
@@ -481,16 +482,13 @@ class Pack3dFn(torch.autograd.Function):
         B, C, H, W = x.shape
         dout = as_act(dout, x.dtype)
         dop, ldo = _pl(dout)
-        xp, ldx = _pl(x)
-        st = _stream()
-        dwb = torch.empty((112,), dtype=torch.float32, device=x.device)
-        lib.mte_pack3d_bwd_weight(xp, ldx, dop, ldo, dwb.data_ptr(), B, H, W, C, _dt(x), st)
+        dw3, db3 = _conv3d_weight_grads(lib.mte_pack3d_bwd_weight, x, dout, *ctx.params)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(B, C, H, W, x.dtype, x.device)
             dxp, lddx = _pl(dx)
-            lib.mte_pack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), st)
-        return dx, dwb[:108].view(4, 1, 3, 3, 3), dwb[108:112]
+            lib.mte_pack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), _stream())
+        return dx, dw3, db3
 
 
 class Unpack3dFn(torch.autograd.Function):
@@ -505,6 +503,7 @@ class Unpack3dFn(torch.autograd.Function):
         w3c, b3c = w3.detach().contiguous().float(), b3.detach().contiguous().float()
         lib.mte_unpack3d_fwd(xp, ldx, w3c.data_ptr(), b3c.data_ptr(), op, ldo, B, H, W, C, _dt(x), _stream())
         ctx.save_for_backward(x, w3c)
+        ctx.params = (w3, b3)
         return out
 
     @staticmethod
@@ -513,14 +512,11 @@ class Unpack3dFn(torch.autograd.Function):
         B, C, H, W = x.shape
         dout = as_act(dout, x.dtype)
         dop, ldo = _pl(dout)
-        xp, ldx = _pl(x)
-        st = _stream()
-        dwb = torch.empty((112,), dtype=torch.float32, device=x.device)
-        lib.mte_unpack3d_bwd_weight(xp, ldx, dop, ldo, dwb.data_ptr(), B, H, W, C, _dt(x), st)
+        dw3, db3 = _conv3d_weight_grads(lib.mte_unpack3d_bwd_weight, x, dout, *ctx.params)
         dx = new_act(B, C, H, W, x.dtype, x.device)
         dxp, lddx = _pl(dx)
-        lib.mte_unpack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), st)
-        return dx, dwb[:108].view(4, 1, 3, 3, 3), dwb[108:112]
+        lib.mte_unpack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), _stream())
+        return dx, dw3, db3
 
 
 def _rect(src, sy, sx, dst, dy, dx, h, w, mode=0):
@@ -544,6 +540,28 @@ def _deliver(p, t):
             sk.ready(p)
             return None
     return t
+
+
+def _all_sunk(*params):
+    sk = _sink["active"]
+    return sk is not None and all(sk.lookup(p) is not None for p in params)
+
+
+def _conv3d_weight_grads(kernel, x, dout, w3, b3):
+    """(dW3, db3) of a Conv3d(1->4) pack/unpack op; queued on the weight-gradient side stream when both land in the sink."""
+    B, C, H, W = x.shape
+
+    def run():
+        dop, ldo = _pl(dout)
+        xp, ldx = _pl(x)
+        dwb = torch.empty((112,), dtype=torch.float32, device=x.device)
+        kernel(xp, ldx, dop, ldo, dwb.data_ptr(), B, H, W, C, _dt(x), _stream())
+        return _deliver(w3, dwb[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dwb[108:112])
+
+    if _side["enabled"] and _all_sunk(w3, b3):
+        with torch.cuda.stream(_side_stream_for(x, dout)):
+            return run()
+    return run()
 
 
 def pack_fold_applicable(H2, W2, k):
@@ -622,32 +640,49 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         dyb2 = torch.zeros((2 * B, H2, hb, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
         _rect(dy, pad, 0, dyb2[:B], pad, 0, H2 - 2 * pad, pad)
         _rect(dy, pad, W2 - pad, dyb2[B:], pad, hb - pad, H2 - 2 * pad, pad)
-        dw_band = db_band = None
-        dk3b = torch.zeros((112,), dtype=torch.float32, device=dev)
-        dxb = []
+        dTs, dxb = [], []
         for xb, T, dyb in ((xb1, T1, dyb1), (xb2, T2, dyb2)):
-            dT, dwi, dbi = conv_backward(T, dyb, w, pack_unf, True)
-            dw_band = dwi if dw_band is None else dw_band.add_(dwi)
-            db_band = dbi if db_band is None else db_band.add_(dbi)
+            dT, _, _ = conv_backward(T, dyb, w, pack_unf, True, need_dw=False)
             Bb, _, hx, wx = xb.shape
-            tmp = torch.empty((112,), dtype=torch.float32, device=dev)
-            sp, lds_ = _pl(xb)
             tp, ldt = _pl(dT)
-            lib.mte_pack3d_bwd_weight(sp, lds_, tp, ldt, tmp.data_ptr(), Bb, hx, wx, C, dt, st)
-            dk3b.add_(tmp)
             dxi = new_act(Bb, C, hx, wx, P.dtype, dev)
             dp_, ldd = _pl(dxi)
             lib.mte_pack3d_bwd_data(tp, ldt, w3c.data_ptr(), dp_, ldd, Bb, hx, wx, C, dt, st)
+            dTs.append(dT)
             dxb.append(dxi)
         # ---- interior path (folded): band pixels carry no gradient here
         _rect(None, 0, 0, dy, 0, 0, pad, W2, mode=2)
         _rect(None, 0, 0, dy, H2 - pad, 0, pad, W2, mode=2)
         _rect(None, 0, 0, dy, pad, 0, H2 - 2 * pad, pad, mode=2)
         _rect(None, 0, 0, dy, pad, W2 - pad, H2 - 2 * pad, pad, mode=2)
-        dP, dWf, dbf = conv_backward(P, dy, Wf, pack_fold, True)
-        lib.mte_unfold_pack_wgrad(dWf.data_ptr(), dbf.data_ptr(), w.detach().data_ptr(), w3c.data_ptr(), b3c.data_ptr(),
-                                  dw_band.data_ptr(), dk3b.data_ptr(), co, 4 * C, k, 1, st)
-        db = dbf.add_(db_band)
+
+        def weight_grads():
+            """every parameter gradient of the layer except gamma/beta; nothing on the data-gradient chain needs them"""
+            sw = _stream()
+            dw_band = db_band = None
+            dk3b = torch.zeros((112,), dtype=torch.float32, device=dev)
+            for xb, T, dyb, dT in ((xb1, T1, dyb1, dTs[0]), (xb2, T2, dyb2, dTs[1])):
+                dwi, dbi = _conv_wgrad(T, dyb, w, True, None, None)
+                dw_band = dwi if dw_band is None else dw_band.add_(dwi)
+                db_band = dbi if db_band is None else db_band.add_(dbi)
+                Bb, _, hx, wx = xb.shape
+                tmp = torch.empty((112,), dtype=torch.float32, device=dev)
+                sp, lds_ = _pl(xb)
+                tp, ldt = _pl(dT)
+                lib.mte_pack3d_bwd_weight(sp, lds_, tp, ldt, tmp.data_ptr(), Bb, hx, wx, C, dt, sw)
+                dk3b.add_(tmp)
+            dWf, dbf = _conv_wgrad(P, dy, Wf, True, None, None)
+            lib.mte_unfold_pack_wgrad(dWf.data_ptr(), dbf.data_ptr(), w.detach().data_ptr(), w3c.data_ptr(), b3c.data_ptr(),
+                                      dw_band.data_ptr(), dk3b.data_ptr(), co, 4 * C, k, 1, sw)
+            db = dbf.add_(db_band)
+            return (_deliver(w3, dk3b[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dk3b[108:112]), _deliver(w, dw_band), _deliver(b, db))
+
+        if _side["enabled"] and _all_sunk(w3, b3, w, b):
+            with torch.cuda.stream(_side_stream_for(P, dy, T1, T2, dyb1, dyb2, dTs[0], dTs[1], xb1, xb2, Wf)):
+                g3, gb3, gw, gb = weight_grads()
+        else:
+            g3, gb3, gw, gb = weight_grads()
+        dP, _, _ = conv_backward(P, dy, Wf, pack_fold, True, need_dw=False)
         dx = new_act(B, C, H, W, P.dtype, dev)
         sp, lds_ = _pl(dP)
         dp_, ldd = _pl(dx)
@@ -656,8 +691,7 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         _rect(dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, mode=1)
         _rect(dxb[1][:B], 0, 0, dx, 0, 0, H, 2 * hb, mode=1)
         _rect(dxb[1][B:], 0, 0, dx, 0, W - 2 * hb, H, 2 * hb, mode=1)
-        return (dx, _deliver(w3, dk3b[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dk3b[108:112]), _deliver(w, dw_band), _deliver(b, db),
-                _deliver(gamma, dgamma), _deliver(beta, dbeta), None, None)
+        return (dx, g3, gb3, gw, gb, _deliver(gamma, dgamma), _deliver(beta, dbeta), None, None)
 
 
 class InvDepthFn(torch.autograd.Function):
