@@ -236,6 +236,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    host_dt = time.perf_counter() - t0                   # time the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0
     # Per-kernel HIP-event timing runs on `ksteps` further steps of the same workload, outside the clocked region:
@@ -267,7 +268,8 @@ def main():
                                        "I%d: PackNet-SAN depth inference" % B) + ", %dx%d, %d frames/GPU, dropout 0.5, flip 0.5" % (H, W, B),
                           "global_batch": B * world, "height": H, "width": W,
                           "parallelism": "dp%d (bucketed RCCL all-reduce overlapped with backward)" % world if world > 1 else "single GPU"},
-               "final_loss" if args.mode == "train" else "mean_inv_depth": final}
+               "final_loss" if args.mode == "train" else "mean_inv_depth": final,
+               "host_enqueue_ms_per_step": host_dt / args.steps * 1e3}
         passes = 3.0 if args.mode == "train" else 1.0
         step_flops = conv_flops_per_image(H, W) * B * passes
         res["mfma_fraction_of_step"] = step_flops / (ms * 1e-3) / (BF16_DENSE_PEAK_TFLOPS * 1e12)

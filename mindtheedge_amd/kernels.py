@@ -112,6 +112,17 @@ def new_act(B, C, H, W, dtype=None, device="cuda"):
     return torch.empty((B, H, W, C), dtype=dtype or compute_dtype(), device=device).permute(0, 3, 1, 2)
 
 
+def alias_of(t):
+    """A fresh tensor object over the same memory (not an autograd view of `t`): lets an op write its result into a
+    caller-chosen place (a channel slice of a decoder concat buffer) and still return a tensor it owns."""
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.size(), t.stride())
+
+
+def channel_slice(buf, c0, c1):
+    """Channel block [c0, c1) of an NHWC activation as an independent tensor object (see alias_of)."""
+    return alias_of(buf[:, c0:c1])
+
+
 def is_act(t):
     if t.dim() != 4 or t.dtype not in (torch.bfloat16, torch.float32):
         return False
@@ -358,6 +369,8 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, stats=None):
         stats = torch.empty((B, 16, 2), dtype=torch.float64, device=y1.device)
         lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
+    if tuple(z.shape) != (B, C, H, W) or z.dtype != y1.dtype:
+        raise MteError("output destination has shape %s / %s, expected %s / %s" % (tuple(z.shape), z.dtype, (B, C, H, W), y1.dtype))
     zp, lz = _pl(z)
     lib.mte_gn_elu_fwd(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), zp, lz,
                        B, H * W, C, eps, _dt(y1), st)
@@ -393,12 +406,13 @@ class ConvGnEluFn(torch.autograd.Function):
     """ELU(GroupNorm16(conv_k(zero_pad(x)) + b))  -- reference Conv2D.forward, layers01.py:35-38."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, pack):
+    def forward(ctx, x, w, b, gamma, beta, pack, out=None):
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
         stats = torch.empty((x.shape[0], 16, 2), dtype=torch.float64, device=x.device)
         y, fused = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w, gn_stats=stats)
-        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, stats=stats if fused else None)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, stats=stats if fused else None,
+                               out=None if out is None else alias_of(out))
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
         ctx.bias = b
@@ -415,7 +429,7 @@ class ConvGnEluFn(torch.autograd.Function):
         dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
                                                 dgamma=gg, dbeta=gb, dbias=gbias)
         dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw)
-        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None
+        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None, None
 
 
 class ConvFn(torch.autograd.Function):
@@ -495,9 +509,11 @@ class Unpack3dFn(torch.autograd.Function):
     """Conv3d(1->4) + view + PixelShuffle(2)  (UnpackLayerConv3d.forward after its Conv2D, layers01.py:281-286)."""
 
     @staticmethod
-    def forward(ctx, x, w3, b3):
+    def forward(ctx, x, w3, b3, out=None):
         B, C, H, W = x.shape
-        out = new_act(B, C, 2 * H, 2 * W, x.dtype, x.device)
+        out = alias_of(out) if out is not None else new_act(B, C, 2 * H, 2 * W, x.dtype, x.device)
+        if tuple(out.shape) != (B, C, 2 * H, 2 * W) or out.dtype != x.dtype:
+            raise MteError("unpack destination has shape %s, expected %s" % (tuple(out.shape), (B, C, 2 * H, 2 * W)))
         xp, ldx = _pl(x)
         op, ldo = _pl(out)
         w3c, b3c = w3.detach().contiguous().float(), b3.detach().contiguous().float()
@@ -516,7 +532,7 @@ class Unpack3dFn(torch.autograd.Function):
         dx = new_act(B, C, H, W, x.dtype, x.device)
         dxp, lddx = _pl(dx)
         lib.mte_unpack3d_bwd_data(dop, ldo, w3c.data_ptr(), dxp, lddx, B, H, W, C, _dt(x), _stream())
-        return dx, dw3, db3
+        return dx, dw3, db3, None
 
 
 def _rect(src, sy, sx, dst, dy, dx, h, w, mode=0):
@@ -577,7 +593,7 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
     with the unfolded kernels on four thin bands and pasted over the folded result; backward mirrors it."""
 
     @staticmethod
-    def forward(ctx, x, w3, b3, w, b, gamma, beta, pack_unf, pack_fold):
+    def forward(ctx, x, w3, b3, w, b, gamma, beta, pack_unf, pack_fold, out=None):
         B, C, H, W = x.shape
         H2, W2 = H // 2, W // 2
         co, _, k, _ = w.shape
@@ -617,7 +633,7 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         _rect(yb1[B:], hb - pad, 0, y, H2 - pad, 0, pad, W2)
         _rect(yb2[:B], pad, 0, y, pad, 0, H2 - 2 * pad, pad)
         _rect(yb2[B:], pad, hb - pad, y, pad, W2 - pad, H2 - 2 * pad, pad)
-        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out))
         ctx.save_for_backward(P, xb1, xb2, Tb[0], Tb[1], y, stats, w, w3c, b3c, gamma, beta, Wf)
         ctx.params = (w3, b3, b)
         ctx.packs = (pack_unf, pack_fold)
@@ -691,7 +707,7 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         _rect(dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, mode=1)
         _rect(dxb[1][:B], 0, 0, dx, 0, 0, H, 2 * hb, mode=1)
         _rect(dxb[1][B:], 0, 0, dx, 0, W - 2 * hb, H, 2 * hb, mode=1)
-        return (dx, g3, gb3, gw, gb, _deliver(gamma, dgamma), _deliver(beta, dbeta), None, None)
+        return (dx, g3, gb3, gw, gb, _deliver(gamma, dgamma), _deliver(beta, dbeta), None, None, None)
 
 
 class InvDepthFn(torch.autograd.Function):
@@ -728,21 +744,30 @@ class ConcatFn(torch.autograd.Function):
     multiple of 8 (decoder version 'A', PackNetSAN01.py:105-143).  Backward hands out channel-slice views."""
 
     @staticmethod
-    def forward(ctx, inv, *parts):
+    def forward(ctx, inv, buf, *parts):
+        """`buf` (optional): pre-allocated concat buffer (new_concat_buffer); parts that already live in their channel
+        block of it (producers were given channel_slice(buf, ..) as destination) are not copied."""
         B, _, H, W = parts[0].shape
         dtype = parts[0].dtype
         chans = [p.shape[1] for p in parts]
         ctot = sum(chans) + (8 if inv is not None else 0)
-        buf = new_act(B, ctot, H, W, dtype, parts[0].device)
+        if buf is None:
+            buf = new_act(B, ctot, H, W, dtype, parts[0].device)
+        else:
+            if tuple(buf.shape) != (B, ctot, H, W) or buf.dtype != dtype:
+                raise MteError("concat buffer has shape %s, expected %s" % (tuple(buf.shape), (B, ctot, H, W)))
+            buf = alias_of(buf)
         st = _stream()
         off = 0
         for p, c in zip(parts, chans):
+            dst = buf[:, off:off + c]
+            off += c
+            if p.dtype == dtype and p.data_ptr() == dst.data_ptr() and p.stride() == dst.stride():
+                continue                                     # produced in place
             p = as_act(p, dtype)
             sp, lds_ = _pl(p)
-            dst = buf[:, off:off + c]
             dp, ldd = _pl(dst)
             lib.mte_copy_channels(sp, lds_, dp, ldd, B * H * W, c, _dt(p), st)
-            off += c
         if inv is not None:
             dst = buf[:, off:off + 8]
             dp, ldd = _pl(dst)
@@ -766,7 +791,12 @@ class ConcatFn(torch.autograd.Function):
             src = dbuf[:, off:off + 8]
             sp, lds_ = _pl(src)
             lib.mte_upsample_inv_bwd(sp, lds_, dinv.data_ptr(), B, H // 2, W // 2, 0, _dt(dbuf), _stream())
-        return (dinv,) + tuple(outs)
+        return (dinv, None) + tuple(outs)
+
+
+def new_concat_buffer(B, chans, with_inv, H, W, dtype=None, device="cuda"):
+    """Decoder concat buffer for ConcatFn: channel blocks `chans` (+ one 8-channel block for an up-sampled inv-depth map)."""
+    return new_act(B, sum(chans) + (8 if with_inv else 0), H, W, dtype or compute_dtype(), device)
 
 
 def image_to_act(rgb, flip=False, dtype=None):

@@ -8,6 +8,8 @@ packnet_sfm/networks/depth/PackNetSAN01.py: same constructor signature, module t
 The sparse LiDAR (SAN / MinkowskiEngine) branch is outside this build's scope: passing
 ``input_depth`` raises NotImplementedError instead of silently ignoring it.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -33,12 +35,15 @@ class PackNetSlimEnc01(nn.Module):
         self.conv4 = ResidualBlock(n3, n4, num_blocks[2], 1, dropout=dropout)
         self.conv5 = ResidualBlock(n4, n5, num_blocks[3], 1, dropout=dropout)
 
-    def forward(self, rgb):
-        x = self.pre_calc(rgb)
-        x1p = self.pack1(self.conv1(x))
-        x2p = self.pack2(self.conv2(x1p))
-        x3p = self.pack3(self.conv3(x2p))
-        x4p = self.pack4(self.conv4(x3p))
+    def forward(self, rgb, skip_out=None):
+        """`skip_out`: optional destinations for the five skip tensors (channel blocks of the decoder's concat buffers,
+        see Decoder.concat_buffers) so that torch.cat never has to copy them."""
+        so = skip_out or [None] * 5
+        x = self.pre_calc(rgb, out=so[0])
+        x1p = self.pack1(self.conv1(x), out=so[1])
+        x2p = self.pack2(self.conv2(x1p), out=so[2])
+        x3p = self.pack3(self.conv3(x2p), out=so[3])
+        x4p = self.pack4(self.conv4(x3p), out=so[4])
         x5p = self.pack5(self.conv5(x4p))
         return x5p, [x, x1p, x2p, x3p, x4p]
 
@@ -64,16 +69,35 @@ class Decoder(nn.Module):
         self.disp2_layer = InvDepth(n2, out_channels=out_channels)
         self.disp1_layer = InvDepth(n1, out_channels=out_channels)
 
-    def forward(self, x5p, skips):
+    def concat_buffers(self, B, H, W, device):
+        """The five torch.cat((unpack, skip[, up(inv_depth)]), 1) results of reference :118-143, allocated up front so the
+        unpack layers and the encoder write their outputs straight into them.  -> (buffers level 1..5, skip destinations)"""
+        bufs, skip_dst = [], []
+        for lvl, (unp, ico) in enumerate(((self.unpack1, self.iconv1), (self.unpack2, self.iconv2), (self.unpack3, self.iconv3),
+                                          (self.unpack4, self.iconv4), (self.unpack5, self.iconv5))):
+            cu = unp.conv.conv_base.out_channels                       # unpack output channels (out * r^2 / d == out)
+            with_inv = lvl < 3
+            cs = ico.conv_base.in_channels - cu - (1 if with_inv else 0)
+            buf = K.new_concat_buffer(B, [cu, cs], with_inv, H >> lvl, W >> lvl, device=device)
+            bufs.append(buf)
+            skip_dst.append(K.channel_slice(buf, cu, cu + cs))
+        return bufs, skip_dst
+
+    def forward(self, x5p, skips, bufs=None):
         skip1, skip2, skip3, skip4, skip5 = skips
-        iconv5 = self.iconv5(K.ConcatFn.apply(None, self.unpack5(x5p), skip5))
-        iconv4 = self.iconv4(K.ConcatFn.apply(None, self.unpack4(iconv5), skip4))
+        b1, b2, b3, b4, b5 = bufs or [None] * 5
+
+        def up_dst(buf, unp):
+            return None if buf is None else K.channel_slice(buf, 0, unp.conv.conv_base.out_channels)
+
+        iconv5 = self.iconv5(K.ConcatFn.apply(None, b5, self.unpack5(x5p, out=up_dst(b5, self.unpack5)), skip5))
+        iconv4 = self.iconv4(K.ConcatFn.apply(None, b4, self.unpack4(iconv5, out=up_dst(b4, self.unpack4)), skip4))
         inv_depth4 = self.disp4_layer(iconv4)
-        iconv3 = self.iconv3(K.ConcatFn.apply(inv_depth4, self.unpack3(iconv4), skip3))
+        iconv3 = self.iconv3(K.ConcatFn.apply(inv_depth4, b3, self.unpack3(iconv4, out=up_dst(b3, self.unpack3)), skip3))
         inv_depth3 = self.disp3_layer(iconv3)
-        iconv2 = self.iconv2(K.ConcatFn.apply(inv_depth3, self.unpack2(iconv3), skip2))
+        iconv2 = self.iconv2(K.ConcatFn.apply(inv_depth3, b2, self.unpack2(iconv3, out=up_dst(b2, self.unpack2)), skip2))
         inv_depth2 = self.disp2_layer(iconv2)
-        iconv1 = self.iconv1(K.ConcatFn.apply(inv_depth2, self.unpack1(iconv2), skip1))
+        iconv1 = self.iconv1(K.ConcatFn.apply(inv_depth2, b1, self.unpack1(iconv2, out=up_dst(b1, self.unpack1)), skip1))
         inv_depth1 = self.disp1_layer(iconv1)
         return [inv_depth1, inv_depth2, inv_depth3, inv_depth4]
 
@@ -124,8 +148,11 @@ class PackNetSAN01(nn.Module):
     def run_network(self, rgb, input_depth=None):
         if input_depth is not None:
             raise NotImplementedError("the sparse LiDAR (SAN) branch is out of scope of this build (SURVEY.md 8(f-1))")
-        x5p, skips = self.encoder(rgb)
-        return [self.decoder(x5p, skips), skips + [x5p]]
+        bufs = skip_dst = None
+        if rgb.is_cuda and rgb.shape[2] % 32 == 0 and rgb.shape[3] % 32 == 0 and not os.environ.get("MTE_NO_CONCAT_PLACEMENT"):
+            bufs, skip_dst = self.decoder.concat_buffers(rgb.shape[0], rgb.shape[2], rgb.shape[3], rgb.device)
+        x5p, skips = self.encoder(rgb, skip_out=skip_dst)
+        return [self.decoder(x5p, skips, bufs), skips + [x5p]]
 
     def forward(self, rgb, input_depth=None, rgb_edge=None, output_features=False, **kwargs):
         if self.in_channels == 4:

@@ -75,10 +75,11 @@ class Conv2D(nn.Module):
         self.conv_base = _ConvParams(in_channels, out_channels, kernel_size)
         self.normalize = _GroupNormParams(out_channels)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """`out`: optional destination (e.g. K.channel_slice of a decoder concat buffer) for the result"""
         x = _enter(x, self.conv_base.in_channels)
         return K.ConvGnEluFn.apply(x, self.conv_base.weight, self.conv_base.bias, self.normalize.weight, self.normalize.bias,
-                                   self.conv_base.pack)
+                                   self.conv_base.pack, out)
 
 
 class ResidualConv(nn.Module):
@@ -150,14 +151,14 @@ class PackLayerConv3d(nn.Module):
         self.conv3d = _Conv3dParams(d)
         self.fold_pack = K.WeightPack()       # packs of the conv3d-folded (k+2)x(k+2) weights
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = _enter(x, self.in_channels)
         k = self.conv.kernel_size
         if K.pack_folding_enabled() and self.in_channels % 8 == 0 and K.pack_fold_applicable(x.shape[2] // 2, x.shape[3] // 2, k):
             cb, gn = self.conv.conv_base, self.conv.normalize
             return K.PackFoldedConvGnEluFn.apply(x, self.conv3d.weight, self.conv3d.bias, cb.weight, cb.bias, gn.weight, gn.bias,
-                                                 cb.pack, self.fold_pack)
-        return self.conv(K.Pack3dFn.apply(x, self.conv3d.weight, self.conv3d.bias))
+                                                 cb.pack, self.fold_pack, out)
+        return self.conv(K.Pack3dFn.apply(x, self.conv3d.weight, self.conv3d.bias), out=out)
 
 
 class UnpackLayerConv3d(nn.Module):
@@ -170,5 +171,5 @@ class UnpackLayerConv3d(nn.Module):
         self.conv = Conv2D(in_channels, out_channels * (r ** 2) // d, kernel_size, 1)
         self.conv3d = _Conv3dParams(d)
 
-    def forward(self, x):
-        return K.Unpack3dFn.apply(self.conv(x), self.conv3d.weight, self.conv3d.bias)
+    def forward(self, x, out=None):
+        return K.Unpack3dFn.apply(self.conv(x), self.conv3d.weight, self.conv3d.bias, out)

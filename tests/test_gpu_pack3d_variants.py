@@ -46,7 +46,7 @@ def _run_unpack(C, B, H, W, lds):
         x = K.image_to_act((torch.rand(B, C, H, W, generator=g) * 2 - 1).cuda()).detach().requires_grad_(True)
         w3 = ((torch.rand(4, 1, 3, 3, 3, generator=g) - 0.5) * 0.8).cuda().requires_grad_(True)
         b3 = ((torch.rand(4, generator=g) - 0.5) * 0.4).cuda().requires_grad_(True)
-        y = K.Unpack3dFn.apply(x, w3, b3)
+        y = K.Unpack3dFn.apply(x, w3, b3, None)
         G = (torch.rand(y.shape, generator=g) * 2 - 1).cuda()
         (y.float() * G).sum().backward()
         torch.cuda.synchronize()

@@ -16,3 +16,29 @@ tot = sum(v[1] for v in agg.values())
 print("total kernel time / step: %.2f ms" % (tot / steps * 1e-3))
 for (name, grid, lds), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 70]:
     print("%8.1f us/step %6.1f calls/step %9.1f us/call  grid=%-9s lds=%-6s %s" % (us / steps, n / steps, us / n, grid, lds, name))
+
+# ---- GPU occupancy over time: union of kernel intervals vs wall span (idle = launch gaps / host-bound phases)
+iv = []
+with open(path) as f:
+    for r in csv.DictReader(f):
+        iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+iv.sort()
+# drop the warm-up/initialisation part: keep the last 60 % of kernels
+iv = iv[int(len(iv) * 0.4):]
+busy, cur_s, cur_e, gaps = 0, iv[0][0], iv[0][1], []
+for s_, e_ in iv[1:]:
+    if s_ > cur_e:
+        busy += cur_e - cur_s
+        gaps.append(s_ - cur_e)
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+busy += cur_e - cur_s
+span = cur_e - iv[0][0]
+print("steady-state window: span %.2f ms, busy %.2f ms (%.1f %%), idle %.2f ms in %d gaps" % (span * 1e-6, busy * 1e-6, 100.0 * busy / span, (span - busy) * 1e-6, len(gaps)))
+gaps.sort(reverse=True)
+print("largest gaps (us):", [round(g * 1e-3, 1) for g in gaps[:12]])
+import bisect
+for lim in (2, 5, 10, 20, 50):
+    sel = [g for g in gaps if g * 1e-3 <= lim]
+    print("  gaps <= %3d us: %6d, total %.2f ms" % (lim, len(sel), sum(sel) * 1e-6))
