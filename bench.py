@@ -91,6 +91,20 @@ class ConvTimer:
         return out
 
 
+def pmc_traffic_per_launch(args, B, H, W):
+    """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in
+    separate runs by tools/pmc_traffic.sh as MI355X_MICROARCH.md prescribes; bench.py cannot read PMCs itself).  Only
+    reported for the workload the passes were taken on."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    if (d.get("mode"), d.get("batch"), d.get("height"), d.get("width"), d.get("dtype")) != (args.mode, B, H, W, args.dtype):
+        return None
+    return d["conv_family_bytes_per_launch"]
+
+
 def conv_flops_per_image(H, W):
     """Algorithmic conv FLOPs per image forward (285.27 GMAC at 384x1280, scales with pixels)."""
     return 2.0 * 285.27e9 * (H * W) / (384.0 * 1280.0)
@@ -244,12 +258,16 @@ def main():
     # would distort `value`; the kernel durations themselves are unaffected by the gaps.
     ksteps = 0
     if timer:
+        # the weight-gradient side stream is switched off for these steps: with kernels of two streams sharing the CUs an
+        # event pair measures contention, not the kernel
         timer.enabled = True
+        K.use_wgrad_side_stream(False)
         ksteps = min(args.steps, 3)
         for _ in range(ksteps):
             step()
         sync()
         timer.enabled = False
+        K.use_wgrad_side_stream(not os.environ.get("MTE_NO_SIDE_STREAM"))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -259,8 +277,8 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
-        res = {"metric": "training images/sec, PackNet-SAN+edge-loss 384x1280 bf16" if args.mode == "train"
-               else "inference images/sec, PackNet-SAN 384x1280 bf16",
+        res = {"metric": ("training images/sec, PackNet-SAN+edge-loss %dx%d %s" if args.mode == "train"
+                          else "inference images/sec, PackNet-SAN %dx%d %s") % (H, W, args.dtype),
                "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic (SURVEY.md 8(d): rgb U[0,1), 5% sparse depth, soft thin edges, uniform normals; xavier init seed 42)",
@@ -287,8 +305,10 @@ def main():
                 peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
                 alg = conv2d_flops_per_image(H, W) * B * passes * ksteps          # algorithmic conv2d FLOPs of the timed launches
                 ach = alg / tot_t / 1e12
-                res["roofline"] = {"bound": "mfma", "kernel": "conv2d implicit-GEMM family (mte_conv2d_igemm fwd+dgrad, mte_conv2d_wgrad)",
-                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                res["roofline"] = {"bound": "mfma", "kernel": "conv2d MFMA family (mte_conv2d_igemm fwd+dgrad, mte_conv2d_wgrad, "
+                                                              "mte_conv2d_patch_fwd, mte_conv2d_patch_wgrad)",
+                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                   "traffic": pmc_traffic_per_launch(args, B, H, W),
                                    "launches_per_step": n / ksteps, "avg_launch_ms": tot_t / n * 1e3,
                                    "conv_ms_per_step": tot_t / ksteps * 1e3, "timed_steps": ksteps,
                                    "algorithmic_flops_per_step": alg / ksteps, "executed_flops_per_step": tot_f / ksteps,

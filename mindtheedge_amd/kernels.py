@@ -8,6 +8,7 @@ path -- a missing library or an unsupported shape raises.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -265,7 +266,8 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stat
 # many short, latency-bound kernels of the main chain (GroupNorm passes, low-resolution layers) leave idle.  The main
 # stream re-joins at the end of the autograd pass (engine callback) and wherever gradients are consumed earlier
 # (bucketed all-reduce).
-_side = {"enabled": True, "stream": None, "keep": [], "keep_bytes": 0, "callback_queued": False, "dirty": False}
+_side = {"enabled": True, "streams": [], "next": 0, "keep": [], "keep_bytes": 0, "callback_queued": False, "dirty": False}
+_SIDE_STREAMS = int(os.environ.get("MTE_SIDE_STREAMS", "1"))
 _SIDE_KEEP_LIMIT = 24 << 30          # bytes of (x, dy) kept alive for the side stream before a forced join
 
 
@@ -276,9 +278,10 @@ def use_wgrad_side_stream(flag):
 def join_side_stream():
     """Make the current stream wait for every weight-gradient kernel queued on the side stream so far."""
     if _side["dirty"]:
-        ev = torch.cuda.Event()
-        ev.record(_side["stream"])
-        torch.cuda.current_stream().wait_event(ev)
+        for st in _side["streams"]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            torch.cuda.current_stream().wait_event(ev)
         _side["dirty"] = False
     _side["keep"].clear()
     _side["keep_bytes"] = 0
@@ -292,11 +295,13 @@ def _side_join_callback():
 def _side_stream_for(*tensors):
     """-> side stream (after making it wait for the work queued so far on the current stream), keeping `tensors` alive
     until the next join (their memory must not be recycled by main-stream allocations while the side stream reads it)."""
-    if _side["stream"] is None:
-        _side["stream"] = torch.cuda.Stream()
+    if not _side["streams"]:
+        _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
+    side = _side["streams"][_side["next"] % len(_side["streams"])]
+    _side["next"] += 1
     ev = torch.cuda.Event()
     ev.record()
-    _side["stream"].wait_event(ev)
+    side.wait_event(ev)
     _side["keep"].append(tensors)
     _side["keep_bytes"] += sum(t.numel() * t.element_size() for t in tensors)
     _side["dirty"] = True
@@ -306,7 +311,7 @@ def _side_stream_for(*tensors):
             _side["callback_queued"] = True
         except RuntimeError:          # not inside a backward pass: the caller joins explicitly
             pass
-    return _side["stream"]
+    return side
 
 
 def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):

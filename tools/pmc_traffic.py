@@ -1,0 +1,43 @@
+"""Summarise rocprofv3 FETCH_SIZE / WRITE_SIZE counter_collection.csv files per kernel family.
+usage: pmc_traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <steps in each run>"""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    for key, fam in (("conv_igemm", "conv igemm (fwd+dgrad)"), ("splitk_finish", "conv igemm (fwd+dgrad)"), ("conv_wgrad", "conv wgrad generic"),
+                     ("conv_patch_fwd", "conv patch fwd+dgrad"), ("conv_patch_wgrad", "conv patch wgrad"), ("gn_", "GroupNorm+ELU"),
+                     ("pack3d", "conv3d pack/unpack"), ("unpack3d", "conv3d pack/unpack"), ("invdepth", "invdepth head"),
+                     ("adam", "adam"), ("fillBuffer", "memset"), ("copyBuffer", "memcpy")):
+        if key in n:
+            return fam
+    return "other"
+
+
+def load(d, counter):
+    out = defaultdict(lambda: [0, 0.0])
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            e = out[family(r["Kernel_Name"])]
+            e[0] += 1
+            e[1] += float(r["Counter_Value"])
+    return out
+
+
+F, W, steps = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), float(sys.argv[3])
+print("# per training step (T8: 8 x 384x1280), counters in KiB as rocprofv3 reports them; read = 2 x FETCH_SIZE (gfx950 correction)")
+print("%-28s %10s %12s %12s %12s" % ("family", "launches", "read MB", "write MB", "total MB"))
+tot_r = tot_w = 0.0
+for fam in sorted(set(F) | set(W), key=lambda k: -(2 * F[k][1] + W[k][1])):
+    r = 2.0 * F[fam][1] * 1024 / steps / 1e6
+    w = W[fam][1] * 1024 / steps / 1e6
+    tot_r += r
+    tot_w += w
+    print("%-28s %10.1f %12.1f %12.1f %12.1f" % (fam, max(F[fam][0], W[fam][0]) / steps, r, w, r + w))
+print("%-28s %10s %12.1f %12.1f %12.1f" % ("all kernels", "", tot_r, tot_w, tot_r + tot_w))
