@@ -7,8 +7,10 @@ arithmetic step of the hot path is a hand-written gfx950 kernel in libmte_hip.so
 path -- a missing library or an unsupported shape raises.
 """
 import ctypes
+import itertools
 import math
 import os
+import weakref
 
 import torch
 
@@ -167,47 +169,142 @@ class WeightPack:
     """Kernel-ready copies of one OIHW fp32 conv weight: forward [Cout][taps][Cin_p] and data-gradient
     [Cin_p][taps rot180][Cout] packs in the compute dtype.  Re-packed when the parameter changes."""
 
+    _live = []                          # weak references to every pack (prefetch_weight_packs walks them)
+    _seq = itertools.count()
+
     def __init__(self):
         self.key = None
         self.wf = self.wb = None
         self.pf = self.pb = None        # fragment-block packs for the LDS-patch kernels (bf16, C_out <= 64)
         self.pkey = None
+        self._last = None               # (weakref to the parameter, dtype) of the latest request
+        self._order = -1                # when it was last requested (forward execution order)
+        self._event = None              # set by prefetch_weight_packs: side-stream event that makes the packs valid
+        WeightPack._live.append(weakref.ref(self))
 
-    def get_patch(self, w, which):
-        """which = 'f' (forward: N = Cout, K over Cin) or 'b' (data gradient: N = Cin_p, K over Cout)."""
-        wf, wb = self.get(w, torch.bfloat16, which == 'b')
-        if self.pkey != self.key:
-            self.pf = self.pb = None
-            self.pkey = self.key
+    def _sync_prefetch(self):
+        if self._event is not None:
+            if self._event is not _side.get("last_waited"):   # packs are prefetched in groups that share one event
+                torch.cuda.current_stream().wait_event(self._event)
+                _side["last_waited"] = self._event
+            self._event = None
+
+    def _patch_pack(self, w, which):
+        wf, wb = self.wf, self.wb
         cout, cin, kh, kw = w.shape
         cin_p = round8(cin)
         if which == 'f':
-            if self.pf is None:
-                n = lib.mte_conv2d_patch_pack_elems(cin_p, cout, kh, kw)
+            n = lib.mte_conv2d_patch_pack_elems(cin_p, cout, kh, kw)
+            if self.pf is None or self.pf.numel() != n:
                 self.pf = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
-                lib.mte_conv2d_patch_repack(wf.data_ptr(), self.pf.data_ptr(), cin_p, cout, kh, kw, _stream())
-            return self.pf
-        if self.pb is None:
+            lib.mte_conv2d_patch_repack(wf.data_ptr(), self.pf.data_ptr(), cin_p, cout, kh, kw, _stream())
+        else:
             n = lib.mte_conv2d_patch_pack_elems(cout, cin_p, kh, kw)
-            self.pb = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+            if self.pb is None or self.pb.numel() != n:
+                self.pb = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
             lib.mte_conv2d_patch_repack(wb.data_ptr(), self.pb.data_ptr(), cout, cin_p, kh, kw, _stream())
+
+    def get_patch(self, w, which):
+        """which = 'f' (forward: N = Cout, K over Cin) or 'b' (data gradient: N = Cin_p, K over Cout)."""
+        self.get(w, torch.bfloat16, which == 'b')
+        if self.pkey != self.key:
+            self.pf_ok = self.pb_ok = False
+            self.pkey = self.key
+        if which == 'f':
+            if not self.pf_ok:
+                self._patch_pack(w, 'f')
+                self.pf_ok = True
+            return self.pf
+        if not self.pb_ok:
+            self._patch_pack(w, 'b')
+            self.pb_ok = True
         return self.pb
 
-    def get(self, w, dtype, need_bwd):
-        key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
+    pf_ok = pb_ok = False
+
+    def _pack(self, w, dtype, need_bwd):
+        """(re)build the forward (and data-gradient) pack on the current stream, re-using the buffers when they fit"""
         cout, cin, kh, kw = w.shape
         cin_p = round8(cin)
         dtc = DT_BF16 if dtype == torch.bfloat16 else DT_F32
-        if key != self.key:
+        if self.wf is None or self.wf.dtype != dtype or tuple(self.wf.shape) != (cout, kh * kw, cin_p):
             self.wf = torch.empty((cout, kh * kw, cin_p), dtype=dtype, device=w.device)
-            self.wb = torch.empty((cin_p, kh * kw, cout), dtype=dtype, device=w.device) if need_bwd else None
-            lib.mte_pack_conv_weights(w.detach().contiguous().data_ptr(), self.wf.data_ptr(), _ptr(self.wb), cout, cin, kh, kw,
-                                      cin_p, cout, dtc, _stream())
-            self.key = key
-        elif need_bwd and self.wb is None:
+            self.wb = None
+        if need_bwd and (self.wb is None or self.wb.dtype != dtype):
             self.wb = torch.empty((cin_p, kh * kw, cout), dtype=dtype, device=w.device)
-            lib.mte_pack_conv_weights_bwd(self.wf.data_ptr(), self.wb.data_ptr(), cout, kh, kw, cin_p, dtc, _stream())
-        return self.wf, self.wb
+        lib.mte_pack_conv_weights(w.detach().contiguous().data_ptr(), self.wf.data_ptr(), _ptr(self.wb) if need_bwd else 0,
+                                  cout, cin, kh, kw, cin_p, cout, dtc, _stream())
+        self.has_bwd = bool(need_bwd)
+
+    has_bwd = False
+
+    def get(self, w, dtype, need_bwd):
+        key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
+        self._last = (weakref.ref(w), dtype)
+        self._order = next(WeightPack._seq)
+        if key != self.key:
+            self._event = None
+            self._pack(w, dtype, need_bwd)
+            self.key = key
+        else:
+            self._sync_prefetch()
+            if need_bwd and not self.has_bwd:
+                cout, cin, kh, kw = w.shape
+                cin_p = round8(cin)
+                if self.wb is None:
+                    self.wb = torch.empty((cin_p, kh * kw, cout), dtype=dtype, device=w.device)
+                lib.mte_pack_conv_weights_bwd(self.wf.data_ptr(), self.wb.data_ptr(), cout, kh, kw, cin_p,
+                                              DT_BF16 if dtype == torch.bfloat16 else DT_F32, _stream())
+                self.has_bwd = True
+        return self.wf, (self.wb if self.has_bwd else None)
+
+
+def prefetch_weight_packs():
+    """Re-pack every conv weight that the last forward/backward used, now, on the side stream (called by the optimizer
+    right after it changed the parameters): the ~100 small pack kernels of a step then overlap the first layers of the
+    next forward instead of sitting in front of each layer's convolution.  Packs are rebuilt in place; each carries an
+    event that its next user waits on."""
+    if not _side["enabled"]:
+        return
+    packs = []
+    for r in WeightPack._live:
+        pk = r()
+        if pk is not None and pk._last is not None and pk.key is not None and pk._last[0]() is not None:
+            packs.append(pk)
+    WeightPack._live = [r for r in WeightPack._live if r() is not None]
+    if not packs:
+        return
+    packs.sort(key=lambda pk: pk._order)
+    if not _side["streams"]:
+        _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
+    side = _side["streams"][0]
+    ev = torch.cuda.Event()
+    ev.record()                                              # the parameter update (and every earlier user of the packs)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        group = []
+        for i, pk in enumerate(packs):
+            w, dtype = pk._last[0](), pk._last[1]
+            if not w.is_cuda:
+                continue
+            had_pf, had_pb = pk.pf_ok and pk.pkey == pk.key, pk.pb_ok and pk.pkey == pk.key
+            pk._pack(w, dtype, pk.has_bwd)
+            pk.key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
+            pk.pkey = pk.key
+            pk.pf_ok = pk.pb_ok = False
+            if had_pf:
+                pk._patch_pack(w, 'f')
+                pk.pf_ok = True
+            if had_pb and pk.has_bwd:
+                pk._patch_pack(w, 'b')
+                pk.pb_ok = True
+            group.append(pk)
+            if len(group) == 8 or i + 1 == len(packs):       # one event per group: a stream wait costs about as much as a pack kernel
+                ev = torch.cuda.Event()
+                ev.record(side)
+                for g in group:
+                    g._event = ev
+                group = []
 
 
 def _splitk_workspace(M, N, device):

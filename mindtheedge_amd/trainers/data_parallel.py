@@ -138,6 +138,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.steps += 1
         K.adam_step_flat(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq, self.steps, lr=g['lr'],
                          betas=g['betas'], eps=g['eps'], gscale=gscale)
+        if self.flatp.grad.is_cuda:
+            K.prefetch_weight_packs()                       # next step's kernel-ready weight packs, off the critical path
 
     def state_dict(self):
         return {'steps': self.steps, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
