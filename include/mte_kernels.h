@@ -42,6 +42,11 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
                      float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, mte_stream_t stream);
+/* Library options.  MTE_OPT_GN_PREZEROED (0): when 1, the GroupNorm statistics / reduction / bias-gradient outputs handed to
+ * mte_gn_stats, mte_gn_elu_bwd and the gn_stats argument of the conv entry points are already zero (the caller clears
+ * one arena per step with a single memset) and the library skips its own per-call hipMemsetAsync. */
+#define MTE_OPT_GN_PREZEROED 0
+int mte_set_option(int option, int value);
 /* development knob (A/B experiments): key 0 = igemm tile loader, 1 = LDS-DMA (default), 0 = register staging */
 int mte_debug_set(int key, int value);
 /* weight gradient of the same conv: dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) */

@@ -90,6 +90,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// mte_set_option(MTE_OPT_GN_PREZEROED, 1): the caller hands over GroupNorm statistics / reduction / bias-gradient buffers
+// that are already zero (carved from one arena it clears with a single memset), so the library skips its ~140 tiny
+// per-layer hipMemsetAsync launches per training step.  Defined in norm_act.hip.
+extern int g_mte_gn_prezeroed;
+
 static inline int mte_check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) fprintf(stderr, "[libmte_hip] launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));

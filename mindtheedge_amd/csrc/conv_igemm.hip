@@ -407,7 +407,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
                       a.N % 16 == 0;
     if (stats_done) *stats_done = fuse ? 1 : 0;
     if (!fuse) a.gn_stats = nullptr;
-    else { a.gn_gs = a.N / 16; if (hipMemsetAsync(a.gn_stats, 0, sizeof(double) * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
+    else { a.gn_gs = a.N / 16; if (!g_mte_gn_prezeroed && hipMemsetAsync(a.gn_stats, 0, sizeof(double) * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
     if (a.splits > 1 && hipMemsetAsync(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
     if constexpr ((BN * 4) % 256 == 0) {
         if (g_igemm_dma) {

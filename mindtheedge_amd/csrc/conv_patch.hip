@@ -435,7 +435,7 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
     if (gn_stats && N % 16 != 0) return MTE_ERR_ARG;
-    if (gn_stats && hipMemsetAsync(gn_stats, 0, sizeof(double) * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (gn_stats && !g_mte_gn_prezeroed && hipMemsetAsync(gn_stats, 0, sizeof(double) * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, gn_stats};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
 }

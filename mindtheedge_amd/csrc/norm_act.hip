@@ -12,6 +12,8 @@
 // cross-GPU reduction anywhere in this file.
 #include "common.hpp"
 
+int g_mte_gn_prezeroed = 0;
+
 namespace {
 
 constexpr int GN_GROUPS = 16;
@@ -28,6 +30,7 @@ struct GnArgs {
     void* d1; long ldd1;               // backward outputs
     void* d2; long ldd2;
     float* dbias;                      // optional [C]: per-channel sum of d1 (= gradient of the conv bias in front of the norm)
+    float* dgamma; float* dbeta;       // [C], written by block (0, 0) of the apply pass
     int B, HW, C;
     float eps;
     int blocks_per_sample;
@@ -231,6 +234,16 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
         atomicAdd(&s_S[2 * (c / gs)], gc * r.x); atomicAdd(&s_S[2 * (c / gs) + 1], gc * r.y);
     }
     __syncthreads();
+    if (blockIdx.x == 0 && b == 0) {                      // dgamma_c = sum_b r2, dbeta_c = sum_b r1 (red is complete: pass 1 ran before)
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            float g = 0.f, bsum = 0.f;
+            for (int bb = 0; bb < a.B; ++bb) {
+                const float2 r = *(const float2*)(a.red + ((long)bb * a.C + c) * 2);
+                bsum += r.x; g += r.y;
+            }
+            a.dgamma[c] = g; a.dbeta[c] = bsum;
+        }
+    }
     float db[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) db[i] = 0.f;
@@ -285,14 +298,6 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
     }
 }
 
-__global__ void gn_param_grad_kernel(const float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float g = 0.f, bt = 0.f;
-    for (int b = 0; b < B; ++b) { bt += red[((long)b * C + c) * 2]; g += red[((long)b * C + c) * 2 + 1]; }
-    dgamma[c] = g; dbeta[c] = bt;
-}
-
 int g_gn_min_rows = 32, g_gn_target = 2048;         // development knobs (mte_debug_set(2 / 3, v))
 
 int gn_blocks(int B, int HW, int rstep) {
@@ -325,7 +330,7 @@ int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float
                  int B, int HW, int C, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
-    if (hipMemsetAsync(stats, 0, sizeof(double) * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (!g_mte_gn_prezeroed && hipMemsetAsync(stats, 0, sizeof(double) * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));
@@ -358,9 +363,11 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
                    int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dz || !y1 || !stats || !gamma || !beta || !red || !d1 || !dgamma || !dbeta || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
-    if (hipMemsetAsync(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    GnArgs a{}; a.dbias = dbias; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
+    if (!g_mte_gn_prezeroed) {
+        if (hipMemsetAsync(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    }
+    GnArgs a{}; a.dbias = dbias; a.dgamma = dgamma; a.dbeta = dbeta; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
     a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;
     a.B = B; a.HW = HW; a.C = C; a.eps = eps;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
@@ -374,8 +381,12 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
         hipLaunchKernelGGL(gn_elu_bwd_reduce_kernel<float>, grid, dim3(256), lds, stream, a);
         hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<float>, grid, dim3(256), dbias ? sizeof(float) * C : 0, stream, a);
     }
-    hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, dgamma, dbeta, B, C);
     return mte_check_launch();
+}
+
+int mte_set_option(int option, int value) {
+    if (option == 0) { g_mte_gn_prezeroed = value ? 1 : 0; return MTE_OK; }      // MTE_OPT_GN_PREZEROED
+    return MTE_ERR_ARG;
 }
 
 }  // extern "C"

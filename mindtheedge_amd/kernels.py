@@ -72,13 +72,16 @@ def set_grad_sink(sink):
     _sink["active"] = sink
 
 
-def _grad_dst(p):
-    """(tensor to write the gradient of `p` into, True if it is the sink's storage)."""
+def _grad_dst(p, zero=False):
+    """(tensor to write the gradient of `p` into, True if it is the sink's storage).  zero: the kernel ACCUMULATES into
+    the destination (the sink's flat gradient buffer is cleared by zero_grad; a private one comes zeroed)."""
     sk = _sink["active"]
     if sk is not None:
         v = sk.lookup(p)
         if v is not None:
             return v, True
+    if zero:
+        return _zeros(p.shape, torch.float32, p.device), False
     return torch.empty(p.shape, dtype=torch.float32, device=p.device), False
 
 
@@ -160,6 +163,42 @@ def _pl(t):
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
+
+
+class _ZeroArena:
+    """Small zero-initialised device buffers (GroupNorm statistics / reductions / bias-gradient vectors) carved from
+    8 MiB chunks that are cleared by ONE fill each: replaces ~140 per-layer 2-32 KiB memset launches per training step
+    (the library runs with MTE_OPT_GN_PREZEROED).  A chunk lives as long as any buffer carved from it."""
+    CHUNK = 8 << 20
+
+    def __init__(self):
+        self.chunks = {}                 # (device, stream) -> [uint8 chunk, offset]
+        self.enabled = False
+
+    def zeros(self, shape, dtype, device):
+        if not self.enabled:             # from now on the library trusts GroupNorm accumulation buffers to arrive zeroed
+            lib.mte_set_option(0, 1)
+            self.enabled = True
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) & ~255
+        if nbytes > self.CHUNK // 4:
+            return torch.zeros(shape, dtype=dtype, device=device)
+        key = (str(device), torch.cuda.current_stream().cuda_stream)
+        c = self.chunks.get(key)
+        if c is None or c[1] + nbytes > self.CHUNK:
+            c = self.chunks[key] = [torch.zeros((self.CHUNK,), dtype=torch.uint8, device=device), 0]
+        out = c[0][c[1]:c[1] + nbytes].view(dtype)[:n].view(shape)
+        c[1] += nbytes
+        return out
+
+
+_arena = _ZeroArena()
+
+
+def _zeros(shape, dtype, device):
+    return _arena.zeros(tuple(shape), dtype, device)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -468,7 +507,7 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, stats=None):
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     st = _stream()
     if stats is None:
-        stats = torch.empty((B, 16, 2), dtype=torch.float64, device=y1.device)
+        stats = _zeros((B, 16, 2), torch.float64, y1.device)
         lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
     if tuple(z.shape) != (B, C, H, W) or z.dtype != y1.dtype:
@@ -482,13 +521,13 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, stats=None):
 def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbias=False, dgamma=None, dbeta=None, dbias=None):
     B, C, H, W = y1.shape
     dz = as_act(dz, y1.dtype)
-    red = torch.empty((B, C, 2), dtype=torch.float32, device=y1.device)
+    red = _zeros((B, C, 2), torch.float32, y1.device)
     d1 = new_act(B, C, H, W, y1.dtype, y1.device)
     d2 = new_act(B, C, H, W, y1.dtype, y1.device) if need_d2 else None
     dgamma = dgamma if dgamma is not None else torch.empty((C,), dtype=torch.float32, device=y1.device)
     dbeta = dbeta if dbeta is not None else torch.empty((C,), dtype=torch.float32, device=y1.device)
     if want_dbias and dbias is None:
-        dbias = torch.empty((C,), dtype=torch.float32, device=y1.device)
+        dbias = _zeros((C,), torch.float32, y1.device)
     pz, lz = _pl(dz)
     p1, l1 = _pl(y1)
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
@@ -503,6 +542,24 @@ def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbia
 
 GN_EPS = 1e-5
 
+_dropout_pool = {}
+
+
+def dropout2d_scale(B, C, p, device):
+    """Dropout2d channel factors keep/(1-p) for one layer, [B, C] fp32 (reference: nn.Dropout2d in ResidualConv.conv3,
+    layers01.py:58-61).  The Bernoulli draws of a whole step's layers come from one pooled torch.rand (4 launches per
+    refill instead of 4 per layer); draws are i.i.d., so pooling does not change the distribution."""
+    key = (str(device), float(p))
+    pool = _dropout_pool.get(key)
+    n = B * C
+    if pool is None or pool[1] + n > pool[0].numel():
+        size = max(1 << 17, 2 * n)
+        pool = _dropout_pool[key] = [(torch.rand((size,), device=device) >= p).float() / (1.0 - p), 0]
+    out = pool[0][pool[1]:pool[1] + n].view(B, C)
+    pool[1] += n
+    return out
+
+
 
 class ConvGnEluFn(torch.autograd.Function):
     """ELU(GroupNorm16(conv_k(zero_pad(x)) + b))  -- reference Conv2D.forward, layers01.py:35-38."""
@@ -511,7 +568,7 @@ class ConvGnEluFn(torch.autograd.Function):
     def forward(ctx, x, w, b, gamma, beta, pack, out=None):
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
-        stats = torch.empty((x.shape[0], 16, 2), dtype=torch.float64, device=x.device)
+        stats = _zeros((x.shape[0], 16, 2), torch.float64, x.device)
         y, fused = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w, gn_stats=stats)
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, stats=stats if fused else None,
                                out=None if out is None else alias_of(out))
@@ -526,7 +583,7 @@ class ConvGnEluFn(torch.autograd.Function):
         b = ctx.bias
         gg, sg = _grad_dst(gamma)
         gb, sb = _grad_dst(beta)
-        gbias, sbias = _grad_dst(b)
+        gbias, sbias = _grad_dst(b, zero=True)
         gw, sw = _grad_dst(w)
         dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
                                                 dgamma=gg, dbeta=gb, dbias=gbias)

@@ -106,8 +106,7 @@ class ResidualConv(nn.Module):
         y = self.conv2(self.conv1(x))
         s = K.ConvFn.apply(x, sc.weight, sc.bias, sc.pack)
         if channel_scale is None and self.dropout and self.training:
-            keep = torch.rand((x.shape[0], sc.out_channels), device=x.device) >= self.dropout
-            channel_scale = keep.float() / (1.0 - self.dropout)
+            channel_scale = K.dropout2d_scale(x.shape[0], sc.out_channels, self.dropout, x.device)
         return K.ResidualTailFn.apply(y, s, channel_scale, self.normalize.weight, self.normalize.bias)
 
 

@@ -42,3 +42,17 @@ import bisect
 for lim in (2, 5, 10, 20, 50):
     sel = [g for g in gaps if g * 1e-3 <= lim]
     print("  gaps <= %3d us: %6d, total %.2f ms" % (lim, len(sel), sum(sel) * 1e-6))
+
+# ---- per HIP stream (HSA queue): which kernels sit on the main chain and which on the side stream
+perq = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+with open(path) as f:
+    for r in csv.DictReader(f):
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0][:40]
+        d = perq[r.get("Queue_Id", "?")][name]
+        d[0] += 1
+        d[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+for q, ks in sorted(perq.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
+    tot = sum(v[1] for v in ks.values())
+    print("queue %s: %.2f ms/step in %d launches/step" % (q, tot / steps * 1e-3, sum(v[0] for v in ks.values()) / steps))
+    for name, (n, us) in sorted(ks.items(), key=lambda kv: -kv[1][1])[:28]:
+        print("    %8.1f us/step %6.1f calls/step  %s" % (us / steps, n / steps, name))
