@@ -113,14 +113,21 @@ int mte_copy_rect(const void* src, long lds_, int Hs, int Ws, int sy, int sx, vo
 /* ---- InvDepth head: sigmoid(conv3x3(x) + b) / min_depth  (layers01.py:99-123) */
 int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,
                      int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);
-int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_out, const float* dout, float* dlogit_scratch,
-                     void* dx, long lddx, float* dwb, int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);
+/* backward, two independent halves: _data writes dlogit [B,H,W] (fp32 scratch, also the input of _weight) and dx;
+ * _weight accumulates dwb [C*9 + 1] = (dW OIHW, db), zeroed here */
+int mte_invdepth_bwd_data(const float* w, const float* inv_out, const float* dout, float* dlogit,
+                          void* dx, long lddx, int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);
+int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float* dwb,
+                            int B, int H, int W, int C, int dtype, mte_stream_t stream);
 
 /* ---- layout / wiring helpers (networks/depth/PackNetSAN01.py:92-143 cat + Upsample; models/model_utils.py:98-117 flip) */
 int mte_nchw_to_nhwc(const float* src, void* dst, long ldd, int B, int C, int H, int W, int Cp, int flip_w, int dtype, mte_stream_t stream);
 int mte_upsample_inv_fwd(const float* inv, void* dst, long ldd, int B, int h, int w, int dtype, mte_stream_t stream);
 int mte_upsample_inv_bwd(const void* dsrc, long lds_, float* dinv, int B, int h, int w, int accumulate, int dtype, mte_stream_t stream);
 int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix, int C, int dtype, mte_stream_t stream);
+/* out = a + b over NHWC channel-slice views: the summed gradient of an activation with two consumers (what autograd's
+ * implicit accumulation does in the reference), one 16-byte-vectorised pass whatever the strides */
+int mte_add_channels(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long npix, int C, int dtype, mte_stream_t stream);
 
 /* ---- depth-edge loss: inv2depth + GradLayer + GradLoss('cross_entropy')
  *      (utils/depth.py:104-121; losses/grad_loss.py:20-31,65-95,122-219) */

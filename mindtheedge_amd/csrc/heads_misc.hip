@@ -76,37 +76,32 @@ __global__ void invdepth_dlogit_kernel(const float* __restrict__ dout, const flo
     }
 }
 
-// dx[q][c] = sum_t dlogit[q - t] * w[c][t];  dw[c][t] += sum_q dlogit[q - t] * x[q][c];  db += sum_q dlogit[q]
-// Both sums are driven by the x pixel q: one 16-byte load of x[q] and the 3x3 neighbourhood of the (fp32, one float per
-// pixel) logit gradient feed 72 weight-gradient and 72 data-gradient FMAs, so x is read exactly once.
+// Backward of the head, as two independent streams over the pixels (the logit gradient dlogit is one fp32 per pixel):
+//   data   : dx[q][c]  = sum_t dlogit[q - t] * w[c][t]        -- needs no activation at all: a pure 16-B store stream
+//   weight : dw[c][t] += sum_q dlogit[q - t] * x[q][c], db += sum_q dlogit[q]   -- a pure load stream with 72 register
+//            accumulators per thread, one LDS + one global atomic pass per block
+// Split because together they need 72 weights + 72 accumulators per thread (256 VGPRs, 8 waves/CU, latency-bound);
+// apart each keeps < 128 VGPRs, and the weight half can run on the weight-gradient side stream.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void invdepth_bwd_kernel(HeadArgs a) {
-    extern __shared__ float sdw[];                               // [C*9 + 1] gradient accumulators, then [9][C] weights (tap-major)
-    float* swt = sdw + ((a.C * 9 + 4) & ~3);                     // 16-byte aligned
-    for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) sdw[i] = 0.f;
-    for (int i = threadIdx.x; i < a.C * 9; i += 256) swt[(i % 9) * a.C + i / 9] = a.w[i];
-    __syncthreads();
+__global__ __launch_bounds__(256) void invdepth_bwd_data_kernel(HeadArgs a) {
     const int cb = a.C >> 3;
     const int j = threadIdx.x % cb;
     const int c0 = j * 8;
-    float gw[9][8];
+    float wr[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gw[t][i] = 0.f;
-    float gb = 0.f;
+        for (int i = 0; i < 8; ++i) wr[t][i] = a.w[(c0 + i) * 9 + t];
     const long ppb = 256 / cb;
     const long stride = (long)gridDim.x * ppb;
-    constexpr int U = 2;                                         // pixels in flight per thread
+    constexpr int U = 2;
 #pragma unroll 1
     for (long base = blockIdx.x * ppb + threadIdx.x / cb; base < a.npix; base += stride * U) {
-        u32x4_t xr[U];
         float dl[U][9];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long pix = base + u * stride;
             if (pix < a.npix) {
-                if constexpr (sizeof(T) == 2) xr[u] = *(const u32x4_t*)((const T*)a.x + pix * a.ldx + c0);
                 const int x = (int)(pix % a.W); const int y = (int)((pix / a.W) % a.H);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -120,22 +115,60 @@ __global__ __launch_bounds__(256, 2) void invdepth_bwd_kernel(HeadArgs a) {
         for (int u = 0; u < U; ++u) {
             const long pix = base + u * stride;
             if (pix >= a.npix) break;
-            float v[8], dxv[8];
-            if constexpr (sizeof(T) == 2) unpack16<T>(xr[u], v);
-            else ld8<T>((const T*)a.x + pix * a.ldx + c0, v);            // fp32 validation mode: 8 channels = two chunks
-            if (j == 0) gb += dl[u][4];
+            float dxv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) dxv[i] = 0.f;
 #pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dxv[i] = fmaf(dl[u][t], wr[t][i], dxv[i]);
+            st8<T>((T*)a.dx + pix * a.lddx + c0, dxv);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void invdepth_bwd_weight_kernel(HeadArgs a) {
+    extern __shared__ float sdw[];                               // [C*9 + 1] block-level gradient accumulators
+    for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) sdw[i] = 0.f;
+    __syncthreads();
+    const int cb = a.C >> 3;
+    const int j = threadIdx.x % cb;
+    const int c0 = j * 8;
+    float gw[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gw[t][i] = 0.f;
+    float gb = 0.f;
+    const long ppb = 256 / cb;
+    const long stride = (long)gridDim.x * ppb;
+    constexpr int U = 4;                                         // 16-byte activation loads in flight per thread
+#pragma unroll 1
+    for (long base = blockIdx.x * ppb + threadIdx.x / cb; base < a.npix; base += stride * U) {
+        u32x4_t xr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = base + u * stride;
+            if constexpr (sizeof(T) == 2) { if (pix < a.npix) xr[u] = *(const u32x4_t*)((const T*)a.x + pix * a.ldx + c0); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = base + u * stride;
+            if (pix >= a.npix) break;
+            const int x = (int)(pix % a.W); const int y = (int)((pix / a.W) % a.H);
+            float v[8];
+            if constexpr (sizeof(T) == 2) unpack16<T>(xr[u], v);
+            else ld8<T>((const T*)a.x + pix * a.ldx + c0, v);            // fp32 validation mode: 8 channels = two chunks
+#pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const float d = dl[u][t];
-                const f32x4_t w0 = *(const f32x4_t*)(swt + t * a.C + c0), w1 = *(const f32x4_t*)(swt + t * a.C + c0 + 4);
+                const int oy = t / 3 - 1, ox = t % 3 - 1;
+                const bool ok = (unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W;
+                const float d = ok ? a.dlogit[pix - (long)oy * a.W - ox] : 0.f;
+                if (t == 4 && j == 0) gb += d;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(d, v[i], gw[t][i]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { dxv[i] = fmaf(d, w0[i], dxv[i]); dxv[4 + i] = fmaf(d, w1[i], dxv[4 + i]); }
             }
-            st8<T>((T*)a.dx + pix * a.lddx + c0, dxv);
         }
     }
 #pragma unroll
@@ -196,6 +229,24 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, long lds_, T* __
     }
 }
 
+// out = a + b on channel-slice views (fp32 sum, rounded once): the gradient of a tensor with two consumers
+template <typename T>
+__global__ void add_channels_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, T* __restrict__ out, long ldo,
+                                    long npix, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P;
+    const long n = npix * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cpr; const int cc = (int)(i % cpr);
+        float va[P], vb[P];
+        unpack16<T>(*(const u32x4_t*)(a + pix * lda + cc * P), va);
+        unpack16<T>(*(const u32x4_t*)(b + pix * ldb + cc * P), vb);
+#pragma unroll
+        for (int k = 0; k < P; ++k) va[k] += vb[k];
+        *(u32x4_t*)(out + pix * ldo + cc * P) = pack16<T>(va);
+    }
+}
+
 // torch.optim.Adam semantics (no weight decay, no amsgrad): bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t) from the host
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
@@ -242,23 +293,35 @@ int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias,
 }
 
 // dlogit_scratch [B*H*W] fp32; dwb [C*9 + 1] fp32 (zeroed here): dw (OIHW order, O = 1) followed by db
-int mte_invdepth_bwd(const void* x, long ldx, const float* w, const float* inv_out, const float* dout, float* dlogit_scratch,
-                     void* dx, long lddx, float* dwb, int B, int H, int W, int C, float min_depth, int dtype, hipStream_t stream) {
+int mte_invdepth_bwd_data(const float* w, const float* inv_out, const float* dout, float* dlogit,
+                          void* dx, long lddx, int B, int H, int W, int C, float min_depth, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!x || !w || !inv_out || !dout || !dlogit_scratch || !dx || !dwb || !head_ok(C)) return MTE_ERR_ARG;
+    if (!w || !inv_out || !dout || !dlogit || !dx || !head_ok(C)) return MTE_ERR_ARG;
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(invdepth_dlogit_kernel, dim3(stream_grid(npix)), dim3(256), 0, stream, dout, inv_out, dlogit, npix, 1.f / min_depth);
+    HeadArgs a{}; a.w = w; a.dlogit = dlogit; a.dx = dx; a.lddx = lddx; a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
+    const int ppb = 256 / (C / 8);
+    const int grid = stream_grid(npix, ppb * 4);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_data_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(invdepth_bwd_data_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
+    return mte_check_launch();
+}
+
+int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float* dwb,
+                            int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !dlogit || !dwb || !head_ok(C)) return MTE_ERR_ARG;
     const long npix = (long)B * H * W;
     if (hipMemsetAsync(dwb, 0, sizeof(float) * (C * 9 + 1), stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    hipLaunchKernelGGL(invdepth_dlogit_kernel, dim3(stream_grid(npix)), dim3(256), 0, stream, dout, inv_out, dlogit_scratch, npix, 1.f / min_depth);
-    HeadArgs a{}; a.x = x; a.ldx = ldx; a.w = w; a.dlogit = dlogit_scratch; a.dx = dx; a.lddx = lddx; a.dw = dwb;
-    a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
+    HeadArgs a{}; a.x = x; a.ldx = ldx; a.dlogit = dlogit; a.dw = dwb; a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
     const int ppb = 256 / (C / 8);
-    // few, long-running blocks: every block ends with C*9+1 same-address global atomics (contended adds are ~14x slower)
-    // (each block should stream >= ~4x more 16-byte chunks than it issues atomics: npix * C/8 / g >= 4 * 9C)
-    long g = npix / 288; if (g > 768) g = 768; if (g < 64) g = 64;
+    // few, long-running blocks: every block ends with C*9+1 same-address global atomics (contended adds are ~14x slower);
+    // each block should stream >= ~4x more 16-byte chunks than it issues atomics: npix * C/8 / g >= 4 * 9C
+    long g = npix / 288; if (g > 1024) g = 1024; if (g < 64) g = 64;
     if (g > (npix + ppb - 1) / ppb) g = (npix + ppb - 1) / ppb;
-    const size_t lds = sizeof(float) * (C * 18 + 4);
-    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL(invdepth_bwd_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, a);
+    const size_t lds = sizeof(float) * (C * 9 + 4);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(invdepth_bwd_weight_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, a);
     return mte_check_launch();
 }
 
@@ -295,6 +358,16 @@ int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix
     const int grid = stream_grid(npix * (C / per16));
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, npix, C);
     else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)src, lds_, (float*)dst, ldd, npix, C);
+    return mte_check_launch();
+}
+
+int mte_add_channels(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long npix, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (!a || !b || !out || C % per16 != 0) return MTE_ERR_ARG;
+    const int grid = stream_grid(npix * (C / per16));
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(add_channels_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, npix, C);
+    else hipLaunchKernelGGL(add_channels_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)a, lda, (const float*)b, ldb, (float*)out, ldo, npix, C);
     return mte_check_launch();
 }
 

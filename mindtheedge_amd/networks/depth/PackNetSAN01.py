@@ -39,13 +39,13 @@ class PackNetSlimEnc01(nn.Module):
         """`skip_out`: optional destinations for the five skip tensors (channel blocks of the decoder's concat buffers,
         see Decoder.concat_buffers) so that torch.cat never has to copy them."""
         so = skip_out or [None] * 5
-        x = self.pre_calc(rgb, out=so[0])
-        x1p = self.pack1(self.conv1(x), out=so[1])
-        x2p = self.pack2(self.conv2(x1p), out=so[2])
-        x3p = self.pack3(self.conv3(x2p), out=so[3])
-        x4p = self.pack4(self.conv4(x3p), out=so[4])
+        x, s1 = K.fork(self.pre_calc(rgb, out=so[0]))                  # every skip has two consumers: next stage + decoder
+        x1p, s2 = K.fork(self.pack1(self.conv1(x), out=so[1]))
+        x2p, s3 = K.fork(self.pack2(self.conv2(x1p), out=so[2]))
+        x3p, s4 = K.fork(self.pack3(self.conv3(x2p), out=so[3]))
+        x4p, s5 = K.fork(self.pack4(self.conv4(x3p), out=so[4]))
         x5p = self.pack5(self.conv5(x4p))
-        return x5p, [x, x1p, x2p, x3p, x4p]
+        return x5p, [s1, s2, s3, s4, s5]
 
 
 class Decoder(nn.Module):
@@ -91,12 +91,12 @@ class Decoder(nn.Module):
             return None if buf is None else K.channel_slice(buf, 0, unp.conv.conv_base.out_channels)
 
         iconv5 = self.iconv5(K.ConcatFn.apply(None, b5, self.unpack5(x5p, out=up_dst(b5, self.unpack5)), skip5))
-        iconv4 = self.iconv4(K.ConcatFn.apply(None, b4, self.unpack4(iconv5, out=up_dst(b4, self.unpack4)), skip4))
-        inv_depth4 = self.disp4_layer(iconv4)
-        iconv3 = self.iconv3(K.ConcatFn.apply(inv_depth4, b3, self.unpack3(iconv4, out=up_dst(b3, self.unpack3)), skip3))
-        inv_depth3 = self.disp3_layer(iconv3)
-        iconv2 = self.iconv2(K.ConcatFn.apply(inv_depth3, b2, self.unpack2(iconv3, out=up_dst(b2, self.unpack2)), skip2))
-        inv_depth2 = self.disp2_layer(iconv2)
+        iconv4, f4 = K.fork(self.iconv4(K.ConcatFn.apply(None, b4, self.unpack4(iconv5, out=up_dst(b4, self.unpack4)), skip4)))
+        inv_depth4 = self.disp4_layer(f4)
+        iconv3, f3 = K.fork(self.iconv3(K.ConcatFn.apply(inv_depth4, b3, self.unpack3(iconv4, out=up_dst(b3, self.unpack3)), skip3)))
+        inv_depth3 = self.disp3_layer(f3)
+        iconv2, f2 = K.fork(self.iconv2(K.ConcatFn.apply(inv_depth3, b2, self.unpack2(iconv3, out=up_dst(b2, self.unpack2)), skip2)))
+        inv_depth2 = self.disp2_layer(f2)
         iconv1 = self.iconv1(K.ConcatFn.apply(inv_depth2, b1, self.unpack1(iconv2, out=up_dst(b1, self.unpack1)), skip1))
         inv_depth1 = self.disp1_layer(iconv1)
         return [inv_depth1, inv_depth2, inv_depth3, inv_depth4]

@@ -103,8 +103,9 @@ class ResidualConv(nn.Module):
     def forward(self, x, channel_scale=None):
         sc = self._shortcut_params()
         x = _enter(x, sc.in_channels)
-        y = self.conv2(self.conv1(x))
-        s = K.ConvFn.apply(x, sc.weight, sc.bias, sc.pack)
+        xa, xb = K.fork(x)
+        y = self.conv2(self.conv1(xa))
+        s = K.ConvFn.apply(xb, sc.weight, sc.bias, sc.pack)
         if channel_scale is None and self.dropout and self.training:
             channel_scale = K.dropout2d_scale(x.shape[0], sc.out_channels, self.dropout, x.device)
         return K.ResidualTailFn.apply(y, s, channel_scale, self.normalize.weight, self.normalize.bias)
