@@ -61,12 +61,13 @@ __device__ u32x4_t g_zero16 = {0u, 0u, 0u, 0u};      // source of zero chunks fo
 // address arithmetic, not HBM or LDS, was what held the MFMA pipe at ~25 %.  Out-of-image taps use an out-of-range offset
 // (the buffer bounds check returns zeros).
 template <typename T, int WM, int WN, int TM, int TN, int LD>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool DMA = LD != 0;
+    constexpr int NTHR = WM * WN * 64;                 // one wave per (TM*32) x (TN*32) sub-tile
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PER16 = Elem<T>::PER16;
-    constexpr int A_CH = BM * 4 / 256;                 // 16-B chunks of the A tile per thread
-    constexpr int B_CH = (BN * 4 + 255) / 256;         // (BN = 32: only threads < 128 load)
+    constexpr int A_CH = BM * 4 / NTHR;                 // 16-B chunks of the A tile per thread
+    constexpr int B_CH = (BN * 4 + NTHR - 1) / NTHR;         // (BN = 32: only threads < 128 load)
     constexpr int ST = DMA ? 4 : 2;                    // LDS ring depth
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                                   // [ST][BM*64]
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     long a_pix[A_CH]; int a_oy[A_CH], a_ox[A_CH]; bool a_ok[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int row = (tid + i * 256) >> 2;
+        const int row = (tid + i * NTHR) >> 2;
         const long m = m0 + row;
         a_ok[i] = m < a.M;
         const long mm = a_ok[i] ? m : 0;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int q = 4 * s + kc;
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             const int row = idx >> 2, n = n0 + row;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (idx < BN * 4 && n < a.N && q < total_chunks) v = *(const u32x4_t*)(wp + (long)n * Kp + (long)q * PER16);
@@ -151,15 +152,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
             const bool ok = a_ok[i] && tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const void* src = ok ? (const void*)(xp + (a_pix[i] + (long)dy * a.W + dx) * a.ldx + c * PER16) : (const void*)&g_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * BM * 64 + (wv * 16 + i * 64) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * BM * 64 + (wv * 16 + i * (NTHR / 4)) * 64), 16, 0, 0);
         }
         const int q = 4 * s + kc;
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
-            if (wv * 64 + i * 256 < BN * 4) {                       // wave-uniform (BN*4 is a multiple of 64)
-                const int row = (tid + i * 256) >> 2, n = n0 + row;
+            if (wv * 64 + i * NTHR < BN * 4) {                       // wave-uniform (BN*4 is a multiple of 64)
+                const int row = (tid + i * NTHR) >> 2, n = n0 + row;
                 const void* src = (n < a.N && q < total_chunks) ? (const void*)(wp + (long)n * Kp + (long)q * PER16) : (const void*)&g_zero16;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + buf * BN * 64 + (wv * 16 + i * 64) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + buf * BN * 64 + (wv * 16 + i * (NTHR / 4)) * 64), 16, 0, 0);
             }
         }
         c += 4;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < A_CH; ++i) voffA[i] = (unsigned)((a_pix[i] * a.ldx + kc * PER16) * ES);
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
-            const int n = n0 + ((tid + i * 256) >> 2);
+            const int n = n0 + ((tid + i * NTHR) >> 2);
             voffB[i] = n < a.N ? (unsigned)(((long)n * Kp + kc * PER16) * ES) : OOB;
         }
         const int q0 = 4 * s_begin, tap0 = q0 / cpt;
@@ -206,10 +207,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int soffA = f_cb * PER16 * ES, soffB = s * 64;
 #pragma unroll
         for (int i = 0; i < A_CH; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sA + slot * BM * 64 + (wv * 16 + i * 64) * 64), 16, voffT[i], soffA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sA + slot * BM * 64 + (wv * 16 + i * (NTHR / 4)) * 64), 16, voffT[i], soffA, 0, 0);
 #pragma unroll
         for (int i = 0; i < B_CH; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(sB + slot * BN * 64 + (wv * 16 + i * 64) * 64), 16, voffB[i], soffB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(sB + slot * BN * 64 + (wv * 16 + i * (NTHR / 4)) * 64), 16, voffB[i], soffB, 0, 0);
         f_cb += 4;
 #else
         (void)s; (void)slot;
@@ -218,12 +219,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            const int row = (tid + i * 256) >> 2;
+            const int row = (tid + i * NTHR) >> 2;
             *(u32x4_t*)(sA + buf * BM * 64 + lds_chunk_off(row, kc)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             if (idx < BN * 4) *(u32x4_t*)(sB + buf * BN * 64 + lds_chunk_off(idx >> 2, kc)) = rb[i];
         }
     };
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         // 4-slot LDS ring filled by LDS-DMA three K-steps ahead.  vmcnt is COUNTED (two younger stages stay in
         // flight across the barrier): the only wait per K-step is for the stage about to be consumed, so HBM/L2
         // latency (1-2k cycles under load) is covered by three K-steps of MFMA work instead of one.
-        static_assert((BN * 4) % 256 == 0, "every wave must issue the same number of DMA instructions per stage");
+        static_assert((BN * 4) % NTHR == 0, "every wave must issue the same number of DMA instructions per stage");
         constexpr int LPS = A_CH + B_CH;
         const int nst = s_end - s_begin;
 #pragma unroll
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             constexpr int CPR = BN / PER16;                // 16-B chunks per tile row
             const int cvalid = (a.N - n0) / PER16;         // chunks of this tile inside N (N % 8 == 0)
 #pragma unroll
-            for (int it = 0; it < BM * CPR / 256; ++it) {
-                const int idx = tid + it * 256;
+            for (int it = 0; it < BM * CPR / NTHR; ++it) {
+                const int idx = tid + it * NTHR;
                 const int row = idx / CPR, cc = idx - row * CPR;
                 const long m = m0 + row;
                 if (m < a.M && cc < cvalid)
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (a.gn_stats) {
                 // GroupNorm statistics of the tile as stored (rounded to T): column sums per sample -> groups -> fp64 atomics.
                 // A 128-pixel tile spans at most two samples (H*W >= 128 is checked on the host).
-                constexpr int TPC = 256 / BN, RPP = BM / TPC;          // threads per column, rows per thread
+                constexpr int TPC = NTHR / BN, RPP = BM / TPC;          // threads per column, rows per thread
                 const int col = tid % BN, part = tid / BN;
                 const long hw = (long)a.H * a.W;
                 const int b0 = (int)(m0 / hw);
@@ -398,29 +399,31 @@ inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems) {
 
 template <typename T, int WM, int WN, int TM, int TN>
 int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
     a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems) : 1;
     // GroupNorm statistics can ride on the LDS-staged epilogue of the DMA kernels (not: split-K, fp32 output, the register-staged 128x32 configuration)
-    const bool fuse = a.gn_stats && (BN * 4) % 256 == 0 && g_igemm_dma && a.splits == 1 && !a.out_f32 && (long)a.H * a.W >= BM &&
+    const bool fuse = a.gn_stats && (BN * 4) % NTHR == 0 && g_igemm_dma && a.splits == 1 && !a.out_f32 && (long)a.H * a.W >= BM &&
                       a.N % 16 == 0;
     if (stats_done) *stats_done = fuse ? 1 : 0;
     if (!fuse) a.gn_stats = nullptr;
     else { a.gn_gs = a.N / 16; if (!g_mte_gn_prezeroed && hipMemsetAsync(a.gn_stats, 0, sizeof(double) * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
     if (a.splits > 1 && hipMemsetAsync(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
-    if constexpr ((BN * 4) % 256 == 0) {
+    if constexpr ((BN * 4) % NTHR == 0) {
         if (g_igemm_dma) {
             const size_t lds4 = 4 * (BM + BN) * 64 + 256;
             const long es = (long)sizeof(T);
             const bool fast = g_igemm_dma == 1 && a.Cin_p % (4 * Elem<T>::PER16) == 0 &&
                               ((a.M - 1) * a.ldx + a.Cin_p) * es < 0x7ff00000L && (long)a.N * a.KH * a.KW * a.Cin_p * es < 0x7ff00000L;
-            if (fast) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds4, st, a);
-            else hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 1>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds4, st, a);
+            if (fast) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2>), dim3((unsigned)(tiles * a.splits)), dim3(NTHR), lds4, st, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 1>), dim3((unsigned)(tiles * a.splits)), dim3(NTHR), lds4, st, a);
             goto launched;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 0>), dim3((unsigned)(tiles * a.splits)), dim3(256), 2 * (BM + BN) * 64, st, a);
+    if constexpr (NTHR == 256)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 0>), dim3((unsigned)(tiles * a.splits)), dim3(256), 2 * (BM + BN) * 64, st, a);
+    else return MTE_ERR_UNSUPPORTED;
 launched:
     if (a.splits > 1) {
         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
@@ -429,7 +432,24 @@ launched:
     return mte_check_launch();
 }
 
+int g_igemm_big_min_tiles = 224;
+int g_igemm_big = 2;                                 // development knob (mte_debug_set(6, v)): 256 x 128 tiles where they pay
+
 template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st, int* stats_done) {
+    if constexpr (sizeof(T) == 2) {
+        // 256 x 128 tile, 8 waves: 24 KB of operands per K-step feed twice the MFMA work of a 128 x 128 tile (16 KB).  The
+        // 4-wave kernel runs at ~14 TB/s of L2->LDS traffic with three stages in flight -- the latency-bandwidth product,
+        // not the MFMA pipe, bounds it -- so fewer bytes per flop is the lever.  Needs the buffer-DMA loader and enough
+        // tiles to cover the CUs.
+        const long tiles_big = ((a.M + 255) / 256) * ((a.N + 127) / 128);
+        const bool dma_ok = g_igemm_dma == 1 && a.Cin_p % 32 == 0 && ((a.M - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L &&
+                            (long)a.N * a.KH * a.KW * a.Cin_p * 2 < 0x7ff00000L;
+        if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N % 256 == 0 &&
+            ((a.M + 255) / 256) * (a.N / 256) >= g_igemm_big_min_tiles)
+            return launch_igemm<T, 4, 4, 2, 2>(a, 0, st, stats_done);                  // 256 x 256, 16 waves
+        if (g_igemm_big && dma_ok && !a.out_f32 && a.N % 128 == 0 && tiles_big >= g_igemm_big_min_tiles)
+            return launch_igemm<T, 4, 2, 2, 2>(a, 0, st, stats_done);
+    }
     if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st, stats_done);       // 128 x 32
     if (a.N <= 64 || (a.N % 128 != 0 && a.N < 128)) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st, stats_done);   // 128 x 64
     return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st, stats_done);                      // 128 x 128
@@ -1068,6 +1088,8 @@ int mte_debug_set(int key, int value) {
     if (key == 1) return mtei_set_pack3d_lds(value);
     if (key == 2 || key == 3) return mtei_set_gn(key - 2, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
+    if (key == 6) { g_igemm_big = value; return MTE_OK; }
+    if (key == 7) { g_igemm_big_min_tiles = value; return MTE_OK; }
     return MTE_ERR_ARG;
 }
 

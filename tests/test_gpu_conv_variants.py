@@ -128,3 +128,46 @@ def test_dma_wgrad_matches_register_staged_wgrad(shape):
         K.lib.mte_debug_set(4, 1)
     assert rel_err(a["dw"], r["dw"]) < 2e-4
     assert rel_err(a["y"], r["y"]) < 8e-3              # (forward split-K sums are order-dependent)
+
+
+@pytest.mark.parametrize("shape", [(64, 128, 3, 2, 24, 40), (96, 256, 3, 3, 10, 52), (32, 128, 5, 1, 30, 33), (128, 384, 1, 2, 16, 48)])
+def test_igemm_256x128_tiles_match_128x128_tiles(shape):
+    """The 8-wave 256x128-tile and 16-wave 256x256-tile instantiations of the implicit GEMM against the 4-wave 128x128 one: same K order, same fp32
+    accumulation chain per output, so forward, fused GroupNorm statistics and data gradient must be bit-identical."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W = shape
+
+    def run(big):
+        K.lib.mte_debug_set(6, big)
+        K.lib.mte_debug_set(7, 1)
+        orig, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)
+        try:
+            g = torch.Generator().manual_seed(3 + cin + cout)
+            w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+            b = (torch.rand(cout, generator=g) - 0.5).cuda()
+            xa = K.image_to_act(torch.rand(B, cin, H, W, generator=g).cuda() * 2 - 1)
+            dy = K.image_to_act(torch.rand(B, cout, H, W, generator=g).cuda() * 2 - 1)
+            pack = K.WeightPack()
+            wf, wb = pack.get(w, xa.dtype, True)
+            stats = torch.zeros((B, 16, 2), dtype=torch.float64, device="cuda")
+            y, fused = K.conv_forward(xa, wf, b, cout, k, k, gn_stats=stats)
+            dx = K.conv_forward(dy, wb, None, K.round8(cin), k, k) if K.round8(cin) % 128 == 0 else None
+            torch.cuda.synchronize()
+            return y.float().cpu(), stats.cpu(), fused, None if dx is None else dx.float().cpu()
+        finally:
+            K._splitk_workspace = orig
+            K.lib.mte_debug_set(6, 2)
+            K.lib.mte_debug_set(7, 224)
+
+    K.use_patch_kernels(False)
+    try:
+        yb, sb, fb, db = run(0)
+        for big in (1, 2):                                          # 1: 256x128 only; 2: 256x256 where C_out % 256 == 0
+            ya, sa, fa, da = run(big)
+            assert fa and fb
+            assert torch.equal(ya, yb)
+            assert torch.allclose(sa, sb, rtol=1e-6, atol=1e-6)     # (fp32 partial sums per tile differ in grouping)
+            if da is not None:
+                assert torch.equal(da, db)
+    finally:
+        K.use_patch_kernels(True)
