@@ -708,17 +708,19 @@ __device__ __forceinline__ bf16x8_t tr_operand(unsigned long long lo, unsigned l
     const u32x4_t c{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
     return __builtin_bit_cast(bf16x8_t, c);
 }
-template <int CPRW> __device__ __forceinline__ int wg_swz(int row) { return CPRW == 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
+template <int CPRW> __device__ __forceinline__ int wg_swz(int row) { return CPRW >= 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
 
-template <int TNO, int TC, bool FL>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a) {
+template <int WNO, int WC, int TNO, int TC, bool FL>
+__global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs a) {
     typedef bf16_t T;
-    constexpr int BNO = 2 * TNO * 32, BC = 2 * TC * 32;               // cout x cin tile, waves 2 x 2
+    constexpr int NW = WNO * WC;                                      // waves, arranged WNO (cout) x WC (cin)
+    constexpr int BNO = WNO * TNO * 32, BC = WC * TC * 32;            // cout x cin tile
     constexpr int KB = 32, ES = 2;
-    constexpr int CPR_Y = BNO / 8, CPR_X = BC / 8;                    // 16-byte chunks per tile row (8 or 16)
+    constexpr int CPR_Y = BNO / 8, CPR_X = BC / 8;                    // 16-byte chunks per tile row (8, 16 or 32)
     constexpr int ROWB_Y = BNO * ES, ROWB_X = BC * ES;
     constexpr int YB = KB * ROWB_Y, XB = KB * ROWB_X, STAGE = YB + XB;
-    constexpr int YI = YB / 1024 / 4, XI = XB / 1024 / 4;              // DMA instructions per wave and stage
+    constexpr int YI = YB / 1024 / NW, XI = XB / 1024 / NW;            // DMA instructions per wave and stage
+    static_assert(YI * 1024 * NW == YB && XI * 1024 * NW == XB, "tiles must split evenly over the waves' DMA instructions");
     static_assert(YI >= 1 && XI >= 1, "tile too small for one DMA instruction per wave");
     constexpr int LPS = YI + XI;
     constexpr int ST = 4;
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int wno = wave >> 1, wc = wave & 1;
+    const int wno = wave / WC, wc = wave % WC;
     const int r = lane & 31, h = lane >> 5;
     // transposing-read lane constants: 16-lane group g covers channels 16*(g&1).., pixels 8*(g>>1) + q (+4 for the high half)
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
@@ -926,9 +928,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a) {
 
 int g_wgrad_dma = 1;                                 // development knob (mte_debug_set(4, v))
 
-template <int TNO, int TC>
+int g_wgrad_big = 0;                                 // development knob (mte_debug_set(8, v)): 256 x 256 / 256 x 128 tiles -- measured slower
+                                                     // (0.5 ms per step: fewer pixel splits, 4x larger atomic epilogues), off
+
+template <int WNO, int WC, int TNO, int TC>
 int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
-    constexpr int BNO = 2 * TNO * 32, BC = 2 * TC * 32;
+    constexpr int BNO = WNO * TNO * 32, BC = WC * TC * 32, NTHR = WNO * WC * 64;
     a.tiles_n = (a.N + BNO - 1) / BNO;
     a.tiles_c = (a.Cin_p + BC - 1) / BC;
     const int taps = a.KH * a.KW;
@@ -936,7 +941,8 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
     const bool fl = a.W % 32 == 0 || a.W >= 160;
     const long nblk = fl ? (long)a.B * a.H * ((a.W + 31) / 32) : (a.M + 31) / 32;
     const long base_wgs = (long)a.tiles_n * a.tiles_c * taps;
-    long splits = (1024 + base_wgs - 1) / base_wgs;            // aim for >= ~4 workgroups per CU
+    const long want = 1024L * 256 / NTHR;                       // ~4 workgroups of 256 threads (or 1 of 1024) per CU
+    long splits = (want + base_wgs - 1) / base_wgs;
     const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -945,8 +951,8 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
     if (a.splits > 1 && hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
     const size_t lds = 4 * 32 * (BNO + BC) * 2;
     const dim3 grid((unsigned)(base_wgs * a.splits));
-    if (fl) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TNO, TC, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<TNO, TC, false>), grid, dim3(256), lds, st, a);
+    if (fl) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WNO, WC, TNO, TC, true>), grid, dim3(NTHR), lds, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WNO, WC, TNO, TC, false>), grid, dim3(NTHR), lds, st, a);
     return mte_check_launch();
 }
 
@@ -984,7 +990,12 @@ template <typename T> int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         const bool fits = ((a.M + a.KW) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((a.M - 1) * a.ldy + a.N) * 2 < 0x7ff00000L;
         if (g_wgrad_dma && fits && a.N > 32 && a.Cin_p > 32)
-            return a.N <= 64 ? launch_wgrad_dma<1, 2>(a, st) : launch_wgrad_dma<2, 2>(a, st);
+        {
+            if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p % 256 == 0) return launch_wgrad_dma<4, 4, 2, 2>(a, st);   // 256 x 256, 16 waves
+            if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p >= 128) return launch_wgrad_dma<4, 2, 2, 2>(a, st);     // 256 x 128, 8 waves
+            if (g_wgrad_big && a.N >= 128 && a.Cin_p % 256 == 0) return launch_wgrad_dma<2, 4, 2, 2>(a, st);     // 128 x 256, 8 waves
+            return a.N <= 64 ? launch_wgrad_dma<2, 2, 1, 2>(a, st) : launch_wgrad_dma<2, 2, 2, 2>(a, st);
+        }
     }
     if (a.N <= 32) {
         if (a.Cin_p <= 32) return launch_wgrad<T, 1, 4, 1, 1>(a, st);      // 32 x 128 would waste: 32 x (4*32)
@@ -1089,6 +1100,7 @@ int mte_debug_set(int key, int value) {
     if (key == 2 || key == 3) return mtei_set_gn(key - 2, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
+    if (key == 8) { g_wgrad_big = value; return MTE_OK; }
     if (key == 7) { g_igemm_big_min_tiles = value; return MTE_OK; }
     return MTE_ERR_ARG;
 }

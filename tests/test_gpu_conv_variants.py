@@ -111,7 +111,8 @@ def test_conv_epilogue_groupnorm_statistics(shape, dtype):
 
 WGRAD_SHAPES = [  # cin, cout, k, B, H, W — row-aligned blocks (W % 32 == 0, ragged W >= 160), flattened pixels, partial tiles
     (128, 128, 3, 2, 16, 64), (72, 96, 3, 2, 9, 40), (256, 64, 3, 1, 12, 32), (64, 128, 1, 3, 7, 24), (40, 256, 5, 1, 6, 168),
-    (512, 512, 3, 1, 8, 20), (136, 264, 3, 2, 5, 80), (64, 64, 7, 1, 9, 48),
+    (512, 512, 3, 1, 8, 20), (136, 264, 3, 2, 5, 80), (64, 64, 7, 1, 9, 48), (256, 256, 3, 2, 12, 32), (128, 256, 3, 2, 9, 40),
+    (256, 128, 3, 1, 6, 168), (512, 256, 1, 2, 10, 24),
 ]
 
 
@@ -122,11 +123,15 @@ def test_dma_wgrad_matches_register_staged_wgrad(shape):
     from mindtheedge_amd import kernels as K
     try:
         a = _run(*shape, patch=False)
+        K.lib.mte_debug_set(8, 1)                      # 8 / 16-wave tile instantiations (off by default)
+        big = _run(*shape, patch=False)
         K.lib.mte_debug_set(4, 0)
         r = _run(*shape, patch=False)
     finally:
         K.lib.mte_debug_set(4, 1)
+        K.lib.mte_debug_set(8, 0)
     assert rel_err(a["dw"], r["dw"]) < 2e-4
+    assert rel_err(big["dw"], r["dw"]) < 2e-4
     assert rel_err(a["y"], r["y"]) < 8e-3              # (forward split-K sums are order-dependent)
 
 
