@@ -928,6 +928,7 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
 
 int g_wgrad_dma = 1;                                 // development knob (mte_debug_set(4, v))
 
+int g_wgrad_wgs = 256;                               // development knob (mte_debug_set(9, v)): workgroups aimed for (pixel splits)
 int g_wgrad_big = 0;                                 // development knob (mte_debug_set(8, v)): 256 x 256 / 256 x 128 tiles -- measured slower
                                                      // (0.5 ms per step: fewer pixel splits, 4x larger atomic epilogues), off
 
@@ -941,7 +942,7 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
     const bool fl = a.W % 32 == 0 || a.W >= 160;
     const long nblk = fl ? (long)a.B * a.H * ((a.W + 31) / 32) : (a.M + 31) / 32;
     const long base_wgs = (long)a.tiles_n * a.tiles_c * taps;
-    const long want = 1024L * 256 / NTHR;                       // ~4 workgroups of 256 threads (or 1 of 1024) per CU
+    const long want = (long)g_wgrad_wgs * 256 / NTHR;           // ~4 workgroups of 256 threads (or 1 of 1024) per CU
     long splits = (want + base_wgs - 1) / base_wgs;
     const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
     if (splits > max_splits) splits = max_splits;
@@ -1101,6 +1102,7 @@ int mte_debug_set(int key, int value) {
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
     if (key == 8) { g_wgrad_big = value; return MTE_OK; }
+    if (key == 9) { g_wgrad_wgs = value; return MTE_OK; }
     if (key == 7) { g_igemm_big_min_tiles = value; return MTE_OK; }
     return MTE_ERR_ARG;
 }
