@@ -708,6 +708,7 @@ __device__ __forceinline__ bf16x8_t tr_operand(unsigned long long lo, unsigned l
     const u32x4_t c{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
     return __builtin_bit_cast(bf16x8_t, c);
 }
+constexpr int WG_RING = 4;        // LDS ring slots of the DMA wgrad kernel (3 was tried so that it co-resides with 96 KB main-stream workgroups: no gain)
 template <int CPRW> __device__ __forceinline__ int wg_swz(int row) { return CPRW >= 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
 
 template <int WNO, int WC, int TNO, int TC, bool FL>
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
     static_assert(YI * 1024 * NW == YB && XI * 1024 * NW == XB, "tiles must split evenly over the waves' DMA instructions");
     static_assert(YI >= 1 && XI >= 1, "tile too small for one DMA instruction per wave");
     constexpr int LPS = YI + XI;
-    constexpr int ST = 4;
+    constexpr int ST = WG_RING;                                       // LDS ring slots (ST - 1 stages in flight)
     constexpr unsigned OOB = 0xfffffff0u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -893,16 +894,19 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
     };
 
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < ST - 1; ++p)
         if (p < nst) dma_stage(p);
+    int slot = 0, fill = ST - 1;                                      // ring positions of the stage consumed / filled next
     for (int i = 0; i < nst; ++i) {
         const int rem = nst - 1 - i;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        if (ST == 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (i + 3 < nst) dma_stage((i + 3) & 3);
-        compute(i & 3);
+        if (i + ST - 1 < nst) dma_stage(fill);
+        compute(slot);
+        slot = slot + 1 == ST ? 0 : slot + 1;
+        fill = fill + 1 == ST ? 0 : fill + 1;
     }
 
     // ---- epilogue: D[row = cout][col = cin]; col = lane&31 -> contiguous fp32 in the staging buffer
@@ -950,7 +954,7 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
     a.blocks_per_split = (int)((nblk + splits - 1) / splits);
     a.splits = (int)((nblk + a.blocks_per_split - 1) / a.blocks_per_split);
     if (a.splits > 1 && hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
-    const size_t lds = 4 * 32 * (BNO + BC) * 2;
+    const size_t lds = WG_RING * 32 * (BNO + BC) * 2;
     const dim3 grid((unsigned)(base_wgs * a.splits));
     if (fl) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WNO, WC, TNO, TC, true>), grid, dim3(NTHR), lds, st, a);
     else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WNO, WC, TNO, TC, false>), grid, dim3(NTHR), lds, st, a);
