@@ -76,13 +76,17 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         }
     };
 
-    f32x16_t acc[2][NT];
+    // Wave -> sub-tile map.  NT = 1: wave w owns pixel rows 2w, 2w+1.  NT = 2: waves are split over the two 32-channel output
+    // tiles (n = w >> 1) and own four pixel rows each: a wave then fetches half of the slice's weight fragments from L2
+    // (every wave reading all of them made weight traffic, 1.1 GB per 64->64 launch, ~9x the activation traffic).
+    constexpr int MM = NT == 2 ? 4 : 2;
+    const int nsel = NT == 2 ? wave >> 1 : 0;
+    const int mrow0 = NT == 2 ? (wave & 1) * 4 : wave * 2;
+    f32x16_t acc[MM];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MM; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
     load_patch(0);
     store_patch(0);
@@ -94,13 +98,11 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         const u32x4_t* wsl = wl + (long)s * TAPS * 2 * NT * 64;
         // weight fragments come straight from L2 (hundreds of cycles): keep PD taps in flight in a register ring
         constexpr int PD = TAPS < 4 ? TAPS : 4;
-        u32x4_t bq[PD][2][NT];
+        u32x4_t bq[PD][2];
 #pragma unroll
         for (int d = 0; d < PD; ++d)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bq[d][kk][n] = wsl[((d * 2 + kk) * NT + n) * 64];
+            for (int kk = 0; kk < 2; ++kk) bq[d][kk] = wsl[((d * 2 + kk) * NT + nsel) * 64];
 #pragma unroll 1
         for (int t0 = 0; t0 < TAPS; t0 += PD) {
 #pragma unroll
@@ -108,26 +110,22 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
                 const int t = t0 + d;
                 if (t < TAPS) {                                    // wave-uniform
                     const int dy = t / K, dx = t - dy * K;
-                    u32x4_t fa[2][2];
+                    u32x4_t fa[MM][2];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const int p = (wave * 2 + m + dy) * PW + dx + r;
+                    for (int m = 0; m < MM; ++m) {
+                        const int p = (mrow0 + m + dy) * PW + dx + r;
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
                     }
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < MM; ++m)
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]),
-                                                                                    __builtin_bit_cast(bf16x8_t, bq[d][kk][n]), acc[m][n], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]),
+                                                                             __builtin_bit_cast(bf16x8_t, bq[d][kk]), acc[m], 0, 0, 0);
                     if (t + PD < TAPS) {
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n) bq[d][kk][n] = wsl[(((t + PD) * 2 + kk) * NT + n) * 64];
+                        for (int kk = 0; kk < 2; ++kk) bq[d][kk] = wsl[(((t + PD) * 2 + kk) * NT + nsel) * 64];
                     }
                 }
             }
@@ -139,16 +137,15 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int NB = NT * 64;                                    // bytes per pixel
     float* s_gn = (float*)(smem + LDS_BYTES - 128);
     if (a.gn_stats && tid < 32) s_gn[tid] = 0.f;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int ch = n * 32 + r;
+    {
+        const int ch = nsel * 32 + r;
         const float bv = (a.bias && ch < a.N) ? a.bias[ch] : 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MM; ++m)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int px = (e & 3) + 8 * (e >> 2) + 4 * h;
-                *(bf16_t*)(smem + ((wave * 2 + m) * TW + px) * NB + ch * 2) = f2bf(acc[m][n][e] + bv);
+                *(bf16_t*)(smem + ((mrow0 + m) * TW + px) * NB + ch * 2) = f2bf(acc[m][e] + bv);
             }
     }
     __syncthreads();
