@@ -933,8 +933,8 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
 int g_wgrad_dma = 1;                                 // development knob (mte_debug_set(4, v))
 
 int g_wgrad_wgs = 256;                               // development knob (mte_debug_set(9, v)): workgroups aimed for (pixel splits)
-int g_wgrad_big = 0;                                 // development knob (mte_debug_set(8, v)): 256 x 256 / 256 x 128 tiles -- measured slower
-                                                     // (0.5 ms per step: fewer pixel splits, 4x larger atomic epilogues), off
+int g_wgrad_big = 1;                                 // development knob (mte_debug_set(8, v)): 256 x 256 / 256 x 128 / 128 x 256 tiles
+                                                     // (4x fewer re-reads of dy / x; pays once the pixel splits are few: g_wgrad_wgs)
 
 template <int WNO, int WC, int TNO, int TC>
 int launch_wgrad_dma(WgradArgs a, hipStream_t st) {

@@ -123,13 +123,13 @@ def test_dma_wgrad_matches_register_staged_wgrad(shape):
     from mindtheedge_amd import kernels as K
     try:
         a = _run(*shape, patch=False)
-        K.lib.mte_debug_set(8, 1)                      # 8 / 16-wave tile instantiations (off by default)
+        K.lib.mte_debug_set(8, 0)                      # 4-wave 128x128 tiles only
         big = _run(*shape, patch=False)
         K.lib.mte_debug_set(4, 0)
         r = _run(*shape, patch=False)
     finally:
         K.lib.mte_debug_set(4, 1)
-        K.lib.mte_debug_set(8, 0)
+        K.lib.mte_debug_set(8, 1)
     assert rel_err(a["dw"], r["dw"]) < 2e-4
     assert rel_err(big["dw"], r["dw"]) < 2e-4
     assert rel_err(a["y"], r["y"]) < 8e-3              # (forward split-K sums are order-dependent)

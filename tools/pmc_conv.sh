@@ -3,7 +3,7 @@
 mkdir -p gpurun_out; rm -rf gpurun_out/pmc1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-  --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc1 -- python3 $GRAFT_REPO_ROOT/tools/conv_probe.py "$@" 3 nopatch > $GRAFT_REPO_ROOT/gpurun_out/pmc1.txt 2>&1
+  --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc1 -- python3 $GRAFT_REPO_ROOT/tools/conv_probe.py "$@" 3 ${PATCHMODE:-nopatch} > $GRAFT_REPO_ROOT/gpurun_out/pmc1.txt 2>&1
 cd $GRAFT_REPO_ROOT
 tail -2 gpurun_out/pmc1.txt
 python3 - <<'PY'

@@ -17,14 +17,14 @@ def family(name):
     return "other"
 
 
-def load(d, counter):
+def load(d, counter, by_kernel=False):
     out = defaultdict(lambda: [0, 0.0])
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     for f in files:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            e = out[family(r["Kernel_Name"])]
+            e = out[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60] if by_kernel else family(r["Kernel_Name"])]
             e[0] += 1
             e[1] += float(r["Counter_Value"])
     return out
@@ -41,3 +41,11 @@ for fam in sorted(set(F) | set(W), key=lambda k: -(2 * F[k][1] + W[k][1])):
     tot_w += w
     print("%-28s %10.1f %12.1f %12.1f %12.1f" % (fam, max(F[fam][0], W[fam][0]) / steps, r, w, r + w))
 print("%-28s %10s %12.1f %12.1f %12.1f" % ("all kernels", "", tot_r, tot_w, tot_r + tot_w))
+
+print()
+print("# the same per kernel (top 40 by total bytes)")
+Fk, Wk = load(sys.argv[1], "FETCH_SIZE", True), load(sys.argv[2], "WRITE_SIZE", True)
+for k in sorted(set(Fk) | set(Wk), key=lambda k: -(2 * Fk[k][1] + Wk[k][1]))[:40]:
+    r = 2.0 * Fk[k][1] * 1024 / steps / 1e6
+    w = Wk[k][1] * 1024 / steps / 1e6
+    print("%-62s %8.1f %10.1f %10.1f" % (k, max(Fk[k][0], Wk[k][0]) / steps, r, w))
