@@ -766,6 +766,65 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds_kernel(P3LArgs a) {
     }
 }
 
+// Same operator, all four feature planes of the shuffled gradient staged at once (C <= 128, where the tensors are large):
+// the plane-by-plane kernel above touches every 64..256-byte pixel record of dout in four separate sweeps, and by the time a
+// block comes back for the next plane the record has left L2 -- measured 3.4 GB fetched per step for 0.49 GB of dout.
+// The x-tile is four times smaller instead (TH*TW*C = 4096, one 16-depth item per thread) so the four planes fit the
+// same ~46-61 KB of LDS.
+inline P3Tile up4_tile(int C) {
+    if (C <= 32) return {8, 16};
+    if (C <= 64) return {4, 16};
+    return {4, 8};
+}
+inline size_t up4_lds_bytes(int C) { P3Tile t = up4_tile(C); return (size_t)4 * (t.TH + 2) * (t.TW + 2) * C * 2; }
+
+__global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)smem_;
+    __shared__ float sw[108];
+    if (threadIdx.x < 108) sw[threadIdx.x] = a.w3[threadIdx.x];
+    int b, h0, w0;
+    up_tile_coords(a, blockIdx.x, b, h0, w0);
+    const int D = a.C, cbs = a.C >> 4, PW = a.TW + 2;
+    const int plane = (a.TH + 2) * PW * D;              // elements of one staged feature plane
+    P3LArgs t = a;                                      // plane staging view of dout
+    t.ldx = a.ldo; t.C = a.C >> 2; t.H = 2 * a.H; t.W = 2 * a.W;
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {                       // four sweeps over the SAME records back to back: the re-reads hit L2
+        t.x = a.o + f * (a.C >> 2);
+        stage_packed_tile(t, tile + f * plane, b, h0, w0);
+    }
+    __syncthreads();
+    const int it = threadIdx.x;
+    const int cb = it % cbs; const int p = it / cbs;
+    const int pw = p % a.TW, ph = p / a.TW;
+    if (ph >= a.TH) return;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll 1
+        for (int tp = 0; tp < 9; ++tp) {
+            const int kh = tp / 3, kw = tp - 3 * kh;
+            float pv[18];
+            lds_window<2>(tile + f * plane, (ph + 2 - kh) * PW + pw + 2 - kw, D, 16 * cb, pv);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float wv = sw[((f * 3 + kd) * 3 + kh) * 3 + kw];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = fmaf(wv, pv[i + 2 - kd], acc[i]);
+            }
+        }
+    }
+    const int h = h0 + ph, w = w0 + pw;
+    if (h < a.H && w < a.W) {
+        bf16_t* dp = a.dst + (((long)b * a.H + h) * a.W + w) * a.lddst + 16 * cb;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *(u32x4_t*)(dp + 8 * j) = pack16<bf16_t>(&acc[8 * j]);
+    }
+}
+
 // dw3/db3 for UNPACK: x tile staged directly; the 8 feature gradients of an item are gathered from the shuffled dout
 __global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -865,7 +924,7 @@ inline P3LArgs p3l_args(int B, int H, int W, int C) {
     return a;
 }
 
-int g_p3_lds = 1;                                   // development knob (mte_debug_set(1, v))
+int g_p3_lds = 2;                                   // development knob (mte_debug_set(1, v))
 
 }  // namespace
 
@@ -933,6 +992,13 @@ int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx,
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
+    if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && C % 32 == 0 && C <= 128) {
+        P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;
+        const P3Tile t = up4_tile(C); l.TH = t.TH; l.TW = t.TW;
+        l.tiles_h = (H + t.TH - 1) / t.TH; l.tiles_w = (W + t.TW - 1) / t.TW; l.ntiles = l.tiles_h * l.tiles_w * B;
+        l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
+        return launch_p3l(unpack3d_bwd_data_lds4_kernel, l, l.ntiles, stream, up4_lds_bytes(C));
+    }
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 32 == 0 && C <= 512) {
         P3LArgs l = upl_args(B, H, W, C); l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
         return launch_p3l(unpack3d_bwd_data_lds_kernel, l, l.ntiles, stream, up_lds_bytes(C));
