@@ -1,0 +1,123 @@
+"""GPU (-m gpu): properties at BASELINE.json's full resolution (384x1280), where the oracle is too slow to be the checker.
+
+* batch independence: GroupNorm is per sample and nothing else couples the frames of a batch, so frame i of a 3-frame
+  batch must give the same inverse depths as frame i alone (different tile<->sample alignment, statistics atomics and
+  kernel variants per launch, same arithmetic);
+* the bf16 benchmark mode against the fp32 validation mode of the same kernels on a full training step (loss scalars to
+  the north-star's 1e-3, gradient energy to bf16 tolerance);
+* the LDS-patch conv family against the generic implicit GEMM on a full training step;
+* the weight-gradient side stream against single-stream execution (the schedule must not change the result)."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+H, W = 384, 1280
+
+
+def _model(dtype, dropout=None):
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
+    from mindtheedge_amd.models.SemiSupEdgeModel import SemiSupEdgeModel
+    from mindtheedge_amd.losses.grad_loss import GradLoss
+    K.set_compute_dtype(dtype)
+    torch.manual_seed(7)
+    net = PackNetSAN01(dropout=dropout, version="1A").cuda()
+    model = SemiSupEdgeModel(supervised_loss_weight=1.0, depth_edges_loss_weight=1.0, supervised_method="sparse-silog",
+                             supervised_num_scales=1, edges_depth_edge_loss_all_scales=True, flip_lr_prob=0.0)
+    model.add_depth_net(net)
+    model.add_edge_loss(GradLoss("cross_entropy", True, [], 10.0, 1.0))
+    return net, model
+
+
+def _batch(B, seed=11):
+    from mindtheedge_amd.utils.synthetic import synthetic_batch
+    return synthetic_batch(B, H, W, seed, torch.device("cuda"))
+
+
+def _step(dtype, batch, patch=True, side=True):
+    from mindtheedge_amd import kernels as K
+    K.use_patch_kernels(patch)
+    K.use_wgrad_side_stream(side)
+    K.set_grad_sink(None)
+    try:
+        net, model = _model(dtype)
+        model.train()
+        out = model(batch)
+        out["loss"].sum().backward()
+        K.join_side_stream()
+        torch.cuda.synchronize()
+        gsq = {n: float((p.grad.double() ** 2).sum()) for n, p in net.named_parameters() if p.grad is not None}
+        return float(out["loss"].detach().sum()), {k: float(v) for k, v in out["metrics"].items()}, gsq
+    finally:
+        K.use_patch_kernels(True)
+        K.use_wgrad_side_stream(True)
+        K.set_compute_dtype("bf16")
+
+
+def test_frames_of_a_batch_are_independent_at_full_size():
+    from mindtheedge_amd import kernels as K
+    try:
+        net, _ = _model("bf16")
+        net.eval()
+        rgb = _batch(3)["rgb"]
+        with torch.no_grad():
+            full = [t.clone() for t in net(rgb)["inv_depths"][0]]
+            for i in (0, 2):
+                one = net(rgb[i:i + 1])["inv_depths"][0]
+                for s in range(4):
+                    assert tuple(one[s].shape) == (1, 1, H >> s, W >> s)
+                    # same bf16 products; only the order of the GroupNorm statistics sums and the split-K / tile
+                    # alignment differ between the two launches
+                    assert rel_err(one[s].float().cpu(), full[s][i:i + 1].float().cpu()) < 2e-2, (i, s)
+                    assert float((one[s] - full[s][i:i + 1]).abs().mean()) < 8e-3 * float(full[s][i:i + 1].abs().mean())   # ~2 bf16 ulp
+    finally:
+        K.set_compute_dtype("bf16")
+
+
+def test_full_size_training_step_bf16_vs_fp32_and_kernel_families():
+    batch = _batch(1)
+    l32, m32, g32 = _step("fp32", batch)
+    l16, m16, g16 = _step("bf16", batch)
+    assert abs(l16 - l32) <= 1e-3 * abs(l32)                                   # north-star tolerance on the loss scalar
+    for k in ("edge_loss", "supervised_loss"):
+        assert abs(m16[k] - m32[k]) <= 2e-3 * abs(m32[k]), k
+    tot32, tot16 = sum(g32.values()), sum(g16.values())
+    assert abs(tot16 - tot32) <= 0.05 * tot32                                  # gradient energy, bf16 storage of ~60 layers
+    # LDS-patch conv family vs generic implicit GEMM (bf16, same products)
+    lg, _, gg = _step("bf16", batch, patch=False)
+    assert abs(lg - l16) <= 2e-4 * abs(l16)
+    assert abs(sum(gg.values()) - tot16) <= 0.02 * tot16
+
+
+def test_full_size_side_stream_schedule_does_not_change_gradients():
+    """fp32 mode + gradient sink: the weight-gradient side stream only moves kernels in time."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.trainers.data_parallel import FlatParameters
+    batch = _batch(1)
+
+    def run(side):
+        K.use_wgrad_side_stream(side)
+        K.set_grad_sink(None)
+        try:
+            net, model = _model("fp32")
+            model.train()
+            flat = FlatParameters(net.parameters())
+            flat.zero_grad()
+            loss = model(batch)["loss"].sum()
+            loss.backward()
+            K.join_side_stream()
+            torch.cuda.synchronize()
+            return float(loss.detach()), flat.grad.clone()
+        finally:
+            K.use_wgrad_side_stream(True)
+            K.set_grad_sink(None)
+            K.set_compute_dtype("bf16")
+
+    la, ga = run(True)
+    lb, gb = run(False)
+    assert la == pytest.approx(lb, rel=1e-6)
+    assert float((ga - gb).norm()) <= 1e-3 * float(gb.norm())
+    assert float(gb.norm()) > 0
