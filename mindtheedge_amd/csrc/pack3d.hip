@@ -469,14 +469,25 @@ bool p3_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <=
 namespace {
 
 struct P3Tile { int TH, TW; };
+int g_p3_small_tiles = 1;                            // development knob (mte_debug_set(12, v))
 inline P3Tile p3_tile(int C) {
+    if (g_p3_small_tiles) {
+        if (C <= 32) return {4, 16};
+        if (C <= 64) return {4, 8};
+        if (C <= 128) return {2, 8};
+        if (C <= 256) return {2, 4};
+        return {2, 2};
+    }
     if (C <= 32) return {8, 16};
     if (C <= 64) return {4, 16};
     if (C <= 128) return {4, 8};
     if (C <= 256) return {2, 8};
     return {2, 4};
 }
-inline size_t p3_lds_bytes(int C) { P3Tile t = p3_tile(C); return (size_t)(t.TH + 2) * (t.TW + 2) * 4 * C * 2; }
+// LDS tiles keep 8 pad elements (16 B) after the D depths of every pixel: with a power-of-two pixel stride the 16-byte window
+// reads of a wave (64..1024 B apart) fall on a few banks only -- SQ_LDS_BANK_CONFLICT was 47-84 % of the LDS-active cycles.
+#define LDP(D) ((D) + 8)
+inline size_t p3_lds_bytes(int C) { P3Tile t = p3_tile(C); return (size_t)(t.TH + 2) * (t.TW + 2) * LDP(4 * C) * 2; }
 
 struct P3LArgs {
     const bf16_t* x; long ldx;         // un-packed side [B,H,W,C]
@@ -500,7 +511,7 @@ __device__ __forceinline__ void stage_packed_tile(const P3LArgs& a, bf16_t* tile
         u32x4_t v = {0u, 0u, 0u, 0u};
         if ((unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2)
             v = *(const u32x4_t*)(a.x + (((long)b * a.H + 2 * hh + (py & 1)) * a.W + 2 * ww + (px & 1)) * a.ldx + cc * 8);
-        bf16_t* dstp = tile + ((py >> 1) * (a.TW + 2) + (px >> 1)) * D + 32 * cc + ((py & 1) * 2 + (px & 1));
+        bf16_t* dstp = tile + ((py >> 1) * (a.TW + 2) + (px >> 1)) * LDP(D) + 32 * cc + ((py & 1) * 2 + (px & 1));
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dstp[8 * i] = (bf16_t)(v[i] & 0xffffu); dstp[8 * i + 4] = (bf16_t)(v[i] >> 16); }
     }
@@ -509,7 +520,7 @@ __device__ __forceinline__ void stage_packed_tile(const P3LArgs& a, bf16_t* tile
 // window of NB*8 depths + 1 halo each side at tile pixel `pix`, depth d0 -> pv[0 .. NB*8+1]
 template <int NB>
 __device__ __forceinline__ void lds_window(const bf16_t* tile, int pix, int D, int d0, float* pv) {
-    const bf16_t* p = tile + pix * D + d0;
+    const bf16_t* p = tile + pix * LDP(D) + d0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) unpack16<bf16_t>(*(const u32x4_t*)(p + 8 * k), &pv[1 + 8 * k]);
     pv[0] = d0 > 0 ? bf2f(p[-1]) : 0.f;
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(256) void pack3d_bwd_data_lds_kernel(P3LArgs a) {
             u32x4_t v = {0u, 0u, 0u, 0u};
             if ((unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2)
                 v = *(const u32x4_t*)(a.o + (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + dc * 8);
-            *(u32x4_t*)(tile + p * D + dc * 8) = v;
+            *(u32x4_t*)(tile + p * LDP(D) + dc * 8) = v;
         }
         __syncthreads();
 #pragma unroll
@@ -703,7 +714,7 @@ inline P3Tile up_tile(int C) {                       // TH*TW*C = 16384 (2 items
     if (C <= 256) return {4, 16};
     return {4, 8};
 }
-inline size_t up_lds_bytes(int C) { P3Tile t = up_tile(C); return (size_t)(t.TH + 2) * (t.TW + 2) * C * 2; }
+inline size_t up_lds_bytes(int C) { P3Tile t = up_tile(C); return (size_t)(t.TH + 2) * (t.TW + 2) * LDP(C) * 2; }
 
 __device__ __forceinline__ void up_tile_coords(const P3LArgs& a, int tile, int& b, int& h0, int& w0) {
     const int tw = tile % a.tiles_w; int t = tile / a.tiles_w;
@@ -776,7 +787,7 @@ inline P3Tile up4_tile(int C) {
     if (C <= 64) return {4, 16};
     return {4, 8};
 }
-inline size_t up4_lds_bytes(int C) { P3Tile t = up4_tile(C); return (size_t)4 * (t.TH + 2) * (t.TW + 2) * C * 2; }
+inline size_t up4_lds_bytes(int C) { P3Tile t = up4_tile(C); return (size_t)4 * (t.TH + 2) * (t.TW + 2) * LDP(C) * 2; }
 
 __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -786,7 +797,7 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) 
     int b, h0, w0;
     up_tile_coords(a, blockIdx.x, b, h0, w0);
     const int D = a.C, cbs = a.C >> 4, PW = a.TW + 2;
-    const int plane = (a.TH + 2) * PW * D;              // elements of one staged feature plane
+    const int plane = (a.TH + 2) * PW * LDP(D);         // elements of one staged feature plane
     P3LArgs t = a;                                      // plane staging view of dout
     t.ldx = a.ldo; t.C = a.C >> 2; t.H = 2 * a.H; t.W = 2 * a.W;
 #pragma unroll 1
@@ -845,7 +856,7 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a)
             u32x4_t v = {0u, 0u, 0u, 0u};
             if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W)
                 v = *(const u32x4_t*)(a.x + (((long)b * a.H + hh) * a.W + ww) * a.ldx + dc * 8);
-            *(u32x4_t*)(tile + p * D + dc * 8) = v;
+            *(u32x4_t*)(tile + p * LDP(D) + dc * 8) = v;
         }
         __syncthreads();
 #pragma unroll 1
@@ -897,9 +908,11 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a)
         atomicAdd(a.dwb + threadIdx.x, sred[threadIdx.x] + sred[112 + threadIdx.x] + sred[224 + threadIdx.x] + sred[336 + threadIdx.x]);
 }
 
-inline P3LArgs upl_args(int B, int H, int W, int C) {
+inline P3LArgs upl_args(int B, int H, int W, int C, bool half_tile = false) {
     P3LArgs a{}; a.B = B; a.H = H; a.W = W; a.C = C;
-    const P3Tile t = up_tile(C); a.TH = t.TH; a.TW = t.TW;
+    P3Tile t = up_tile(C);
+    if (half_tile && t.TH >= 4) t.TH /= 2;               // kernels with generic item loops: half the LDS, twice the resident blocks
+    a.TH = t.TH; a.TW = t.TW;
     a.tiles_h = (H + t.TH - 1) / t.TH; a.tiles_w = (W + t.TW - 1) / t.TW; a.ntiles = a.tiles_h * a.tiles_w * B;
     return a;
 }
@@ -928,7 +941,7 @@ int g_p3_lds = 2;                                   // development knob (mte_deb
 
 }  // namespace
 
-extern "C" int mtei_set_pack3d_lds(int value) { g_p3_lds = value; return MTE_OK; }
+extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
 
 
 extern "C" {
@@ -1013,8 +1026,10 @@ int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo,
     if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 32 == 0 && C <= 512) {
-        P3LArgs l = upl_args(B, H, W, C); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;
-        return launch_p3l(unpack3d_bwd_weight_lds_kernel, l, l.ntiles < 512 ? l.ntiles : 512, stream, up_lds_bytes(C));
+        P3LArgs l = upl_args(B, H, W, C, g_p3_small_tiles != 0); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;
+        const size_t lds = (size_t)(l.TH + 2) * (l.TW + 2) * LDP(C) * 2;
+        const int cap = g_p3_small_tiles ? 1024 : 512;
+        return launch_p3l(unpack3d_bwd_weight_lds_kernel, l, l.ntiles < cap ? l.ntiles : cap, stream, lds);
     }
     a.total = (long)B * H * W * (C / 8);
     long threads = a.total < 256L * 2048 ? a.total : 256L * 2048;
