@@ -932,7 +932,7 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
 
 int g_wgrad_dma = 1;                                 // development knob (mte_debug_set(4, v))
 
-int g_wgrad_wgs = 256;                               // development knob (mte_debug_set(9, v)): workgroups aimed for (pixel splits)
+int g_wgrad_wgs = 512;                               // development knob (mte_debug_set(9, v)): workgroups aimed for (pixel splits)
 int g_wgrad_big = 1;                                 // development knob (mte_debug_set(8, v)): 256 x 256 / 256 x 128 / 128 x 256 tiles
                                                      // (4x fewer re-reads of dy / x; pays once the pixel splits are few: g_wgrad_wgs)
 
