@@ -881,6 +881,7 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
 #pragma unroll
             for (int j = 0; j < TC; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(y0[i][0], y0[i][1]), tr_operand(x0[j][0], x0[j][1]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);            // keep the first k16 step's MFMAs ahead of the wait for the second step's reads
         if constexpr (TNO == 2)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y1[0][0]), "+v"(y1[0][1]), "+v"(y1[TNO - 1][0]), "+v"(y1[TNO - 1][1]),
                          "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]));
