@@ -52,16 +52,26 @@ __global__ __launch_bounds__(256) void invdepth_fwd_kernel(HeadArgs a) {
         const bool live = pixl < a.npix;
         const long pix = live ? pixl : a.npix - 1;
         const int x = (int)(pix % a.W); const long t2 = pix / a.W; const int y = (int)(t2 % a.H);
-        float acc = 0.f;
+        // all nine 16-byte loads are issued before the first multiply (clamped addresses, out-of-image taps masked afterwards)
+        u32x4_t raw[9];
+        bool ok[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-                float v[8];
-                ld8<T>((const T*)a.x + (pix + (long)(t / 3 - 1) * a.W + (t % 3 - 1)) * a.ldx + c0, v);
+            ok[t] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const long q = ok[t] ? pix + (long)(t / 3 - 1) * a.W + (t % 3 - 1) : pix;
+            if constexpr (sizeof(T) == 2) raw[t] = *(const u32x4_t*)((const T*)a.x + q * a.ldx + c0);
+        }
+        float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc = fmaf(v[i], wr[t][i], acc);
-            }
+        for (int t = 0; t < 9; ++t) {
+            float v[8];
+            if constexpr (sizeof(T) == 2) unpack16<T>(raw[t], v);
+            else ld8<T>((const T*)a.x + (ok[t] ? pix + (long)(t / 3 - 1) * a.W + (t % 3 - 1) : pix) * a.ldx + c0, v);
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part = fmaf(v[i], wr[t][i], part);
+            acc += ok[t] ? part : 0.f;
         }
         for (int o = cb >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (live && j == 0) a.out[pix] = a.inv_min_depth / (1.f + __expf(-(acc + bias)));
