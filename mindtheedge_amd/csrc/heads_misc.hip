@@ -157,28 +157,33 @@ __global__ __launch_bounds__(256) void invdepth_bwd_weight_kernel(HeadArgs a) {
 #pragma unroll 1
     for (long base = blockIdx.x * ppb + threadIdx.x / cb; base < a.npix; base += stride * U) {
         u32x4_t xr[U];
+        float dl[U][9];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U; ++u) {                              // every load of the batch first: activations and logit gradients
             const long pix = base + u * stride;
-            if constexpr (sizeof(T) == 2) { if (pix < a.npix) xr[u] = *(const u32x4_t*)((const T*)a.x + pix * a.ldx + c0); }
+            if (pix < a.npix) {
+                if constexpr (sizeof(T) == 2) xr[u] = *(const u32x4_t*)((const T*)a.x + pix * a.ldx + c0);
+                const int x = (int)(pix % a.W); const int y = (int)((pix / a.W) % a.H);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int oy = t / 3 - 1, ox = t % 3 - 1;
+                    const bool ok = (unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W;
+                    dl[u][t] = ok ? a.dlogit[pix - (long)oy * a.W - ox] : 0.f;
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long pix = base + u * stride;
             if (pix >= a.npix) break;
-            const int x = (int)(pix % a.W); const int y = (int)((pix / a.W) % a.H);
             float v[8];
             if constexpr (sizeof(T) == 2) unpack16<T>(xr[u], v);
             else ld8<T>((const T*)a.x + pix * a.ldx + c0, v);            // fp32 validation mode: 8 channels = two chunks
+            if (j == 0) gb += dl[u][4];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int oy = t / 3 - 1, ox = t % 3 - 1;
-                const bool ok = (unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W;
-                const float d = ok ? a.dlogit[pix - (long)oy * a.W - ox] : 0.f;
-                if (t == 4 && j == 0) gb += d;
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(d, v[i], gw[t][i]);
-            }
+                for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(dl[u][t], v[i], gw[t][i]);
         }
     }
 #pragma unroll
