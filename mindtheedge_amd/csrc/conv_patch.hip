@@ -208,7 +208,8 @@ struct PatchWgradArgs {
 template <int K, int NT, int SL>
 __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a) {
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
-    constexpr int TPW = (TAPS + 3) / 4;                            // taps per wave
+    constexpr int UNITS = TAPS * SL;                               // (tap, slice) accumulator units, dealt round-robin to the 4 waves
+    constexpr int TPW = (UNITS + 3) / 4;                           // (dealing whole taps left 3x3 layers at 3:2:2:2 -- 25 % of the MFMA slots idle)
     constexpr int XRS = SL == 1 ? 64 : 192;                        // x / dy pixel row strides: odd multiples of 64 B
     constexpr int XCH = PH * PW * 4 * SL, NXC = (XCH + 255) / 256;
     constexpr int YRS = NT == 1 ? 64 : 192;
@@ -269,15 +270,13 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
         }
     };
 
-    f32x16_t acc[TPW][SL][NT];
+    f32x16_t acc[TPW][NT];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
-        for (int sl = 0; sl < SL; ++sl)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][sl][n][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
 
     // transposing-read lane roles: 16-lane group g: channels 16*(g&1) + 4p.., pixels 8*(g>>1) + q (+4 for the 2nd read)
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
@@ -304,21 +303,19 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const int tap = wave + 4 * i;
-                    if (tap < TAPS) {
+                    const int u = wave + 4 * i;
+                    if (u < UNITS) {
+                        const int tap = u / SL, sl = u - tap * SL;
                         const int dyy = tap / K, dxx = tap - dyy * K;
+                        const char* base = X + ((row + dyy) * PW + col0 + dxx + pxb) * XRS + sl * 64 + chb * 2;
+                        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * XRS));
+                        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                        const u32x4_t fx = u32x4_t{l2.x, l2.y, h2.x, h2.y};
 #pragma unroll
-                        for (int sl = 0; sl < SL; ++sl) {
-                            const char* base = X + ((row + dyy) * PW + col0 + dxx + pxb) * XRS + sl * 64 + chb * 2;
-                            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
-                            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * XRS));
-                            uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                            const u32x4_t fx = u32x4_t{l2.x, l2.y, h2.x, h2.y};
-#pragma unroll
-                            for (int n = 0; n < NT; ++n)
-                                acc[i][sl][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[n]),
-                                                                                       __builtin_bit_cast(bf16x8_t, fx), acc[i][sl][n], 0, 0, 0);
-                        }
+                        for (int n = 0; n < NT; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[n]),
+                                                                                __builtin_bit_cast(bf16x8_t, fx), acc[i][n], 0, 0, 0);
                     }
                 }
             }
@@ -327,22 +324,19 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
     // D[row = cout][col = cin]: col = lane&31 -> contiguous fp32 in the stage
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int sl = 0; sl < SL; ++sl) {
+    for (int i = 0; i < TPW; ++i) {
+        const int u = wave + 4 * i;
+        if (u >= UNITS) continue;
+        const int tap = u / SL, sl = u - tap * SL;
         const int cc = (slice * SL + sl) * 32 + r;
         if (cc >= a.Cin_p) continue;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int tap = wave + 4 * i;
-            if (tap < TAPS) {
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int co = n * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (co < a.N) atomicAdd(a.dw + ((long)co * TAPS + tap) * a.Cin_p + cc, acc[i][sl][n][e]);
-                    }
+            for (int e = 0; e < 16; ++e) {
+                const int co = n * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < a.N) atomicAdd(a.dw + ((long)co * TAPS + tap) * a.Cin_p + cc, acc[i][n][e]);
             }
-        }
     }
 }
 
