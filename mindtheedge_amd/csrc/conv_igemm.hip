@@ -1053,12 +1053,23 @@ __global__ __launch_bounds__(256) void pack_weights_bwd_kernel(const T* __restri
     }
 }
 
-// staging [N][taps][Cin_p] fp32 -> OIHW fp32 gradient (overwrite)
-__global__ void unpack_wgrad_kernel(const float* __restrict__ st, float* __restrict__ dw, int Cout, int Cin, int taps, int Cin_p) {
-    const long n = (long)Cout * Cin * taps;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % taps); long t = i / taps; const int c = (int)(t % Cin); const int o = (int)(t / Cin);
-        dw[i] = st[((long)o * taps + tap) * Cin_p + c];
+// staging [N][taps][Cin_p] fp32 -> OIHW fp32 gradient (overwrite).  One block = (output channel n, 64 input channels): the
+// [taps][64] slab is read along c (coalesced), transposed in LDS and written as one contiguous run of 64*taps floats.
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ st, float* __restrict__ dw, int Cout, int Cin, int taps, int Cin_p) {
+    extern __shared__ float s_t[];                                   // [taps][64 + 1]
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    const int nc = min(64, Cin - c0);
+    if (nc <= 0) return;
+    const float* src = st + (long)n * taps * Cin_p + c0;
+    for (int i = threadIdx.x; i < taps * 64; i += 256) {
+        const int tap = i >> 6, cl = i & 63;
+        if (cl < nc) s_t[tap * 65 + cl] = src[(long)tap * Cin_p + cl];
+    }
+    __syncthreads();
+    float* dst = dw + ((long)n * Cin + c0) * taps;
+    for (int i = threadIdx.x; i < nc * taps; i += 256) {
+        const int cl = i / taps, tap = i - cl * taps;
+        dst[i] = s_t[tap * 65 + cl];
     }
 }
 
@@ -1172,9 +1183,8 @@ int mte_pack_conv_weights_bwd(const void* wfwd, void* wbwd, int Cout, int KH, in
 int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dw_stage || !dw_oihw) return MTE_ERR_ARG;
-    const long n = (long)Cout * Cin * KH * KW;
-    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, stream, dw_stage, dw_oihw, Cout, Cin, KH * KW, Cin_p);
+    const dim3 grid(Cout, (Cin + 63) / 64);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, grid, dim3(256), sizeof(float) * KH * KW * 65, stream, dw_stage, dw_oihw, Cout, Cin, KH * KW, Cin_p);
     return mte_check_launch();
 }
 
