@@ -444,14 +444,17 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         const long tiles_big = ((a.M + 255) / 256) * ((a.N + 127) / 128);
         const bool dma_ok = g_igemm_dma == 1 && a.Cin_p % 32 == 0 && ((a.M - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L &&
                             (long)a.N * a.KH * a.KW * a.Cin_p * 2 < 0x7ff00000L;
-        if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N % 256 == 0 &&
-            ((a.M + 255) / 256) * (a.N / 256) >= g_igemm_big_min_tiles)
+        // (odd widths -- 72 / 104 / 200 input channels of the decoder concats as data-gradient N -- take the tile that covers
+        //  them in ONE column block: the padded columns cost the same MFMA work as two narrower blocks, A is read once)
+        const long n256 = (a.N + 255) / 256;
+        if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
+            ((a.M + 255) / 256) * n256 >= g_igemm_big_min_tiles)
             return launch_igemm<T, 4, 4, 2, 2>(a, 0, st, stats_done);                  // 256 x 256, 16 waves
-        if (g_igemm_big && dma_ok && !a.out_f32 && a.N % 128 == 0 && tiles_big >= g_igemm_big_min_tiles)
+        if (g_igemm_big && dma_ok && !a.out_f32 && a.N > 64 && tiles_big >= g_igemm_big_min_tiles)
             return launch_igemm<T, 4, 2, 2, 2>(a, 0, st, stats_done);
     }
     if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st, stats_done);       // 128 x 32
-    if (a.N <= 64 || (a.N % 128 != 0 && a.N < 128)) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st, stats_done);   // 128 x 64
+    if (a.N <= 64) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st, stats_done);        // 128 x 64
     return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st, stats_done);                      // 128 x 128
 }
 
