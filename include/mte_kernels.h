@@ -36,7 +36,7 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
  * Also the data-gradient: call with the "backward" pack and x := dy.
  * workspace (nullable): fp32 scratch of >= B*H*W*N elements; when given, shapes with few output tiles and a long
  * reduction (pack4/pack5.conv at low resolution) are split along K over several workgroups.
- * gn_stats (nullable, device, [B][16][2] doubles) + gn_stats_done (nullable, HOST int): when the launched variant can, the
+ * gn_stats (nullable, device, [MTE_GN_REP][B][16][2] doubles, see mte_gn_stats) + gn_stats_done (nullable, HOST int): when the launched variant can, the
  * GroupNorm(16) sum / sum-of-squares of the stored outputs are accumulated in the epilogue and *gn_stats_done = 1;
  * otherwise *gn_stats_done = 0 and the caller runs mte_gn_stats. */
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
@@ -74,7 +74,10 @@ int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, f
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 
 /* ---- GroupNorm(16, C) + ELU, optionally over y1 + scale2[b,c]*y2 (residual tail with Dropout2d)
- *      (layers01.py:32-38 Conv2D; layers01.py:62-73 ResidualConv) */
+ *      (layers01.py:32-38 Conv2D; layers01.py:62-73 ResidualConv)
+ * Statistics buffers hold MTE_GN_REP partial copies, [MTE_GN_REP][B][16][2] doubles (sum, sum of squares): producers spread
+ * their atomics over the copies (same-address fp64 atomics serialise), consumers add them up. */
+#define MTE_GN_REP 16
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
                  int B, int HW, int C, int dtype, mte_stream_t stream);
 int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, const double* stats,

@@ -95,6 +95,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // per-layer hipMemsetAsync launches per training step.  Defined in norm_act.hip.
 extern int g_mte_gn_prezeroed;
 
+// GroupNorm statistics buffers are [MTE_GN_REP][B][16][2] doubles: producers spread their same-address fp64 atomics over
+// MTE_GN_REP partial copies (tile / block index mod MTE_GN_REP), consumers add the copies up.  One (sample, group) address
+// took 240 (implicit GEMM) to 1900 (full-resolution patch conv) serialised atomics per launch, and a kernel does not retire
+// before they land: statistics fused into the conv epilogues cost more than the stand-alone pass they replaced.
+#define MTE_GN_REP 16
+
 static inline int mte_check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) fprintf(stderr, "[libmte_hip] launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));

@@ -32,7 +32,7 @@ struct ConvArgs {
     int B, H, W, Cin_p, N, KH, KW;
     long M;
     int splits; float* ws;          // split-K: partial sums are atomically added into ws[M][N] (fp32), finished separately
-    double* gn_stats; int gn_gs;    // optional fused GroupNorm statistics: stats[B][16][2] += (sum, sumsq) of the stored outputs
+    double* gn_stats; int gn_gs;    // optional fused GroupNorm statistics: stats[MTE_GN_REP][B][16][2] += (sum, sumsq) of the stored outputs
 };
 
 template <typename T> struct Mma;
@@ -313,39 +313,61 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
             __syncthreads();
             constexpr int CPR = BN / PER16;                // 16-B chunks per tile row
             const int cvalid = (a.N - n0) / PER16;         // chunks of this tile inside N (N % 8 == 0)
+            // GroupNorm statistics of the tile as stored (rounded to T) ride on the store loop: a thread keeps the same 16-byte
+            // column chunk in every iteration (NTHR % CPR == 0), so it accumulates that chunk's PER16 column sums in registers
+            // while the chunk passes through them anyway, for the (at most two: H*W >= BM is checked on the host) samples of
+            // the tile, then folds them into the tile's per-group sums with a few LDS atomics.
+            static_assert(NTHR % CPR == 0, "a thread must stay on one column chunk");
+            const long hw = (long)a.H * a.W;
+            const int b0 = (int)(m0 / hw);
+            const long rsplit = (b0 + 1) * hw - m0;                     // tile rows < rsplit belong to sample b0
+            float cs[2][PER16], cq[2][PER16];
+#pragma unroll
+            for (int k = 0; k < PER16; ++k) { cs[0][k] = cs[1][k] = 0.f; cq[0][k] = cq[1][k] = 0.f; }
+            const int cc = tid % CPR;
 #pragma unroll
             for (int it = 0; it < BM * CPR / NTHR; ++it) {
-                const int idx = tid + it * NTHR;
-                const int row = idx / CPR, cc = idx - row * CPR;
+                const int row = tid / CPR + it * (NTHR / CPR);
                 const long m = m0 + row;
-                if (m < a.M && cc < cvalid)
-                    *(u32x4_t*)((T*)a.y + m * a.ldy + n0 + cc * PER16) = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
-            }
-            if (a.gn_stats) {
-                // GroupNorm statistics of the tile as stored (rounded to T): column sums per sample -> groups -> fp64 atomics.
-                // A 128-pixel tile spans at most two samples (H*W >= 128 is checked on the host).
-                constexpr int TPC = NTHR / BN, RPP = BM / TPC;          // threads per column, rows per thread
-                const int col = tid % BN, part = tid / BN;
-                const long hw = (long)a.H * a.W;
-                const int b0 = (int)(m0 / hw);
-                const long rsplit = (b0 + 1) * hw - m0;                 // tile rows < rsplit belong to sample b0
-                float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-                if (n0 + col < a.N) {
-                    for (int rr = part * RPP; rr < (part + 1) * RPP; ++rr) {
-                        if (m0 + rr < a.M) {
-                            const float v = Elem<T>::ld((const T*)(smem + (rr * BN + col) * ES));
-                            if (rr < rsplit) { s0 += v; q0 = fmaf(v, v, q0); } else { s1 += v; q1 = fmaf(v, v, q1); }
+                if (m < a.M && cc < cvalid) {
+                    const u32x4_t c = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
+                    *(u32x4_t*)((T*)a.y + m * a.ldy + n0 + cc * PER16) = c;
+                    if (a.gn_stats) {
+                        float v[PER16];
+                        unpack16<T>(c, v);
+                        if (row < rsplit) {
+#pragma unroll
+                            for (int k = 0; k < PER16; ++k) { cs[0][k] += v[k]; cq[0][k] = fmaf(v[k], v[k], cq[0][k]); }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < PER16; ++k) { cs[1][k] += v[k]; cq[1][k] = fmaf(v[k], v[k], cq[1][k]); }
                         }
                     }
-                    const int g = (n0 + col) / a.gn_gs;
-                    atomicAdd(&s_gn[g * 2], s0); atomicAdd(&s_gn[g * 2 + 1], q0);
-                    atomicAdd(&s_gn[32 + g * 2], s1); atomicAdd(&s_gn[32 + g * 2 + 1], q1);
+                }
+            }
+            if (a.gn_stats) {
+                if (cc < cvalid) {
+#pragma unroll
+                    for (int sm = 0; sm < 2; ++sm) {
+                        // fold the chunk's columns into groups (a group is gn_gs consecutive channels; chunks are aligned)
+                        float gs_ = 0.f, gq_ = 0.f;
+#pragma unroll
+                        for (int k = 0; k < PER16; ++k) {
+                            gs_ += cs[sm][k]; gq_ += cq[sm][k];
+                            const int ch = n0 + cc * PER16 + k;
+                            if (k == PER16 - 1 || (ch + 1) % a.gn_gs == 0) {
+                                const int g = ch / a.gn_gs;
+                                if (gs_ != 0.f || gq_ != 0.f) { atomicAdd(&s_gn[sm * 32 + g * 2], gs_); atomicAdd(&s_gn[sm * 32 + g * 2 + 1], gq_); }
+                                gs_ = 0.f; gq_ = 0.f;
+                            }
+                        }
+                    }
                 }
                 __syncthreads();
                 if (tid < 64) {
                     const int b = b0 + (tid >> 5);
                     const float v = s_gn[tid];
-                    if (b < a.B && v != 0.f) atomicAdd(&a.gn_stats[(long)b * 32 + (tid & 31)], (double)v);
+                    if (b < a.B && v != 0.f) atomicAdd(&a.gn_stats[((long)(tile_m % MTE_GN_REP) * a.B + b) * 32 + (tid & 31)], (double)v);
                 }
             }
             return;
@@ -408,7 +430,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
                       a.N % 16 == 0;
     if (stats_done) *stats_done = fuse ? 1 : 0;
     if (!fuse) a.gn_stats = nullptr;
-    else { a.gn_gs = a.N / 16; if (!g_mte_gn_prezeroed && hipMemsetAsync(a.gn_stats, 0, sizeof(double) * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
+    else { a.gn_gs = a.N / 16; if (!g_mte_gn_prezeroed && hipMemsetAsync(a.gn_stats, 0, sizeof(double) * MTE_GN_REP * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
     if (a.splits > 1 && hipMemsetAsync(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
     if constexpr ((BN * 4) % NTHR == 0) {
         if (g_igemm_dma) {

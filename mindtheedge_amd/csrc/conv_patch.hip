@@ -29,7 +29,7 @@ struct PatchArgs {
     const float* bias;
     bf16_t* y; long ldy;
     int B, H, W, Cin_p, N;
-    double* gn_stats;                              // optional [B][16][2] fused GroupNorm(16) statistics (pre-zeroed)
+    double* gn_stats;                              // optional [MTE_GN_REP][B][16][2] fused GroupNorm(16) statistics
 };
 
 // ---- forward / dgrad --------------------------------------------------------------------------------------
@@ -151,30 +151,44 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     __syncthreads();
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
+    // GroupNorm statistics of the stored (bf16-rounded) tile ride on the store loop: a thread keeps the same 16-byte channel
+    // chunk in every iteration (256 % (NT*4) == 0), so it sums that chunk's 8 channels in registers as they pass through
+    float cs[8], cq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { cs[k] = 0.f; cq[k] = 0.f; }
+    const int c = tid % (NT * 4);
 #pragma unroll
     for (int i = 0; i < OCH / 256; ++i) {
-        const int idc = tid + i * 256;
-        const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
+        const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
         const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
-        if (yy < a.H && c < cpp)
-            *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * NB + c * 16);
+        if (yy < a.H && c < cpp) {
+            const u32x4_t v16 = *(const u32x4_t*)(smem + pix * NB + c * 16);
+            *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
+            if (a.gn_stats) {
+                float v[8];
+                unpack16<bf16_t>(v16, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { cs[k] += v[k]; cq[k] = fmaf(v[k], v[k], cq[k]); }
+            }
+        }
     }
-    if (a.gn_stats) {                                              // GroupNorm statistics of the stored (bf16-rounded) tile
-        constexpr int NC = NT * 32, TPC = 256 / NC;
-        const int col = tid % NC, part = tid / NC;
-        float s0 = 0.f, q0 = 0.f;
-        if (col < a.N) {
-            for (int pix = part; pix < TH * TW; pix += TPC) {
-                if (y0 + pix / TW < a.H) {
-                    const float v = bf2f(*(const bf16_t*)(smem + pix * NB + col * 2));
-                    s0 += v; q0 = fmaf(v, v, q0);
+    if (a.gn_stats) {
+        if (c < cpp) {
+            const int gsz = a.N >> 4;                               // channels per group
+            float gs_ = 0.f, gq_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                gs_ += cs[k]; gq_ += cq[k];
+                const int ch = c * 8 + k;
+                if (k == 7 || (ch + 1) % gsz == 0) {
+                    const int g = ch / gsz;
+                    atomicAdd(&s_gn[g * 2], gs_); atomicAdd(&s_gn[g * 2 + 1], gq_);
+                    gs_ = 0.f; gq_ = 0.f;
                 }
             }
-            const int g = col / (a.N >> 4);
-            atomicAdd(&s_gn[g * 2], s0); atomicAdd(&s_gn[g * 2 + 1], q0);
         }
         __syncthreads();
-        if (tid < 32 && s_gn[tid] != 0.f) atomicAdd(&a.gn_stats[(long)b * 32 + tid], (double)s_gn[tid]);
+        if (tid < 32 && s_gn[tid] != 0.f) atomicAdd(&a.gn_stats[((long)(blockIdx.x % MTE_GN_REP) * a.B + b) * 32 + tid], (double)s_gn[tid]);
     }
 }
 
@@ -426,7 +440,7 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
     if (gn_stats && N % 16 != 0) return MTE_ERR_ARG;
-    if (gn_stats && !g_mte_gn_prezeroed && hipMemsetAsync(gn_stats, 0, sizeof(double) * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (gn_stats && !g_mte_gn_prezeroed && hipMemsetAsync(gn_stats, 0, sizeof(double) * MTE_GN_REP * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, gn_stats};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
 }

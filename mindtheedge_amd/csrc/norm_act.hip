@@ -22,7 +22,7 @@ struct GnArgs {
     const void* y1; long ld1;
     const void* y2; long ld2;          // nullable
     const float* scale2;               // [B][C] or null
-    double* stats;                     // [B][16][2] (sum, sumsq)
+    double* stats;                     // [MTE_GN_REP][B][16][2] (sum, sumsq) partial copies, summed by the consumers
     const float* gamma; const float* beta;
     void* z; long ldz;                 // forward output
     const void* dz; long lddz;         // backward input
@@ -112,26 +112,33 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
         else { atomicAdd(&s_acc[2 * g], s[i]); atomicAdd(&s_acc[2 * g + 1], q[i]); }
     }
     __syncthreads();
-    if (threadIdx.x < GN_GROUPS * 2) atomicAdd(&a.stats[(long)b * GN_GROUPS * 2 + threadIdx.x], (double)s_acc[threadIdx.x]);
+    if (threadIdx.x < GN_GROUPS * 2)
+        atomicAdd(&a.stats[((long)(blockIdx.x % MTE_GN_REP) * a.B + b) * GN_GROUPS * 2 + threadIdx.x], (double)s_acc[threadIdx.x]);
 }
 
-__device__ __forceinline__ void group_mean_rstd(const GnArgs& a, int b, int g, int gs, float& mean, float& rstd) {
-    const double n = (double)a.HW * gs;
-    const double S = a.stats[((long)b * GN_GROUPS + g) * 2], Q = a.stats[((long)b * GN_GROUPS + g) * 2 + 1];
-    const double m = S / n;
-    double var = Q / n - m * m;
-    if (var < 0.0) var = 0.0;
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-}
-
-// The fp64 mean / rstd of the 16 groups of sample b are evaluated once per block (16 lanes) and shared through LDS:
-// per-thread evaluation (8 fp64 divisions + square roots per thread) used to dominate the short low-resolution launches.
+// The fp64 mean / rstd of the 16 groups of sample b are evaluated once per block and shared through LDS (per-thread
+// evaluation -- 8 fp64 divisions + square roots per thread -- used to dominate the short low-resolution launches): 32 lanes
+// add up the MTE_GN_REP partial copies of one (group, sum | sum of squares) value each, 16 lanes finish.
 __device__ __forceinline__ void block_group_stats(const GnArgs& a, int b, int gs, float* s_mr) {
+    __shared__ double s_sq[GN_GROUPS * 2];
+    if (threadIdx.x < GN_GROUPS * 2) {
+        const double* sp = a.stats + (long)b * GN_GROUPS * 2 + threadIdx.x;
+        double v[MTE_GN_REP];
+#pragma unroll
+        for (int r = 0; r < MTE_GN_REP; ++r) v[r] = sp[(long)r * a.B * GN_GROUPS * 2];      // independent loads, one latency
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < MTE_GN_REP; ++r) acc += v[r];
+        s_sq[threadIdx.x] = acc;
+    }
+    __syncthreads();
     if (threadIdx.x < GN_GROUPS) {
-        float m, r;
-        group_mean_rstd(a, b, threadIdx.x, gs, m, r);
-        s_mr[2 * threadIdx.x] = m; s_mr[2 * threadIdx.x + 1] = r;
+        const double n = (double)a.HW * gs;
+        const double m = s_sq[2 * threadIdx.x] / n;
+        double var = s_sq[2 * threadIdx.x + 1] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        s_mr[2 * threadIdx.x] = (float)m;
+        s_mr[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
     __syncthreads();
 }
@@ -325,12 +332,12 @@ extern "C" int mtei_set_gn(int which, int value) {
 
 extern "C" {
 
-// stats[B][16][2] (double; zeroed here) <- per-(sample, group) sum and sum of squares of v = y1 + scale2*y2
+// stats[MTE_GN_REP][B][16][2] (double; zeroed here; partial copies) <- per-(sample, group) sum and sum of squares of v = y1 + scale2*y2
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
                  int B, int HW, int C, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
-    if (!g_mte_gn_prezeroed && hipMemsetAsync(stats, 0, sizeof(double) * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (!g_mte_gn_prezeroed && hipMemsetAsync(stats, 0, sizeof(double) * MTE_GN_REP * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));

@@ -354,7 +354,12 @@ def _splitk_workspace(M, N, device):
     return torch.empty((M * N,), dtype=torch.float32, device=device), M * N
 
 
-_cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30}
+# conv_epilogue_stats: accumulate GroupNorm statistics in the conv epilogues instead of a stand-alone pass.  Built, tested
+# and OFF: on T8 the stand-alone pass is 0.7 % faster end to end (it streams the conv output at ~5 TB/s and leaves it in
+# the Infinity Cache for the normalisation pass that follows, while the fused form lengthens ~45 conv kernels by LDS
+# atomics, one more barrier and a tail of fp64 atomics that must land before the kernel retires).
+_cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30,
+        "conv_epilogue_stats": bool(os.environ.get("MTE_STATS_FUSION"))}
 
 
 def use_pack_folding(flag):
@@ -364,6 +369,11 @@ def use_pack_folding(flag):
 
 def pack_folding_enabled():
     return _cfg["pack_folding"]
+
+
+def use_conv_epilogue_stats(flag):
+    """Enable/disable GroupNorm statistics in the conv epilogues (see _cfg)."""
+    _cfg["conv_epilogue_stats"] = bool(flag)
 
 
 def use_patch_kernels(flag):
@@ -383,7 +393,7 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stat
         out = new_act(B, cout, H, W, x.dtype, x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(out)
-    want = gn_stats is not None and cout % 16 == 0
+    want = gn_stats is not None and cout % 16 == 0 and _cfg["conv_epilogue_stats"]
     if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
         lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw,
                                  gn_stats.data_ptr() if want else 0, _stream())
@@ -507,7 +517,7 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, stats=None):
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     st = _stream()
     if stats is None:
-        stats = _zeros((B, 16, 2), torch.float64, y1.device)
+        stats = _zeros((GN_REP, B, 16, 2), torch.float64, y1.device)
         lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
     if tuple(z.shape) != (B, C, H, W) or z.dtype != y1.dtype:
@@ -541,6 +551,7 @@ def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbia
 
 
 GN_EPS = 1e-5
+GN_REP = 16           # MTE_GN_REP of include/mte_kernels.h: partial copies of a GroupNorm statistics buffer
 
 _dropout_pool = {}
 
@@ -568,7 +579,7 @@ class ConvGnEluFn(torch.autograd.Function):
     def forward(ctx, x, w, b, gamma, beta, pack, out=None):
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
-        stats = _zeros((x.shape[0], 16, 2), torch.float64, x.device)
+        stats = _zeros((GN_REP, x.shape[0], 16, 2), torch.float64, x.device)
         y, fused = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w, gn_stats=stats)
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, stats=stats if fused else None,
                                out=None if out is None else alias_of(out))

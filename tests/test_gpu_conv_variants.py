@@ -76,6 +76,7 @@ def test_conv_epilogue_groupnorm_statistics(shape, dtype):
     from mindtheedge_amd import kernels as K
     cin, cout, k, B, H, W = shape
     K.set_compute_dtype(dtype)
+    K.use_conv_epilogue_stats(True)
     K.lib.mte_set_option(0, 0)          # library-zeroes mode: the garbage-filled statistics buffers below must be cleared by it
     try:
         g = torch.Generator().manual_seed(7 + cin + cout)
@@ -84,7 +85,7 @@ def test_conv_epilogue_groupnorm_statistics(shape, dtype):
         xa = K.image_to_act(torch.rand(B, cin, H, W, generator=g).cuda() * 2 - 1)
         pack = K.WeightPack()
         wf, _ = pack.get(w, xa.dtype, False)
-        stats = torch.full((B, 16, 2), 123.0, dtype=torch.float64, device="cuda")
+        stats = torch.full((K.GN_REP, B, 16, 2), 123.0, dtype=torch.float64, device="cuda")
         ws_fn, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)      # split-K launches do not fuse
         try:
             y, fused = K.conv_forward(xa, wf, b, cout, k, k, pack=pack, w=w, gn_stats=stats)
@@ -102,9 +103,10 @@ def test_conv_epilogue_groupnorm_statistics(shape, dtype):
         exact = torch.stack([yf.sum(-1), (yf * yf).sum(-1)], -1)
         n = yf.shape[-1]
         # compare as (mean, E[x^2]); fp32 partial sums inside a tile, fp64 across tiles
-        assert torch.allclose(stats / n, exact / n, rtol=2e-5, atol=2e-6)
-        assert torch.allclose(ref / n, exact / n, rtol=2e-5, atol=2e-6)
+        assert torch.allclose(stats.sum(0) / n, exact / n, rtol=2e-5, atol=2e-6)      # the partial copies add up to the statistics
+        assert torch.allclose(ref.sum(0) / n, exact / n, rtol=2e-5, atol=2e-6)
     finally:
+        K.use_conv_epilogue_stats(False)
         K.lib.mte_set_option(0, 1 if K._arena.enabled else 0)
         K.set_compute_dtype("bf16")
 
@@ -143,6 +145,7 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape):
     cin, cout, k, B, H, W = shape
 
     def run(big):
+        K.use_conv_epilogue_stats(True)
         K.lib.mte_debug_set(6, big)
         K.lib.mte_debug_set(7, 1)
         orig, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)
@@ -154,12 +157,13 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape):
             dy = K.image_to_act(torch.rand(B, cout, H, W, generator=g).cuda() * 2 - 1)
             pack = K.WeightPack()
             wf, wb = pack.get(w, xa.dtype, True)
-            stats = torch.zeros((B, 16, 2), dtype=torch.float64, device="cuda")
+            stats = torch.zeros((K.GN_REP, B, 16, 2), dtype=torch.float64, device="cuda")
             y, fused = K.conv_forward(xa, wf, b, cout, k, k, gn_stats=stats)
             dx = K.conv_forward(dy, wb, None, K.round8(cin), k, k) if K.round8(cin) % 128 == 0 else None
             torch.cuda.synchronize()
-            return y.float().cpu(), stats.cpu(), fused, None if dx is None else dx.float().cpu()
+            return y.float().cpu(), stats.sum(0).cpu(), fused, None if dx is None else dx.float().cpu()
         finally:
+            K.use_conv_epilogue_stats(False)
             K._splitk_workspace = orig
             K.lib.mte_debug_set(6, 2)
             K.lib.mte_debug_set(7, 224)
