@@ -1136,6 +1136,7 @@ extern "C" {
 // (1 = LDS-tiled, 0 = gather).  Not part of the product contract.
 extern "C" int mtei_set_pack3d_lds(int value);
 extern "C" int mtei_set_gn(int which, int value);
+extern "C" int mtei_set_patch_tall(int v);
 int mte_debug_set(int key, int value) {
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
     if (key == 1) return mtei_set_pack3d_lds(value);
@@ -1144,6 +1145,7 @@ int mte_debug_set(int key, int value) {
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
     if (key == 8) { g_wgrad_big = value; return MTE_OK; }
     if (key == 9) { g_wgrad_wgs = value; return MTE_OK; }
+    if (key == 11) return mtei_set_patch_tall(value);
     if (key == 7) { g_igemm_big_min_tiles = value; return MTE_OK; }
     return MTE_ERR_ARG;
 }

@@ -33,14 +33,20 @@ struct PatchArgs {
 };
 
 // ---- forward / dgrad --------------------------------------------------------------------------------------
-template <int K, int NT>
+// TALL (NT = 1, one 32-channel input slice): 16 x 32-pixel tile, four pixel rows per wave -- every weight fragment fetched
+// from L2 feeds twice the MFMAs (with two rows per wave the 7x7 full-resolution layers pulled 6 GB of weight fragments
+// per launch, ~10 TB/s of L2 bandwidth); the single slice needs only one patch buffer, so two workgroups still fit a CU.
+template <int K, int NT, bool TALL>
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
+    static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
+    constexpr int TH = TALL ? 16 : 8;                               // (shadows the file-level 8-row tile of the wgrad kernels)
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int PCH = PH * PW * 4;                               // 16-B chunks per patch slice
     constexpr int NCH = (PCH + 255) / 256;
     constexpr int PBYTES = PH * PW * 64;
     constexpr int OBYTES = TH * TW * NT * 64;                      // output staging (bf16 [256 px][32*NT])
-    constexpr int LDS_BYTES = ((2 * PBYTES > OBYTES) ? 2 * PBYTES : OBYTES) + 128;    // + [16 groups][2] statistics
+    constexpr int NBUF = TALL ? 1 : 2;                             // patch buffers (TALL: exactly one slice per tile)
+    constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES) ? NBUF * PBYTES : OBYTES) + 128;    // + [16 groups][2] statistics
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,9 +85,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     // Wave -> sub-tile map.  NT = 1: wave w owns pixel rows 2w, 2w+1.  NT = 2: waves are split over the two 32-channel output
     // tiles (n = w >> 1) and own four pixel rows each: a wave then fetches half of the slice's weight fragments from L2
     // (every wave reading all of them made weight traffic, 1.1 GB per 64->64 launch, ~9x the activation traffic).
-    constexpr int MM = NT == 2 ? 4 : 2;
+    constexpr int MM = (NT == 2 || TALL) ? 4 : 2;
     const int nsel = NT == 2 ? wave >> 1 : 0;
-    const int mrow0 = NT == 2 ? (wave & 1) * 4 : wave * 2;
+    const int mrow0 = NT == 2 ? (wave & 1) * 4 : wave * MM;
     f32x16_t acc[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m)
@@ -354,9 +360,18 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
     }
 }
 
+int g_patch_tall = 1;                                // development knob (mte_debug_set(11, v))
+
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
+    if constexpr (NT == 1) {
+        if (g_patch_tall && a.Cin_p <= 32 && a.H >= 16) {
+            const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
+            hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            return mte_check_launch();
+        }
+    }
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
-    hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     return mte_check_launch();
 }
 template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
@@ -411,6 +426,8 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 }
 
 }  // namespace
+
+extern "C" int mtei_set_patch_tall(int v) { g_patch_tall = v; return MTE_OK; }
 
 extern "C" {
 
