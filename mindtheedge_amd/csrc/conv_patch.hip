@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int NCH = (PCH + 255) / 256;
     constexpr int PBYTES = PH * PW * 64;
     constexpr int OBYTES = TH * TW * NT * 64;                      // output staging (bf16 [256 px][32*NT])
-    constexpr int NBUF = TALL ? 1 : 2;                             // patch buffers (TALL: exactly one slice per tile)
+    constexpr int NBUF = (TALL && K > 3) ? 1 : 2;                  // patch buffers (tall 5x5 / 7x7 tiles: single-slice layers only)
     constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES) ? NBUF * PBYTES : OBYTES) + 128;    // + [16 groups][2] statistics
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -364,7 +364,7 @@ int g_patch_tall = 1;                                // development knob (mte_de
 
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
     if constexpr (NT == 1) {
-        if (g_patch_tall && a.Cin_p <= 32 && a.H >= 16) {
+        if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
             hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             return mte_check_launch();
