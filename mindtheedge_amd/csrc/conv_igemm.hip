@@ -411,9 +411,10 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, const float* 
 }
 
 // split-K factor for small-M / huge-K layers (pack5.conv: 120 tiles for 256 CUs); 1 = no split
-inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems) {
-    if (tiles >= 384 || ws_elems < M * N || N % 4 != 0) return 1;
-    long s = (768 + tiles - 1) / tiles;
+inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems, int nthr = 256) {
+    const long want = 768L * 256 / nthr;               // ~3 four-wave workgroups per CU, or their equivalent in larger ones
+    if (tiles >= want / 2 || ws_elems < M * N || N % 4 != 0) return 1;
+    long s = (want + tiles - 1) / tiles;
     const long max_s = ksteps / 16;                    // keep >= 16 K-steps (1 KiB of K per row) per split
     if (s > max_s) s = max_s;
     return (int)(s < 1 ? 1 : s);
@@ -424,7 +425,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
-    a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems) : 1;
+    a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems, NTHR) : 1;
     // GroupNorm statistics can ride on the LDS-staged epilogue of the DMA kernels (not: split-K, fp32 output, the register-staged 128x32 configuration)
     const bool fuse = a.gn_stats && (BN * 4) % NTHR == 0 && g_igemm_dma && a.splits == 1 && !a.out_f32 && (long)a.H * a.W >= BM &&
                       a.N % 16 == 0;
@@ -469,9 +470,15 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         // (odd widths -- 72 / 104 / 200 input channels of the decoder concats as data-gradient N -- take the tile that covers
         //  them in ONE column block: the padded columns cost the same MFMA work as two narrower blocks, A is read once)
         const long n256 = (a.N + 255) / 256;
+        const long t256 = ((a.M + 255) / 256) * n256;
+        const int ksteps = a.KH * a.KW * (a.Cin_p / 32);
+        // few tiles but a huge reduction (pack4/pack5.conv: K = 9 x 4096 / 8192): the big tiles keep their bytes-per-flop
+        // advantage when the K range is split over workgroups (fp32 atomics into the workspace, then the finish kernel)
+        const bool can_split = a.ws && ws_elems >= a.M * a.N && a.N % 4 == 0;
+        const long reach256 = t256 * (can_split ? (ksteps / 16 < 8 ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : 8) : 1);
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
-            ((a.M + 255) / 256) * n256 >= g_igemm_big_min_tiles)
-            return launch_igemm<T, 4, 4, 2, 2>(a, 0, st, stats_done);                  // 256 x 256, 16 waves
+            (t256 >= g_igemm_big_min_tiles || reach256 >= 160))
+            return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st, stats_done);   // 256 x 256, 16 waves
         if (g_igemm_big && dma_ok && !a.out_f32 && a.N > 64 && tiles_big >= g_igemm_big_min_tiles)
             return launch_igemm<T, 4, 2, 2, 2>(a, 0, st, stats_done);
     }

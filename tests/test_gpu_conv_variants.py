@@ -180,3 +180,28 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape):
                 assert torch.equal(da, db)
     finally:
         K.use_patch_kernels(True)
+
+
+@pytest.mark.parametrize("shape", [(512, 256, 3, 4, 32, 40), (1024, 512, 3, 2, 40, 64)])
+def test_big_tile_split_k_matches_small_tiles(shape):
+    """Few output tiles + a long reduction (the pack4/pack5.conv regime): 256x256 tiles with the K range split over
+    workgroups (fp32 atomics + finish kernel) against the 128x128 split-K path -- same bf16 products, different
+    summation order."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W = shape
+    K.use_patch_kernels(False)
+    try:
+        outs = []
+        for big in (2, 0):
+            K.lib.mte_debug_set(6, big)
+            g = torch.Generator().manual_seed(11 + cin)
+            w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+            b = (torch.rand(cout, generator=g) - 0.5).cuda()
+            xa = K.image_to_act(torch.rand(B, cin, H, W, generator=g).cuda() * 2 - 1)
+            wf, _ = K.WeightPack().get(w, xa.dtype, False)
+            outs.append(K.conv_forward(xa, wf, b, cout, k, k).float().cpu())
+        assert rel_err(outs[0], outs[1]) < 8e-3
+        assert float(outs[0].abs().mean()) > 0.1                 # (not trivially zero)
+    finally:
+        K.lib.mte_debug_set(6, 2)
+        K.use_patch_kernels(True)
