@@ -477,7 +477,7 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         const bool can_split = a.ws && ws_elems >= a.M * a.N && a.N % 4 == 0;
         const long reach256 = t256 * (can_split ? (ksteps / 16 < 8 ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : 8) : 1);
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
-            (t256 >= g_igemm_big_min_tiles || reach256 >= 160))
+            (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160)))   // (96: below it choose_splits does split)
             return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st, stats_done);   // 256 x 256, 16 waves
         if (g_igemm_big && dma_ok && !a.out_f32 && a.N > 64 && tiles_big >= g_igemm_big_min_tiles)
             return launch_igemm<T, 4, 2, 2, 2>(a, 0, st, stats_done);
