@@ -38,10 +38,12 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
  * reduction (pack4/pack5.conv at low resolution) are split along K over several workgroups.
  * gn_stats (nullable, device, [MTE_GN_REP][B][16][2] doubles, see mte_gn_stats) + gn_stats_done (nullable, HOST int): when the launched variant can, the
  * GroupNorm(16) sum / sum-of-squares of the stored outputs are accumulated in the epilogue and *gn_stats_done = 1;
- * otherwise *gn_stats_done = 0 and the caller runs mte_gn_stats. */
+ * otherwise *gn_stats_done = 0 and the caller runs mte_gn_stats.
+ * accumulate = 1: y += conv(x) (sum formed in fp32, rounded once): the second data gradient of an activation with two consumers
+ * lands in the first one's buffer instead of going through a separate add. */
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
-                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, mte_stream_t stream);
+                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, int accumulate, mte_stream_t stream);
 /* Library options.  MTE_OPT_GN_PREZEROED (0): when 1, the GroupNorm statistics / reduction / bias-gradient outputs handed to
  * mte_gn_stats, mte_gn_elu_bwd and the gn_stats argument of the conv entry points are already zero (the caller clears
  * one arena per step with a single memset) and the library skips its own per-call hipMemsetAsync. */
@@ -69,7 +71,7 @@ int mte_conv2d_patch_supported(int W, int Cin_p, int N, int KH, int KW, int dtyp
 long mte_conv2d_patch_pack_elems(int Cin_p, int N, int KH, int KW);
 int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
-                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, mte_stream_t stream);
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, int accumulate, mte_stream_t stream);
 int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 

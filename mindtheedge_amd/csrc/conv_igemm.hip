@@ -32,6 +32,7 @@ struct ConvArgs {
     int B, H, W, Cin_p, N, KH, KW;
     long M;
     int splits; float* ws;          // split-K: partial sums are atomically added into ws[M][N] (fp32), finished separately
+    int accum;                      // 1: y += conv (sum formed in fp32, rounded once) -- second gradient of a two-consumer activation
     double* gn_stats; int gn_gs;    // optional fused GroupNorm statistics: stats[MTE_GN_REP][B][16][2] += (sum, sumsq) of the stored outputs
 };
 
@@ -330,7 +331,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
                 const int row = tid / CPR + it * (NTHR / CPR);
                 const long m = m0 + row;
                 if (m < a.M && cc < cvalid) {
-                    const u32x4_t c = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
+                    u32x4_t c = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
+                    if (a.accum) {
+                        float vn[PER16], vo[PER16];
+                        unpack16<T>(c, vn);
+                        unpack16<T>(*(const u32x4_t*)((const T*)a.y + m * a.ldy + n0 + cc * PER16), vo);
+#pragma unroll
+                        for (int k = 0; k < PER16; ++k) vn[k] += vo[k];
+                        c = pack16<T>(vn);
+                    }
                     *(u32x4_t*)((T*)a.y + m * a.ldy + n0 + cc * PER16) = c;
                     if (a.gn_stats) {
                         float v[PER16];
@@ -388,8 +397,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
                 if (m < a.M) {
                     const float v = acc[i][j][e] + bv;
                     if (a.splits > 1) atomicAdd(a.ws + m * a.N + n, acc[i][j][e]);
-                    else if (a.out_f32) ((float*)a.y)[m * a.ldy + n] = v;
-                    else Elem<T>::st((T*)a.y + m * a.ldy + n, v);
+                    else if (a.out_f32) ((float*)a.y)[m * a.ldy + n] = a.accum ? v + ((float*)a.y)[m * a.ldy + n] : v;
+                    else Elem<T>::st((T*)a.y + m * a.ldy + n, a.accum ? v + Elem<T>::ld((const T*)a.y + m * a.ldy + n) : v);
                 }
             }
         }
@@ -400,13 +409,13 @@ int g_igemm_dma = 1;                                 // development knob (mte_de
 
 // y = T(ws + bias) after a split-K launch
 template <typename T>
-__global__ void splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ y, long ldy, long M, int N) {
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* y, long ldy, long M, int N, int accum) {
     const long n4 = M * N / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long m = (i * 4) / N; const int n = (int)((i * 4) % N);
         const f32x4_t v = ((const f32x4_t*)ws)[i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Elem<T>::st(y + m * ldy + n + k, v[k] + (bias ? bias[n + k] : 0.f));
+        for (int k = 0; k < 4; ++k) Elem<T>::st(y + m * ldy + n + k, v[k] + (bias ? bias[n + k] : 0.f) + (accum ? Elem<T>::ld(y + m * ldy + n + k) : 0.f));
     }
 }
 
@@ -450,7 +459,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
 launched:
     if (a.splits > 1) {
         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, a.ws, a.bias, (T*)a.y, a.ldy, a.M, a.N);
+        hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, a.ws, a.bias, (T*)a.y, a.ldy, a.M, a.N, a.accum);
     }
     return mte_check_launch();
 }
@@ -1161,12 +1170,12 @@ int mte_debug_set(int key, int value) {
 // workspace (nullable): fp32 scratch of workspace_elems >= B*H*W*N elements enables split-K for small-M / huge-K shapes.
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
-                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, hipStream_t stream) {
+                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, int accumulate, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
-    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, gn_stats, 1};
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, accumulate ? 1 : 0, gn_stats, 1};
     if (gn_stats_done) *gn_stats_done = 0;
     if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream, gn_stats_done);
     if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream, gn_stats_done);

@@ -29,6 +29,7 @@ struct PatchArgs {
     const float* bias;
     bf16_t* y; long ldy;
     int B, H, W, Cin_p, N;
+    int accum;                                     // 1: y += conv (fp32 sum, rounded once)
     double* gn_stats;                              // optional [MTE_GN_REP][B][16][2] fused GroupNorm(16) statistics
 };
 
@@ -168,7 +169,15 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
         const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
         if (yy < a.H && c < cpp) {
-            const u32x4_t v16 = *(const u32x4_t*)(smem + pix * NB + c * 16);
+            u32x4_t v16 = *(const u32x4_t*)(smem + pix * NB + c * 16);
+            if (a.accum) {
+                float vn[8], vo[8];
+                unpack16<bf16_t>(v16, vn);
+                unpack16<bf16_t>(*(const u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8), vo);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vn[k] += vo[k];
+                v16 = pack16<bf16_t>(vn);
+            }
             *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
             if (a.gn_stats) {
                 float v[8];
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
     }
 }
 
+int g_patch_wgrad_wgs = 512;                         // development knob (mte_debug_set(12, v))
 int g_patch_tall = 1;                                // development knob (mte_debug_set(11, v))
 
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
@@ -390,7 +400,7 @@ template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream
     const size_t lds = PH * PW * XRS + TH * TW * YRS;
     const int nslices = (a.Cin_p + 32 * SL - 1) / (32 * SL);
     const long ntiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
-    long groups = (512 + nslices - 1) / nslices;                   // ~2 workgroups per CU in total
+    long groups = (g_patch_wgrad_wgs + nslices - 1) / nslices;     // ~2 workgroups per CU in total
     if (groups > ntiles) groups = ntiles;
     a.groups = (int)groups;
     static bool attr_set = false;
@@ -427,7 +437,7 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 
 }  // namespace
 
-extern "C" int mtei_set_patch_tall(int v) { g_patch_tall = v; return MTE_OK; }
+extern "C" int mtei_set_patch_tall(int v) { if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
 
 extern "C" {
 
@@ -453,12 +463,12 @@ int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N
 
 // y = conv(x, wpatch) + bias for C_out <= 64 (forward, or data-gradient with the backward pack); bf16 only.
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
-                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, hipStream_t stream) {
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, int accumulate, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
     if (gn_stats && N % 16 != 0) return MTE_ERR_ARG;
     if (gn_stats && !g_mte_gn_prezeroed && hipMemsetAsync(gn_stats, 0, sizeof(double) * MTE_GN_REP * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, gn_stats};
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, gn_stats};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
 }
 

@@ -359,7 +359,8 @@ def _splitk_workspace(M, N, device):
 # the Infinity Cache for the normalisation pass that follows, while the fused form lengthens ~45 conv kernels by LDS
 # atomics, one more barrier and a tail of fp64 atomics that must land before the kernel retires).
 _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30,
-        "conv_epilogue_stats": bool(os.environ.get("MTE_STATS_FUSION"))}
+        "conv_epilogue_stats": bool(os.environ.get("MTE_STATS_FUSION")),
+        "no_fork_accumulate": bool(os.environ.get("MTE_NO_FORK_ACCUM"))}
 
 
 def use_pack_folding(flag):
@@ -385,7 +386,7 @@ def _patch_ok(W, cin_p, n, kh, kw, dtype):
     return _cfg["patch_kernels"] and dtype == torch.bfloat16 and lib.mte_conv2d_patch_supported(W, cin_p, n, kh, kw, DT_BF16) == 1
 
 
-def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stats=None):
+def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stats=None, accumulate=False):
     """-> y, or (y, stats_fused) when `gn_stats` ([B,16,2] fp64) is offered: the conv epilogue accumulates the GroupNorm(16)
     statistics of its own output when the launched kernel variant can (saves one full read of y)."""
     B, Cp, H, W = x.shape
@@ -396,12 +397,12 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stat
     want = gn_stats is not None and cout % 16 == 0 and _cfg["conv_epilogue_stats"]
     if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
         lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw,
-                                 gn_stats.data_ptr() if want else 0, _stream())
+                                 gn_stats.data_ptr() if want else 0, 1 if accumulate else 0, _stream())
         return (out, want) if gn_stats is not None else out
     ws, ws_n = _splitk_workspace(B * H * W, cout, x.device)
     done = ctypes.c_int(0)
     lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _ptr(ws), ws_n,
-                         gn_stats.data_ptr() if want else 0, ctypes.byref(done), _stream())
+                         gn_stats.data_ptr() if want else 0, ctypes.byref(done), 1 if accumulate else 0, _stream())
     return (out, bool(done.value)) if gn_stats is not None else out
 
 
@@ -480,8 +481,9 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     return dw, dbias
 
 
-def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None):
-    """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations"""
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None):
+    """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations;
+    fork_slot: see ForkFn -- the data gradient is accumulated into the gradient another consumer of x already produced"""
     cout, cin, kh, kw = w.shape
     B, Cp, H, W = x.shape
     dyp, lddy = _pl(dy)
@@ -497,16 +499,19 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
                 dw, dbias = _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
         else:
             dw, dbias = _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
-    if need_dx and _patch_ok(W, cout, Cp, kh, kw, x.dtype):
-        dx = new_act(B, Cp, H, W, x.dtype, x.device)
+    if need_dx:
+        target = _fork_target(fork_slot, (B, Cp, H, W), x.dtype)
+        dx = target if target is not None else new_act(B, Cp, H, W, x.dtype, x.device)
+        acc = 1 if target is not None else 0
         dxp, lddx = _pl(dx)
-        lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, 0, st)
-    elif need_dx:
-        _, wb = pack.get(w, x.dtype, True)
-        dx = new_act(B, Cp, H, W, x.dtype, x.device)
-        dxp, lddx = _pl(dx)
-        ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
-        lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, 0, 0, st)
+        if _patch_ok(W, cout, Cp, kh, kw, x.dtype):
+            lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, 0, acc, st)
+        else:
+            _, wb = pack.get(w, x.dtype, True)
+            ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
+            lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, 0, 0, acc, st)
+        if fork_slot is not None:
+            fork_slot["buf"] = dx
     return dx, dw, dbias
 
 
@@ -577,6 +582,7 @@ class ConvGnEluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, pack, out=None):
+        ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
         stats = _zeros((GN_REP, x.shape[0], 16, 2), torch.float64, x.device)
@@ -598,7 +604,7 @@ class ConvGnEluFn(torch.autograd.Function):
         gw, sw = _grad_dst(w)
         dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
                                                 dgamma=gg, dbeta=gb, dbias=gbias)
-        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw)
+        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot)
         return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None, None
 
 
@@ -607,6 +613,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, pack):
+        ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
         y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
@@ -622,7 +629,7 @@ class ConvFn(torch.autograd.Function):
         dy = as_act(dy, x.dtype)
         gw, sw = _grad_dst(w)
         gbias, sbias = _grad_dst(b)
-        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias)
+        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias, fork_slot=ctx.fork_slot)
         return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None
 
 
@@ -921,35 +928,61 @@ class InvDepthFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def _fork_target(slot, shape, dtype):
+    """The buffer a data gradient should be ACCUMULATED into: the gradient that another consumer of the same forked
+    activation (or, for a fork of a fork, of its parent) has already produced.  None = this consumer is the first."""
+    if _cfg.get("no_fork_accumulate"):
+        return None
+    while slot is not None:
+        buf = slot["buf"]
+        if buf is not None:
+            return buf if (tuple(buf.shape) == tuple(shape) and buf.dtype == dtype and is_act(buf)) else None
+        slot = slot["parent"]
+    return None
+
+
 class ForkFn(torch.autograd.Function):
     """An activation with two consumers (residual shortcut + main branch, encoder skip + next stage, decoder feature +
-    inv-depth head).  Forward hands out two aliases; backward sums the two gradients in one strided-view-aware pass
-    instead of autograd's generic add (whose non-contiguous path is 3x slower on channel-slice gradients)."""
+    inv-depth head).  Forward hands out two aliases that carry a shared `slot`; a consumer whose backward produces the data
+    gradient through a conv epilogue deposits it there, and the second one accumulates into the same buffer
+    (`accumulate` of mte_conv2d_igemm / mte_conv2d_patch_fwd; a decoder concat deposits its channel-slice view), so the
+    autograd sum of the two gradients usually costs no pass at all.  Otherwise backward adds them in one strided-view-aware
+    pass (autograd's generic add is 3x slower on channel-slice gradients)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot):
+        ctx.slot = slot
         return alias_of(x), alias_of(x)
 
     @staticmethod
     def backward(ctx, g1, g2):
+        slot = ctx.slot
         if g1 is None or g2 is None:
-            return g1 if g2 is None else g2
-        dt = g1.dtype if g1.dtype == g2.dtype else compute_dtype()
-        g1, g2 = as_act(g1, dt), as_act(g2, dt)
-        B, C, H, W = g1.shape
-        out = new_act(B, C, H, W, dt, g1.device)
-        p1, l1 = _pl(g1)
-        p2, l2 = _pl(g2)
-        po, lo = _pl(out)
-        lib.mte_add_channels(p1, l1, p2, l2, po, lo, B * H * W, C, _dt(out), _stream())
-        return out
+            out = g1 if g2 is None else g2
+        elif g1.data_ptr() == g2.data_ptr() and g1.shape == g2.shape and g1.stride() == g2.stride():
+            out = g1                                         # the consumers shared one buffer: it already holds the sum
+        else:
+            dt = g1.dtype if g1.dtype == g2.dtype else compute_dtype()
+            g1, g2 = as_act(g1, dt), as_act(g2, dt)
+            B, C, H, W = g1.shape
+            out = new_act(B, C, H, W, dt, g1.device)
+            p1, l1 = _pl(g1)
+            p2, l2 = _pl(g2)
+            po, lo = _pl(out)
+            lib.mte_add_channels(p1, l1, p2, l2, po, lo, B * H * W, C, _dt(out), _stream())
+        slot["buf"] = None
+        return out, None
 
 
 def fork(x):
     """-> two aliases of the NHWC activation x for its two consumers (see ForkFn); no-op without gradients"""
     if not (torch.is_grad_enabled() and x.requires_grad):
         return x, x
-    return ForkFn.apply(x)
+    slot = {"buf": None, "parent": getattr(x, "_mte_fork_slot", None)}
+    a, b = ForkFn.apply(x, slot)
+    a._mte_fork_slot = slot
+    b._mte_fork_slot = slot
+    return a, b
 
 
 class ConcatFn(torch.autograd.Function):
@@ -987,6 +1020,7 @@ class ConcatFn(torch.autograd.Function):
             lib.mte_upsample_inv_fwd(inv.contiguous().data_ptr(), dp, ldd, B, H // 2, W // 2, _dt(buf), st)
         ctx.chans = chans
         ctx.has_inv = inv is not None
+        ctx.slots = [getattr(p, "_mte_fork_slot", None) for p in parts]
         return buf
 
     @staticmethod
@@ -995,8 +1029,11 @@ class ConcatFn(torch.autograd.Function):
         B, _, H, W = dbuf.shape
         outs = []
         off = 0
-        for c in ctx.chans:
-            outs.append(dbuf[:, off:off + c])
+        for c, slot in zip(ctx.chans, ctx.slots):
+            g = dbuf[:, off:off + c]
+            if slot is not None and slot["buf"] is None and _fork_target(slot["parent"], g.shape, g.dtype) is None:
+                slot["buf"] = g                              # the other consumer's conv epilogue will add into this slice
+            outs.append(g)
             off += c
         dinv = None
         if ctx.has_inv:
