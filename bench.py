@@ -74,7 +74,7 @@ class ConvTimer:
                     elif name == "mte_conv2d_patch_fwd":
                         shp = args[6:13]           # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, KH, KW, stream)
                     else:
-                        shp = args[5:12]           # (x, ldx, dy, lddy, dw, B, H, W, Cin_p, N, KH, KW, ...)
+                        shp = args[7:14]           # (x, ldx, dy, lddy, dw, stage_parts, parts_out, B, H, W, Cin_p, N, KH, KW, ...)
                     B, H, W, Cin_p, N, KH, KW = shp
                     outer.records.append((name, e0, e1, 2.0 * B * H * W * Cin_p * N * KH * KW, tuple(shp)))
                 return timed

@@ -51,16 +51,19 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
 int mte_set_option(int option, int value);
 /* development knob (A/B experiments): key 0 = igemm tile loader, 1 = LDS-DMA (default), 0 = register staging */
 int mte_debug_set(int key, int value);
-/* weight gradient of the same conv: dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) */
-int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage,
+/* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
+ * pixels is split over workgroups; when their number fits stage_parts each one stores its PARTIAL gradient in its own part
+ * (plain stores; *parts_out = parts written, mte_unpack_conv_wgrad adds them), otherwise -- always with stage_parts = 1 --
+ * they are combined with fp32 atomics in part 0 (*parts_out = 1). */
+int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int stage_parts, int* parts_out,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
 /* OIHW fp32 master weights -> forward pack [Cout][taps][Cin_p] and (optional) dgrad pack [Cin_p][taps rot180][Cout_p] */
 int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout, int Cin, int KH, int KW,
                           int Cin_p, int Cout_p, int dtype, mte_stream_t stream);
 /* dgrad pack derived from an existing forward pack */
 int mte_pack_conv_weights_bwd(const void* wfwd, void* wbwd, int Cout, int KH, int KW, int Cin_p, int dtype, mte_stream_t stream);
-/* dw_stage -> OIHW fp32 gradient (drops channel padding) */
-int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, mte_stream_t stream);
+/* sum of the `parts` partial stages -> OIHW fp32 gradient (drops channel padding) */
+int mte_unpack_conv_wgrad(const float* dw_stage, int parts, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, mte_stream_t stream);
 /* out[N] = column sums of y[M][N] (conv bias gradient) */
 int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, mte_stream_t stream);
 
@@ -72,7 +75,7 @@ long mte_conv2d_patch_pack_elems(int Cin_p, int N, int KH, int KW);
 int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
                          int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, int accumulate, mte_stream_t stream);
-int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage,
+int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 
 /* ---- GroupNorm(16, C) + ELU, optionally over y1 + scale2[b,c]*y2 (residual tail with Dropout2d)

@@ -512,6 +512,7 @@ struct WgradArgs {
     long M;
     int splits, blocks_per_split;   // pixel blocks of 32
     int tiles_c, tiles_n;
+    long part_stride;               // > 0: pixel split s stores its partial gradient at dw + s * part_stride (no atomics)
 };
 
 template <int BYTES> __device__ __forceinline__ int padded_row(void) {
@@ -963,8 +964,8 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + (wno * TNO + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (n < a.N) {
-                    float* dst = a.dw + (long)n * Kp + (long)tap * a.Cin_p + cc;
-                    if (a.splits > 1) atomicAdd(dst, acc[i][j][e]);
+                    float* dst = a.dw + (long)split * a.part_stride + (long)n * Kp + (long)tap * a.Cin_p + cc;
+                    if (a.splits > 1 && a.part_stride == 0) atomicAdd(dst, acc[i][j][e]);
                     else *dst = acc[i][j][e];
                 }
             }
@@ -979,7 +980,7 @@ int g_wgrad_big = 1;                                 // development knob (mte_de
                                                      // (4x fewer re-reads of dy / x; pays once the pixel splits are few: g_wgrad_wgs)
 
 template <int WNO, int WC, int TNO, int TC>
-int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
+int launch_wgrad_dma(WgradArgs a, hipStream_t st, int parts_cap, int* parts_out) {
     constexpr int BNO = WNO * TNO * 32, BC = WC * TC * 32, NTHR = WNO * WC * 64;
     a.tiles_n = (a.N + BNO - 1) / BNO;
     a.tiles_c = (a.Cin_p + BC - 1) / BC;
@@ -995,7 +996,16 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st) {
     if (splits < 1) splits = 1;
     a.blocks_per_split = (int)((nblk + splits - 1) / splits);
     a.splits = (int)((nblk + a.blocks_per_split - 1) / a.blocks_per_split);
-    if (a.splits > 1 && hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+    // partial gradients per pixel split when the caller's stage has room for them: plain stores, summed by the unpack pass
+    // (the fp32 atomics of the combine-in-place form cost 0.4 ms per step: up to 64 K per workgroup onto shared addresses)
+    if (a.splits > 1 && a.splits <= parts_cap) {
+        a.part_stride = (long)a.N * taps * a.Cin_p;
+        if (parts_out) *parts_out = a.splits;
+    } else {
+        a.part_stride = 0;
+        if (parts_out) *parts_out = 1;
+        if (a.splits > 1 && hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+    }
     const size_t lds = WG_RING * 32 * (BNO + BC) * 2;
     const dim3 grid((unsigned)(base_wgs * a.splits));
     if (fl) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WNO, WC, TNO, TC, true>), grid, dim3(NTHR), lds, st, a);
@@ -1033,15 +1043,16 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
     return mte_check_launch();
 }
 
-template <typename T> int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
+template <typename T> int dispatch_wgrad(const WgradArgs& a, hipStream_t st, int parts_cap, int* parts_out) {
+    if (parts_out) *parts_out = 1;
     if constexpr (sizeof(T) == 2) {
         const bool fits = ((a.M + a.KW) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((a.M - 1) * a.ldy + a.N) * 2 < 0x7ff00000L;
         if (g_wgrad_dma && fits && a.N > 32 && a.Cin_p > 32)
         {
-            if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p % 256 == 0) return launch_wgrad_dma<4, 4, 2, 2>(a, st);   // 256 x 256, 16 waves
-            if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p >= 128) return launch_wgrad_dma<4, 2, 2, 2>(a, st);     // 256 x 128, 8 waves
-            if (g_wgrad_big && a.N >= 128 && a.Cin_p % 256 == 0) return launch_wgrad_dma<2, 4, 2, 2>(a, st);     // 128 x 256, 8 waves
-            return a.N <= 64 ? launch_wgrad_dma<2, 2, 1, 2>(a, st) : launch_wgrad_dma<2, 2, 2, 2>(a, st);
+            if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p % 256 == 0) return launch_wgrad_dma<4, 4, 2, 2>(a, st, parts_cap, parts_out);   // 256 x 256, 16 waves
+            if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p >= 128) return launch_wgrad_dma<4, 2, 2, 2>(a, st, parts_cap, parts_out);     // 256 x 128, 8 waves
+            if (g_wgrad_big && a.N >= 128 && a.Cin_p % 256 == 0) return launch_wgrad_dma<2, 4, 2, 2>(a, st, parts_cap, parts_out);     // 128 x 256, 8 waves
+            return a.N <= 64 ? launch_wgrad_dma<2, 2, 1, 2>(a, st, parts_cap, parts_out) : launch_wgrad_dma<2, 2, 2, 2>(a, st, parts_cap, parts_out);
         }
     }
     if (a.N <= 32) {
@@ -1096,7 +1107,7 @@ __global__ __launch_bounds__(256) void pack_weights_bwd_kernel(const T* __restri
 
 // staging [N][taps][Cin_p] fp32 -> OIHW fp32 gradient (overwrite).  One block = (output channel n, 64 input channels): the
 // [taps][64] slab is read along c (coalesced), transposed in LDS and written as one contiguous run of 64*taps floats.
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ st, float* __restrict__ dw, int Cout, int Cin, int taps, int Cin_p) {
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ st, float* __restrict__ dw, int Cout, int Cin, int taps, int Cin_p, int parts) {
     extern __shared__ float s_t[];                                   // [taps][64 + 1]
     const int n = blockIdx.x, c0 = blockIdx.y * 64;
     const int nc = min(64, Cin - c0);
@@ -1104,7 +1115,11 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     const float* src = st + (long)n * taps * Cin_p + c0;
     for (int i = threadIdx.x; i < taps * 64; i += 256) {
         const int tap = i >> 6, cl = i & 63;
-        if (cl < nc) s_t[tap * 65 + cl] = src[(long)tap * Cin_p + cl];
+        if (cl < nc) {
+            float v = 0.f;
+            for (int p = 0; p < parts; ++p) v += src[(long)p * Cout * taps * Cin_p + (long)tap * Cin_p + cl];     // partial gradients of the pixel splits
+            s_t[tap * 65 + cl] = v;
+        }
     }
     __syncthreads();
     float* dst = dw + ((long)n * Cin + c0) * taps;
@@ -1183,14 +1198,14 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
 }
 
 // dw_stage[N][KH*KW][Cin_p] (fp32) = sum over pixels of dy (x) shifted x.
-int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage,
+int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int stage_parts, int* parts_out,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dy || !dw_stage) return MTE_ERR_ARG;
     if (Cin_p % 8 != 0 || N % 8 != 0) return MTE_ERR_ARG;
     WgradArgs a{x, ldx, dy, ldy, dw_stage, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, 0, 0, 0};
-    if (dtype == MTE_DT_BF16) return dispatch_wgrad<bf16_t>(a, stream);
-    if (dtype == MTE_DT_F32) return dispatch_wgrad<float>(a, stream);
+    if (dtype == MTE_DT_BF16) return dispatch_wgrad<bf16_t>(a, stream, stage_parts, parts_out);
+    if (dtype == MTE_DT_F32) return dispatch_wgrad<float>(a, stream, stage_parts, parts_out);
     return MTE_ERR_UNSUPPORTED;
 }
 
@@ -1223,11 +1238,11 @@ int mte_pack_conv_weights_bwd(const void* wfwd, void* wbwd, int Cout, int KH, in
     return mte_check_launch();
 }
 
-int mte_unpack_conv_wgrad(const float* dw_stage, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, hipStream_t stream) {
+int mte_unpack_conv_wgrad(const float* dw_stage, int parts, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!dw_stage || !dw_oihw) return MTE_ERR_ARG;
+    if (!dw_stage || !dw_oihw || parts < 1) return MTE_ERR_ARG;
     const dim3 grid(Cout, (Cin + 63) / 64);
-    hipLaunchKernelGGL(unpack_wgrad_kernel, grid, dim3(256), sizeof(float) * KH * KW * 65, stream, dw_stage, dw_oihw, Cout, Cin, KH * KW, Cin_p);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, grid, dim3(256), sizeof(float) * KH * KW * 65, stream, dw_stage, dw_oihw, Cout, Cin, KH * KW, Cin_p, parts);
     return mte_check_launch();
 }
 

@@ -229,6 +229,7 @@ struct PatchWgradArgs {
     float* dw;                                     // [N][taps][Cin_p] fp32 stage, zeroed by the launcher
     int B, H, W, Cin_p, N;
     int groups;                                    // workgroups per channel slice
+    long part_stride;                              // > 0: group g stores its partial gradient at dw + g * part_stride (no atomics)
 };
 
 // SL = 32-channel input slices per workgroup (2 halves the dy re-reads and doubles the MFMA work per staged tile:
@@ -364,7 +365,10 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = n * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < a.N) atomicAdd(a.dw + ((long)co * TAPS + tap) * a.Cin_p + cc, acc[i][n][e]);
+                if (co < a.N) {
+                    float* dst = a.dw + (long)blockIdx.x * a.part_stride + ((long)co * TAPS + tap) * a.Cin_p + cc;
+                    if (a.part_stride) *dst = acc[i][n][e]; else atomicAdd(dst, acc[i][n][e]);
+                }
             }
     }
 }
@@ -394,7 +398,7 @@ template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
     return MTE_ERR_UNSUPPORTED;
 }
 
-template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream_t st) {
+template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream_t st, int parts_cap, int* parts_out) {
     constexpr int PH = TH + K - 1, PW = TW + K - 1;
     constexpr int XRS = SL == 1 ? 64 : 192, YRS = NT == 1 ? 64 : 192;
     const size_t lds = PH * PW * XRS + TH * TW * YRS;
@@ -409,23 +413,30 @@ template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream
             return MTE_ERR_LAUNCH;
         attr_set = true;
     }
-    if (hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (a.groups > 1 && a.groups <= parts_cap) {                // one partial gradient per group, summed by the unpack pass
+        a.part_stride = (long)a.N * K * K * a.Cin_p;
+        if (parts_out) *parts_out = a.groups;
+    } else {
+        a.part_stride = 0;
+        if (parts_out) *parts_out = 1;
+        if (hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT, SL>), dim3((unsigned)groups, nslices), dim3(256), lds, st, a);
     return mte_check_launch();
 }
-template <int K, int NT> int launch_wgrad(const PatchWgradArgs& a, hipStream_t st) {
+template <int K, int NT> int launch_wgrad(const PatchWgradArgs& a, hipStream_t st, int parts_cap, int* parts_out) {
     // two slices per workgroup where the accumulators still fit (3x3 and 1x1; 5x5 with C_out <= 32) and there is more than one slice
     if constexpr (K <= 3 || (K == 5 && NT == 1)) {
-        if (a.Cin_p > 32) return launch_wgrad_sl<K, NT, 2>(a, st);
+        if (a.Cin_p > 32) return launch_wgrad_sl<K, NT, 2>(a, st, parts_cap, parts_out);
     }
-    return launch_wgrad_sl<K, NT, 1>(a, st);
+    return launch_wgrad_sl<K, NT, 1>(a, st, parts_cap, parts_out);
 }
-template <int NT> int dispatch_wgrad(const PatchWgradArgs& a, int K, hipStream_t st) {
+template <int NT> int dispatch_wgrad(const PatchWgradArgs& a, int K, hipStream_t st, int parts_cap, int* parts_out) {
     switch (K) {
-        case 1: return launch_wgrad<1, NT>(a, st);
-        case 3: return launch_wgrad<3, NT>(a, st);
-        case 5: return launch_wgrad<5, NT>(a, st);
-        case 7: return launch_wgrad<7, NT>(a, st);
+        case 1: return launch_wgrad<1, NT>(a, st, parts_cap, parts_out);
+        case 3: return launch_wgrad<3, NT>(a, st, parts_cap, parts_out);
+        case 5: return launch_wgrad<5, NT>(a, st, parts_cap, parts_out);
+        case 7: return launch_wgrad<7, NT>(a, st, parts_cap, parts_out);
     }
     return MTE_ERR_UNSUPPORTED;
 }
@@ -473,12 +484,13 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
 }
 
 // dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) for C_out <= 64; bf16 only.
-int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage,
+int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dy || !dw_stage || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
     PatchWgradArgs a{(const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, dw_stage, B, H, W, Cin_p, N, 1};
-    return N <= 32 ? dispatch_wgrad<1>(a, KH, stream) : dispatch_wgrad<2>(a, KH, stream);
+    if (parts_out) *parts_out = 1;
+    return N <= 32 ? dispatch_wgrad<1>(a, KH, stream, stage_parts, parts_out) : dispatch_wgrad<2>(a, KH, stream, stage_parts, parts_out);
 }
 
 }  // extern "C"

@@ -468,13 +468,19 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     xp, ldx = _pl(x)
     st = _stream()
     dbias = None
-    stage = torch.empty((cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
+    # room for one partial gradient per pixel split (plain stores, summed by the unpack pass; +0.5 % over fp32 atomics for the
+    # generic kernel's <= 32 splits -- the patch kernel's 128..512 workgroup groups stay on atomics: summing that many parts
+    # in the unpack pass measured 7 % slower)
+    per = cout * kh * kw * Cp
+    cap = max(1, min(32, (96 << 20) // (4 * per)))
+    stage = torch.empty((cap, cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
+    parts = ctypes.c_int(1)
     if _patch_ok(W, Cp, cout, kh, kw, x.dtype):
-        lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, st)
+        lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, Cp, cout, kh, kw, st)
     else:
-        lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), B, H, W, Cp, cout, kh, kw, _dt(x), st)
+        lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, Cp, cout, kh, kw, _dt(x), st)
     dw = dw_out if dw_out is not None else torch.empty_like(w, dtype=torch.float32)
-    lib.mte_unpack_conv_wgrad(stage.data_ptr(), dw.data_ptr(), cout, cin, kh, kw, Cp, st)
+    lib.mte_unpack_conv_wgrad(stage.data_ptr(), parts.value, dw.data_ptr(), cout, cin, kh, kw, Cp, st)
     if need_dbias:
         dbias = dbias_out if dbias_out is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
         lib.mte_colsum(dyp, lddy, B * H * W, cout, dbias.data_ptr(), _dt(dy), st)
