@@ -117,6 +117,9 @@ int mte_unfold_pack_wgrad(const float* dWf, const float* dbf, const float* W, co
 int mte_pixel_shuffle(const void* src, long lds_, void* dst, long ldd, int B, int H, int W, int C, int dir, int dtype, mte_stream_t stream);
 int mte_copy_rect(const void* src, long lds_, int Hs, int Ws, int sy, int sx, void* dst, long ldd, int Hd, int Wd, int dy, int dx,
                   int B, int h, int w, int C, int mode, int dtype, mte_stream_t stream);
+/* the same for up to 8 rectangles in ONE launch; ops = HOST array of n records (device pointers inside) */
+typedef struct { const void* src; long lds_; int Hs, Ws, sy, sx; void* dst; long ldd; int Hd, Wd, dy, dx, h, w, mode; } mte_rect_op;
+int mte_copy_rects(const void* ops, int n, int B, int C, int dtype, mte_stream_t stream);
 
 /* ---- InvDepth head: sigmoid(conv3x3(x) + b) / min_depth  (layers01.py:99-123) */
 int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,

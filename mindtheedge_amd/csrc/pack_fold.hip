@@ -210,6 +210,37 @@ __global__ void copy_rect_kernel(const T* __restrict__ src, long lds_, int Hs, i
     }
 }
 
+// up to 8 rectangle operations in one launch (blockIdx.y = operation): the folded pack layers move four thin border bands
+// in, out, and back per pass -- 60 launches of ~5 us per training step when issued one by one
+struct RectOp { const void* src; long lds_; int Hs, Ws, sy, sx; void* dst; long ldd; int Hd, Wd, dy, dx, h, w, mode; };
+struct RectOps { RectOp op[8]; };
+
+template <typename T>
+__global__ void copy_rects_kernel(RectOps ops, int B, int C) {
+    const RectOp& o = ops.op[blockIdx.y];
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P;
+    const long total = (long)B * o.h * o.w * cpr;
+    const T* src = (const T*)o.src;
+    T* dst = (T*)o.dst;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cpr); long t = i / cpr;
+        const int x = (int)(t % o.w); t /= o.w;
+        const int y = (int)(t % o.h); const int b = (int)(t / o.h);
+        T* q = dst + (((long)b * o.Hd + o.dy + y) * o.Wd + o.dx + x) * o.ldd + cc * P;
+        if (o.mode == 2) { *(u32x4_t*)q = u32x4_t{0u, 0u, 0u, 0u}; continue; }
+        const u32x4_t sv = *(const u32x4_t*)(src + (((long)b * o.Hs + o.sy + y) * o.Ws + o.sx + x) * o.lds_ + cc * P);
+        if (o.mode == 0) *(u32x4_t*)q = sv;
+        else {
+            float a[P], c[P];
+            unpack16<T>(sv, a); unpack16<T>(*(const u32x4_t*)q, c);
+#pragma unroll
+            for (int e = 0; e < P; ++e) c[e] += a[e];
+            *(u32x4_t*)q = pack16<T>(c);
+        }
+    }
+}
+
 inline int sgrid(long n) { long g = (n + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -257,6 +288,28 @@ int mte_copy_rect(const void* src, long lds_, int Hs, int Ws, int sy, int sx, vo
     const int grid = sgrid((long)B * h * w * (C / per16));
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(copy_rect_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, lds_, Hs, Ws, sy, sx, (bf16_t*)dst, ldd, Hd, Wd, dy, dx, B, h, w, C, mode);
     else hipLaunchKernelGGL(copy_rect_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)src, lds_, Hs, Ws, sy, sx, (float*)dst, ldd, Hd, Wd, dy, dx, B, h, w, C, mode);
+    return mte_check_launch();
+}
+
+// n <= 8 rectangle operations (HOST array of mte_rect_op, see the header) on tensors of equal batch and channel count
+int mte_copy_rects(const void* ops_host, int n, int B, int C, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!ops_host || n < 1 || n > 8 || C % 8 != 0) return MTE_ERR_ARG;
+    RectOps ops{};
+    long most = 0;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    for (int i = 0; i < n; ++i) {
+        const RectOp& o = ((const RectOp*)ops_host)[i];
+        if (!o.dst || (o.mode != 2 && !o.src) || o.h <= 0 || o.w <= 0) return MTE_ERR_ARG;
+        if (o.sy < 0 || o.sx < 0 || o.dy < 0 || o.dx < 0 || o.dy + o.h > o.Hd || o.dx + o.w > o.Wd ||
+            (o.mode != 2 && (o.sy + o.h > o.Hs || o.sx + o.w > o.Ws))) return MTE_ERR_ARG;
+        ops.op[i] = o;
+        const long t = (long)B * o.h * o.w * (C / per16);
+        if (t > most) most = t;
+    }
+    const dim3 grid(sgrid(most), n);
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(copy_rects_kernel<bf16_t>, grid, dim3(256), 0, stream, ops, B, C);
+    else hipLaunchKernelGGL(copy_rects_kernel<float>, grid, dim3(256), 0, stream, ops, B, C);
     return mte_check_launch();
 }
 

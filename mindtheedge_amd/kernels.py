@@ -729,6 +729,30 @@ def _rect(src, sy, sx, dst, dy, dx, h, w, mode=0):
     lib.mte_copy_rect(sp, lds_, src.shape[2], src.shape[3], sy, sx, dp, ldd, Hd, Wd, dy, dx, B, h, w, C, mode, _dt(dst), _stream())
 
 
+class _RectOp(ctypes.Structure):          # mte_rect_op of include/mte_kernels.h
+    _fields_ = [("src", ctypes.c_void_p), ("lds_", ctypes.c_long), ("Hs", ctypes.c_int), ("Ws", ctypes.c_int), ("sy", ctypes.c_int),
+                ("sx", ctypes.c_int), ("dst", ctypes.c_void_p), ("ldd", ctypes.c_long), ("Hd", ctypes.c_int), ("Wd", ctypes.c_int),
+                ("dy", ctypes.c_int), ("dx", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("mode", ctypes.c_int)]
+
+
+def _rects(ops):
+    """Several _rect operations in one launch.  ops: (src or None, sy, sx, dst, dy, dx, h, w, mode) with equal batch/channels."""
+    arr = (_RectOp * len(ops))()
+    B = C = dt = None
+    for o, (src, sy, sx, dst, dy, dx, h, w, mode) in zip(arr, ops):
+        Bd, Cd, Hd, Wd = dst.shape
+        if B is None:
+            B, C, dt = Bd, Cd, _dt(dst)
+        elif (Bd, Cd, _dt(dst)) != (B, C, dt):
+            raise MteError("rectangle batch: mixed batch / channel / dtype")
+        dp, ldd = _pl(dst)
+        o.dst, o.ldd, o.Hd, o.Wd, o.dy, o.dx, o.h, o.w, o.mode = dp, ldd, Hd, Wd, dy, dx, h, w, mode
+        if mode != 2:
+            sp, lds_ = _pl(src)
+            o.src, o.lds_, o.Hs, o.Ws, o.sy, o.sx = sp, lds_, src.shape[2], src.shape[3], sy, sx
+    lib.mte_copy_rects(ctypes.addressof(arr), len(ops), B, C, dt, _stream())
+
+
 def _deliver(p, t):
     """hand a finished parameter gradient to the sink (flat buffer) or back to autograd"""
     sk = _sink["active"]
@@ -798,11 +822,9 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         # exact border bands: group 1 = top/bottom rows, group 2 = left/right columns (rows pad .. H2-pad)
         wu, _ = pack_unf.get(w, x.dtype, False)
         xb1 = new_act(2 * B, C, 2 * hb, W, x.dtype, dev)
-        _rect(x, 0, 0, xb1[:B], 0, 0, 2 * hb, W)
-        _rect(x, H - 2 * hb, 0, xb1[B:], 0, 0, 2 * hb, W)
         xb2 = new_act(2 * B, C, H, 2 * hb, x.dtype, dev)
-        _rect(x, 0, 0, xb2[:B], 0, 0, H, 2 * hb)
-        _rect(x, 0, W - 2 * hb, xb2[B:], 0, 0, H, 2 * hb)
+        _rects([(x, 0, 0, xb1[:B], 0, 0, 2 * hb, W, 0), (x, H - 2 * hb, 0, xb1[B:], 0, 0, 2 * hb, W, 0),
+                (x, 0, 0, xb2[:B], 0, 0, H, 2 * hb, 0), (x, 0, W - 2 * hb, xb2[B:], 0, 0, H, 2 * hb, 0)])
         Tb = []
         for xb, (hh, ww) in ((xb1, (hb, W2)), (xb2, (H2, hb))):
             T = new_act(2 * B, 16 * C, hh, ww, x.dtype, dev)
@@ -812,10 +834,8 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
             Tb.append(T)
         yb1 = conv_forward(Tb[0], wu, b, co, k, k, pack=pack_unf, w=w)
         yb2 = conv_forward(Tb[1], wu, b, co, k, k, pack=pack_unf, w=w)
-        _rect(yb1[:B], 0, 0, y, 0, 0, pad, W2)
-        _rect(yb1[B:], hb - pad, 0, y, H2 - pad, 0, pad, W2)
-        _rect(yb2[:B], pad, 0, y, pad, 0, H2 - 2 * pad, pad)
-        _rect(yb2[B:], pad, hb - pad, y, pad, W2 - pad, H2 - 2 * pad, pad)
+        _rects([(yb1[:B], 0, 0, y, 0, 0, pad, W2, 0), (yb1[B:], hb - pad, 0, y, H2 - pad, 0, pad, W2, 0),
+                (yb2[:B], pad, 0, y, pad, 0, H2 - 2 * pad, pad, 0), (yb2[B:], pad, hb - pad, y, pad, W2 - pad, H2 - 2 * pad, pad, 0)])
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out))
         ctx.save_for_backward(P, xb1, xb2, Tb[0], Tb[1], y, stats, w, w3c, b3c, gamma, beta, Wf)
         ctx.params = (w3, b3, b)
@@ -834,11 +854,9 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         dy, _, dgamma, dbeta = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False)
         # ---- band paths (unfolded, exact)
         dyb1 = torch.zeros((2 * B, hb, W2, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
-        _rect(dy, 0, 0, dyb1[:B], 0, 0, pad, W2)
-        _rect(dy, H2 - pad, 0, dyb1[B:], hb - pad, 0, pad, W2)
         dyb2 = torch.zeros((2 * B, H2, hb, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
-        _rect(dy, pad, 0, dyb2[:B], pad, 0, H2 - 2 * pad, pad)
-        _rect(dy, pad, W2 - pad, dyb2[B:], pad, hb - pad, H2 - 2 * pad, pad)
+        _rects([(dy, 0, 0, dyb1[:B], 0, 0, pad, W2, 0), (dy, H2 - pad, 0, dyb1[B:], hb - pad, 0, pad, W2, 0),
+                (dy, pad, 0, dyb2[:B], pad, 0, H2 - 2 * pad, pad, 0), (dy, pad, W2 - pad, dyb2[B:], pad, hb - pad, H2 - 2 * pad, pad, 0)])
         dTs, dxb = [], []
         for xb, T, dyb in ((xb1, T1, dyb1), (xb2, T2, dyb2)):
             dT, _, _ = conv_backward(T, dyb, w, pack_unf, True, need_dw=False)
@@ -850,10 +868,8 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
             dTs.append(dT)
             dxb.append(dxi)
         # ---- interior path (folded): band pixels carry no gradient here
-        _rect(None, 0, 0, dy, 0, 0, pad, W2, mode=2)
-        _rect(None, 0, 0, dy, H2 - pad, 0, pad, W2, mode=2)
-        _rect(None, 0, 0, dy, pad, 0, H2 - 2 * pad, pad, mode=2)
-        _rect(None, 0, 0, dy, pad, W2 - pad, H2 - 2 * pad, pad, mode=2)
+        _rects([(None, 0, 0, dy, 0, 0, pad, W2, 2), (None, 0, 0, dy, H2 - pad, 0, pad, W2, 2),
+                (None, 0, 0, dy, pad, 0, H2 - 2 * pad, pad, 2), (None, 0, 0, dy, pad, W2 - pad, H2 - 2 * pad, pad, 2)])
 
         def weight_grads():
             """every parameter gradient of the layer except gamma/beta; nothing on the data-gradient chain needs them"""
@@ -886,10 +902,9 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         sp, lds_ = _pl(dP)
         dp_, ldd = _pl(dx)
         lib.mte_pixel_shuffle(sp, lds_, dp_, ldd, B, H, W, C, 1, dt, st)
-        _rect(dxb[0][:B], 0, 0, dx, 0, 0, 2 * hb, W, mode=1)
-        _rect(dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, mode=1)
-        _rect(dxb[1][:B], 0, 0, dx, 0, 0, H, 2 * hb, mode=1)
-        _rect(dxb[1][B:], 0, 0, dx, 0, W - 2 * hb, H, 2 * hb, mode=1)
+        # (the four bands overlap in the corners: two launches so that no element is read-modified by two operations at once)
+        _rects([(dxb[0][:B], 0, 0, dx, 0, 0, 2 * hb, W, 1), (dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, 1)])
+        _rects([(dxb[1][:B], 0, 0, dx, 0, 0, H, 2 * hb, 1), (dxb[1][B:], 0, 0, dx, 0, W - 2 * hb, H, 2 * hb, 1)])
         return (dx, g3, gb3, gw, gb, _deliver(gamma, dgamma), _deliver(beta, dbeta), None, None, None)
 
 
