@@ -42,9 +42,6 @@ def parse_header(path=HEADER):
     return protos
 
 
-_SKIP = set(filter(None, os.environ.get("MTE_SKIP", "").split(",")))
-
-
 class _Lib:
     def __init__(self):
         self._dll = None
@@ -71,9 +68,6 @@ class _Lib:
             fn = getattr(self.load(), name)
             if name in QUERIES:
                 return fn
-
-            if name in _SKIP:                      # timing experiments only: MTE_SKIP=mte_a,mte_b turns those entry points into no-ops
-                return lambda *args: None
 
             def call(*args):
                 rc = fn(*args)
