@@ -121,3 +121,34 @@ def test_full_size_side_stream_schedule_does_not_change_gradients():
     assert la == pytest.approx(lb, rel=1e-6)
     assert float((ga - gb).norm()) <= 1e-3 * float(gb.norm())
     assert float(gb.norm()) > 0
+
+
+def test_high_resolution_768x2560_training_step_is_finite_and_matches_fp32_loss():
+    """BASELINE.json's high-resolution configuration (768x2560): one bf16 training step, every gradient finite, loss within
+    the north-star tolerance of the fp32-mode loss of the same kernels."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.utils.synthetic import synthetic_batch
+    batch = synthetic_batch(1, 768, 2560, 5, torch.device("cuda"))
+    losses = {}
+    try:
+        for dtype in ("bf16", "fp32"):
+            K.set_grad_sink(None)
+            net, model = _model(dtype)
+            model.train()
+            out = model(batch)
+            loss = out["loss"].sum()
+            if dtype == "bf16":
+                loss.backward()
+                K.join_side_stream()
+                torch.cuda.synchronize()
+                for n, p in net.named_parameters():
+                    if p.requires_grad and p.grad is not None:
+                        assert bool(torch.isfinite(p.grad).all()), n
+                assert tuple(out["inv_depths"][0].shape) == (1, 1, 768, 2560) if "inv_depths" in out else True
+            losses[dtype] = float(loss.detach())
+            del net, model, out, loss
+            torch.cuda.empty_cache()
+        assert abs(losses["bf16"] - losses["fp32"]) <= 1e-3 * abs(losses["fp32"])
+    finally:
+        K.set_grad_sink(None)
+        K.set_compute_dtype("bf16")
