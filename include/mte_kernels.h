@@ -49,7 +49,13 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
  * one arena per step with a single memset) and the library skips its own per-call hipMemsetAsync. */
 #define MTE_OPT_GN_PREZEROED 0
 int mte_set_option(int option, int value);
-/* development knob (A/B experiments): key 0 = igemm tile loader, 1 = LDS-DMA (default), 0 = register staging */
+/* development knobs for same-box A/B measurements (tools/sweep.sh); not part of the integration surface.  key:
+ *   0 igemm loader (1 buffer-descriptor LDS-DMA [default], 2 pointer LDS-DMA, 0 register staging)
+ *   1 conv3d kernels (0 gather, 1 LDS-tiled, 2 + four-plane unpack data gradient [default]; 100/101 large/half-size tiles)
+ *   2 / 3 GroupNorm launch geometry (min rows per thread / target workgroups)
+ *   4 wgrad kernel (1 LDS-DMA ring [default], 0 register-staged)      6 igemm tiles (0 128x128, 1 + 256x128, 2 + 256x256 [default])
+ *   7 min tiles for the big igemm tiles (224)   8 wgrad 8/16-wave tiles (1)   9 wgrad workgroup target (512)
+ *   11 patch conv: 0/1 tall 16x32 tiles, >= 100 = workgroup target of the patch wgrad (512) */
 int mte_debug_set(int key, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
  * pixels is split over workgroups; when their number fits stage_parts each one stores its PARTIAL gradient in its own part
