@@ -434,6 +434,16 @@ def join_side_stream():
     _side["keep_bytes"] = 0
 
 
+def side_streams_wait_into(stream):
+    """Make ``stream`` wait for the weight-gradient kernels queued so far WITHOUT joining them into the current stream
+    (used by the gradient all-reduce, which must not stall the rest of backward)."""
+    if _side["dirty"]:
+        for st in _side["streams"]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            stream.wait_event(ev)
+
+
 def _side_join_callback():
     _side["callback_queued"] = False
     join_side_stream()

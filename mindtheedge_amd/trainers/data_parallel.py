@@ -77,6 +77,7 @@ class BucketedAllReduce:
         self._seen = set()          # a parameter may be announced by both the gradient sink and its autograd hook
         self._works = []
         self._hooks = []
+        self._stream = None         # collectives are issued from here (see _launch)
         if self.world > 1:
             for p in flat.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
@@ -91,10 +92,23 @@ class BucketedAllReduce:
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b][2]:
             s, e, _ = self.buckets[b]
-            if self.flat.grad.is_cuda:
-                from .. import kernels as K
-                K.join_side_stream()                        # weight gradients of this bucket may still be on the side stream
-            self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._launch(s, e)
+
+    def _launch(self, s, e):
+        g = self.flat.grad[s:e]
+        if not g.is_cuda:
+            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        # The bucket's gradients were produced on the main stream AND on the weight-gradient side stream.  Order the
+        # collective after both from a third stream, so that the main stream (the rest of backward) never stalls on
+        # the side stream's lag at a bucket boundary.
+        from .. import kernels as K
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        K.side_streams_wait_into(self._stream)
+        with torch.cuda.stream(self._stream):
+            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Wait for every launched collective; reduce buckets whose hooks never completed (unused parameters).
@@ -105,7 +119,7 @@ class BucketedAllReduce:
         if self.world > 1:
             for b, (s, e, n) in enumerate(self.buckets):
                 if self._ready[b] != n:
-                    self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._launch(s, e)
             for w in self._works:
                 w.wait()
         self._works, self._ready = [], [0] * len(self.buckets)
