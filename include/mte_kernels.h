@@ -163,6 +163,22 @@ int mte_silog_bwd(const float* inv, const float* depth, const float* aux, const 
 int mte_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   int step, float gscale, mte_stream_t stream);
 
+/* ---- validation depth metrics: fp32 [B,1,H,W] maps, no host synchronisation
+ * mte_post_process_inv_depth = post_process_inv_depth (utils/depth.py:230-256); method 0 'mean', 1 'max', 2 'min'
+ *   (fuse_inv_depth, utils/depth.py:202-227).  `inv_depth_flipped` is the network output on the mirrored image.
+ * mte_depth_metrics = compute_depth_metrics (utils/depth.py:259-325): `pred` [B,1,h,w] is brought to the ground-truth
+ *   resolution by scale_mode 0 'resize' (bilinear, align_corners=True) or 1 'top-center' (utils/depth.py:328-361);
+ *   valid = min_depth < gt < max_depth (and the garg crop window); with use_gt_scale the prediction is multiplied by
+ *   median(gt)/median(pred) over the valid pixels (torch.median = element of rank (n-1)/2); out7 receives
+ *   (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3) averaged over the B images (images without a valid pixel add 0).
+ *   `workspace` needs mte_depth_metrics_workspace_bytes(B) bytes, 8-byte aligned; its content on entry is ignored. */
+long mte_depth_metrics_workspace_bytes(int B);
+int mte_depth_metrics(const float* gt, const float* pred, int B, int H, int W, int h, int w, int scale_mode, int garg_crop,
+                      float min_depth, float max_depth, int use_gt_scale, void* workspace, long workspace_bytes,
+                      float* out7, mte_stream_t stream);
+int mte_post_process_inv_depth(const float* inv_depth, const float* inv_depth_flipped, float* out, int B, int H, int W,
+                               int method, mte_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

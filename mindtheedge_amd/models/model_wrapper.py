@@ -1,14 +1,19 @@
 """Registry + step API the reference trainer talks to (packnet_sfm/models/model_wrapper.py): ``setup_model``,
 ``setup_depth_net``, ``setup_depth_edge_loss`` (:561-672), ``configure_optimizers`` (:142-180), ``training_step``
-(:197-213), ``depth`` (:318-321).  Dataloaders / metric printing are out of scope."""
+(:197-213), ``depth`` (:318-321), and the depth half of validation: ``evaluate_depth`` (:328-352), ``validation_step``
+(:215-225), ``validation_epoch_end`` (:255-277) with the metrics computed on the device.
+Dataloaders, metric printing and the Canny/chamfer edge metrics (OpenCV) are out of scope."""
 import random
+import warnings
+from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 
 from ..utils.load import load_class, load_class_args_create, load_network, filter_args
 from ..losses.grad_loss import GradLoss
-from .model_utils import stack_batch
+from ..utils.depth import inv2depth, post_process_inv_depth, compute_depth_metrics
+from .model_utils import stack_batch, flip_lr
 
 
 def set_random_seed(seed):
@@ -54,6 +59,9 @@ class ModelWrapper(nn.Module):
         set_random_seed(config.arch.seed)
         self.model = self.optimizer = self.scheduler = None
         self.current_epoch = 0
+        self.metrics_name = 'depth'
+        self.metrics_keys = ('abs_rel', 'sqr_rel', 'rmse', 'rmse_log', 'a1', 'a2', 'a3')
+        self.metrics_modes = ('', '_pp', '_gt', '_pp_gt')
         self.model = setup_model(config, prepared=resume is not None)
         if resume and 'state_dict' in resume:
             self.load_state_dict(resume['state_dict'])
@@ -99,6 +107,54 @@ class ModelWrapper(nn.Module):
         batch = stack_batch(batch)
         output = self.model(batch, progress=self.progress)
         return {'loss': output['loss'], 'metrics': output['metrics']}
+
+    @torch.no_grad()
+    def evaluate_depth(self, batch, args=None):
+        """Depth metrics of one validation batch, entirely on the device: prediction, prediction on the mirrored
+        input, flip-TTA fusion, and the 7 metrics x 4 modes ('', '_pp', '_gt', '_pp_gt') -- reference :328-352.
+        The metrics stay DEVICE tensors (float32[7]); nothing here synchronises with the host."""
+        inv_depths = self.model(batch)['inv_depths'][0]
+        inv_depth = inv_depths[0][:, 0:1, :, :]
+        depth = inv2depth(inv_depth)
+        flipped = dict(batch)
+        for key in ('rgb', 'input_depth', 'rgb_edge'):
+            if key in flipped:
+                flipped[key] = flip_lr(flipped[key])
+        inv_depth_flipped = self.model(flipped)['inv_depths'][0][0][:, 0:1, :, :]
+        inv_depth_pp = post_process_inv_depth(inv_depth, inv_depth_flipped, method='mean')
+        depth_pp = inv2depth(inv_depth_pp)
+        metrics = OrderedDict()
+        if 'depth' in batch:
+            for mode in self.metrics_modes:
+                metrics[self.metrics_name + mode] = compute_depth_metrics(
+                    self.config.model.params, gt=batch['depth'], pred=depth_pp if 'pp' in mode else depth,
+                    use_gt_scale='gt' in mode)
+        if 'edge' in batch and not getattr(self, '_warned_edges', False):
+            self._warned_edges = True
+            warnings.warn("edge precision/recall/F1 (cv2.Canny + chamfer, reference :354-442) are not computed by this "
+                          "build (SURVEY.md 8 f-3: OpenCV arithmetic, parity unpinned)")
+        return {'metrics': metrics, 'inv_depth': inv_depth_pp}
+
+    def validation_step(self, batch, *args):
+        output = self.evaluate_depth(stack_batch(batch), args)
+        return {'idx': batch.get('idx'), **output['metrics']}
+
+    def validation_epoch_end(self, output_data_batch):
+        """Mean of the per-batch metrics over the epoch (and over ranks) -> {'depth-abs_rel_pp_gt': float, ...}.
+        One host read per epoch."""
+        import torch.distributed as dist
+        names = [self.metrics_name + m for m in self.metrics_modes]
+        rows = [torch.stack([o[n] for n in names]) for o in output_data_batch if all(n in o for n in names)]
+        if not rows:
+            return {}
+        total = torch.stack(rows).sum(0)
+        count = torch.tensor(float(len(rows)), device=total.device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(total)
+            dist.all_reduce(count)
+        mean = (total / count).cpu()
+        return {'{}-{}{}'.format(self.metrics_name, key, mode): float(mean[i, j])
+                for i, mode in enumerate(self.metrics_modes) for j, key in enumerate(self.metrics_keys)}
 
     def depth(self, rgb, **kwargs):
         return self.model.depth_net(rgb=rgb, **kwargs)

@@ -24,6 +24,7 @@ _DEFAULTS = {
         'name': 'SemiSupEdgeModel', 'checkpoint_path': '',
         'optimizer': {'name': 'Adam', 'depth': {'lr': 0.0002, 'weight_decay': 0.0}},
         'scheduler': {'name': 'StepLR', 'step_size': 10, 'gamma': 0.5},
+        'params': {'crop': '', 'min_depth': 0.0, 'max_depth': 80.0, 'scale_output': 'resize'},     # default_config.py:84-87
         'loss': {'supervised_method': 'sparse-l1', 'supervised_num_scales': 4, 'supervised_loss_weight': 0.9,
                  'depth_edges_loss_weight': 1.0, 'edges_depth_edge_loss_all_scales': False, 'upsample_depth_maps': False,
                  'flip_lr_prob': 0.5, 'progressive_scaling': 0.0},
