@@ -179,6 +179,22 @@ int mte_depth_metrics(const float* gt, const float* pred, int B, int H, int W, i
 int mte_post_process_inv_depth(const float* inv_depth, const float* inv_depth_flipped, float* out, int B, int H, int W,
                                int method, mte_stream_t stream);
 
+/* ---- depth-edge annotation post-processing: fp32 [B,H,W] maps
+ * mte_dee_sobel_nms: prob = pred*scale (the '/2' of infer_edge_estimation.py:192); 5x5 Sobel as cv2.Sobel(CV_64F, ksize=5);
+ *   normals_u8 = uint8(((atan2(-sy,sx)*180/pi+180)/360)*255) (infer_edge_estimation.py:194-200) and/or
+ *   nms = non_max_suppression(prob) (utils/tools.py:9-46; zero one-pixel frame).  Either output may be NULL.
+ * hysteresis(img, t_low, t_high) (utils/tools.py:49-92) in three steps so that the host decides when to stop sweeping:
+ *   mte_hysteresis_begin      classify into `state` (B*H*W bytes), reset `info` (B*4 ints)
+ *   mte_hysteresis_propagate  run `sweeps` propagation sweeps; `flags` (sweeps+1 ints) is reset by the call and
+ *                             flags[sweeps] != 0 afterwards means the last sweep still changed pixels: call again
+ *   mte_hysteresis_finish     out = img * state/max(state), including the reference's treatment of the frame */
+int mte_dee_sobel_nms(const float* pred, float scale, unsigned char* normals_u8, float* nms, int B, int H, int W, mte_stream_t stream);
+int mte_hysteresis_begin(const float* img, unsigned char* state, int* info, int B, int H, int W, double t_low, double t_high,
+                         mte_stream_t stream);
+int mte_hysteresis_propagate(unsigned char* state, int* flags, int sweeps, int B, int H, int W, mte_stream_t stream);
+int mte_hysteresis_finish(const float* img, const unsigned char* state, const int* info, float* out, int B, int H, int W,
+                          mte_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

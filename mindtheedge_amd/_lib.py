@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mte_kernels.h")
 LIB_PATH = os.environ.get("MTE_LIB_PATH") or os.path.join(_HERE, "csrc", "libmte_hip.so")   # (override: A/B of two builds)
 
-_CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "mte_stream_t": ctypes.c_void_p}
+_CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double, "mte_stream_t": ctypes.c_void_p}
 _ERRORS = {-1: "MTE_ERR_ARG (bad argument / unsupported shape)", -2: "MTE_ERR_LAUNCH (HIP launch failed)",
            -3: "MTE_ERR_UNSUPPORTED"}
 
