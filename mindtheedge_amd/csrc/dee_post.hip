@@ -92,11 +92,11 @@ __device__ __forceinline__ float key_to_float(unsigned k) { return __uint_as_flo
 __global__ __launch_bounds__(256) void hyst_classify_kernel(const float* __restrict__ img, unsigned char* __restrict__ state,
                                                             unsigned* __restrict__ info, int H, int W, double t_low, double t_high) {
     const int b = blockIdx.y;
-    const long n = (long)H * W;
+    const int n = H * W;                                       // < 2^31, checked by the caller
     bool strong = false, nan = false;
     unsigned fkey = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i % W);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int y = i / W, x = i - y * W;
         const float v = img[(long)b * n + i];
         unsigned char s;
         if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1) {
@@ -108,11 +108,18 @@ __global__ __launch_bounds__(256) void hyst_classify_kernel(const float* __restr
         }
         state[(long)b * n + i] = s;
     }
-    if (__any(strong) && (threadIdx.x & 63) == 0) atomicOr(&info[b * 4 + 0], 1u);
-    if (__any(nan) && (threadIdx.x & 63) == 0) atomicOr(&info[b * 4 + 2], 1u);
+    // one atomic per block and word: device-scope atomics on one address serialise at ~8 ns each across the 8 XCDs
+    __shared__ unsigned skey[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fkey = max(fkey, (unsigned)__shfl_xor((int)fkey, o, 64));
-    if ((threadIdx.x & 63) == 0 && fkey) atomicMax(&info[b * 4 + 1], fkey);
+    if ((threadIdx.x & 63) == 0) skey[threadIdx.x >> 6] = fkey;
+    const int any_strong = __syncthreads_or(strong), any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) {
+        if (any_strong) atomicOr(&info[b * 4 + 0], 1u);
+        if (any_nan) atomicOr(&info[b * 4 + 2], 1u);
+        const unsigned k = max(max(skey[0], skey[1]), max(skey[2], skey[3]));
+        if (k) atomicMax(&info[b * 4 + 1], k);
+    }
 }
 
 __device__ __forceinline__ bool is_strong(unsigned char v) { return v == 2 || v == 4; }
@@ -157,19 +164,19 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(unsigned char* __re
             }
         }
     }
-    if (__any(any_change) && (threadIdx.x & 63) == 0) atomicOr(&flags[sweep], 1);
+    if (__syncthreads_or(any_change) && threadIdx.x == 0) atomicOr(&flags[sweep], 1);      // one atomic per block (see classify)
 }
 
 __global__ __launch_bounds__(256) void hyst_finish_kernel(const float* __restrict__ img, const unsigned char* __restrict__ state,
                                                           const unsigned* __restrict__ info, float* __restrict__ out, int H, int W) {
     const int b = blockIdx.y;
-    const long n = (long)H * W;
+    const int n = H * W;
     const bool interior = H > 2 && W > 2;
     double maxv = -__builtin_huge_val();
     if (info[b * 4 + 1]) maxv = (double)key_to_float(info[b * 4 + 1]);
     if (interior) maxv = fmax(maxv, info[b * 4 + 0] ? 2.0 : 0.0);
     if (info[b * 4 + 2]) maxv = __builtin_nan("");
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float v = img[(long)b * n + i];
         const unsigned char s = state[(long)b * n + i];
         const double t = s >= 3 ? (double)v : s == 2 ? 2.0 : 0.0;
@@ -187,9 +194,9 @@ extern "C" int mte_dee_sobel_nms(const float* pred, float scale, unsigned char* 
 
 extern "C" int mte_hysteresis_begin(const float* img, unsigned char* state, int* info, int B, int H, int W, double t_low, double t_high,
                                     hipStream_t stream) {
-    if (!img || !state || !info || B <= 0 || H <= 0 || W <= 0) return MTE_ERR_ARG;
+    if (!img || !state || !info || B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 30)) return MTE_ERR_ARG;
     if (hipMemsetAsync(info, 0, (size_t)B * 4 * sizeof(int), stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    const int bx = std::min(cdiv((long)H * W, 256 * 4), 512);
+    const int bx = std::min(cdiv((long)H * W, 256 * 8), 512);
     hipLaunchKernelGGL(hyst_classify_kernel, dim3(bx, B), dim3(256), 0, stream, img, state, (unsigned*)info, H, W, t_low, t_high);
     return mte_check_launch();
 }
@@ -205,8 +212,8 @@ extern "C" int mte_hysteresis_propagate(unsigned char* state, int* flags, int sw
 
 extern "C" int mte_hysteresis_finish(const float* img, const unsigned char* state, const int* info, float* out, int B, int H, int W,
                                      hipStream_t stream) {
-    if (!img || !state || !info || !out || B <= 0 || H <= 0 || W <= 0) return MTE_ERR_ARG;
-    const int bx = std::min(cdiv((long)H * W, 256 * 4), 512);
+    if (!img || !state || !info || !out || B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 30)) return MTE_ERR_ARG;
+    const int bx = std::min(cdiv((long)H * W, 256 * 4), 2048);
     hipLaunchKernelGGL(hyst_finish_kernel, dim3(bx, B), dim3(256), 0, stream, img, state, (const unsigned*)info, out, H, W);
     return mte_check_launch();
 }
