@@ -74,52 +74,63 @@ __device__ __forceinline__ void sobel4(const float* sd, int ly, int lx, float& s
     slr = (n[5] - n[1]) + 2.f * (n[8] - n[0]) + (n[7] - n[3]);
 }
 
+constexpr int FWD_TILES = 8;            // output tiles per block (stacked in y): one set of atomics per 8 tiles
+
 __global__ __launch_bounds__(256) void edge_loss_fwd_kernel(EdgeArgs a) {
     __shared__ float sd[(TY + 2) * (TX + 2)];
     __shared__ double sred[4][10];
-    const int b = blockIdx.z, x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    if (a.is_grad) { load_depth_tile<1>(a, b, x0, y0, sd); __syncthreads(); }
+    const int b = blockIdx.z, x0 = blockIdx.x * TX;
     const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
-    const int gx = x0 + lx, gy = y0 + ly;
-    float acc[10];
+    const int gx = x0 + lx;
+    double acc[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-    if (gx < a.W && gy < a.H) {
-        const long idx = ((long)b * a.H + gy) * a.W + gx;
-        float g;
-        if (a.is_grad) {
-            float sh, sv, srl, slr;
-            sobel4<TX + 2>(sd, ly + 1, lx + 1, sh, sv, srl, slr);
-            if (a.normal) {
-                const int code = direction_code(a.normal[idx]);
-                g = fabsf(code == 0 ? sh : (code == 1 ? sv : (code == 2 ? srl : slr)));
+    for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+    for (int t = 0; t < FWD_TILES; ++t) {
+        const int y0 = (blockIdx.y * FWD_TILES + t) * TY;
+        if (y0 >= a.H) break;
+        if (a.is_grad) { __syncthreads(); load_depth_tile<1>(a, b, x0, y0, sd); __syncthreads(); }
+        const int gy = y0 + ly;
+        if (gx < a.W && gy < a.H) {
+            const long idx = ((long)b * a.H + gy) * a.W + gx;
+            float g;
+            if (a.is_grad) {
+                float sh, sv, srl, slr;
+                sobel4<TX + 2>(sd, ly + 1, lx + 1, sh, sv, srl, slr);
+                if (a.normal) {
+                    const int code = direction_code(a.normal[idx]);
+                    g = fabsf(code == 0 ? sh : (code == 1 ? sv : (code == 2 ? srl : slr)));
+                } else {
+                    g = sqrtf(sv * sv + sh * sh + 1e-6f);
+                }
             } else {
-                g = sqrtf(sv * sv + sh * sh + 1e-6f);
+                g = a.pred[idx];
             }
-        } else {
-            g = a.pred[idx];
+            if (a.gmap) a.gmap[idx] = g;
+            const float p = a.is_sigmoid ? 1.f / (1.f + expf(-(g - a.thresh))) : g;
+            const float e = a.edge[idx];
+            const float m = a.mask ? a.mask[idx] : 1.f;
+            const float pos = -e * logf(p + 0.001f), neg = -(1.f - e) * logf(1.f - p + 0.001f);
+            const float keep = m != 0.f ? 1.f : 0.f;
+            acc[0] += (double)(e * m); acc[1] += (double)((1.f - e) * m); acc[2] += (double)pos; acc[3] += (double)neg;
+            acc[4] += (double)(pos * keep); acc[5] += (double)(neg * keep);
+            acc[6] += m == 0.f ? 1.0 : 0.0; acc[7] += m == 1.f ? 1.0 : 0.0; acc[8] += (m != 0.f && m != 1.f) ? 1.0 : 0.0; acc[9] += (double)m;
         }
-        if (a.gmap) a.gmap[idx] = g;
-        const float p = a.is_sigmoid ? 1.f / (1.f + expf(-(g - a.thresh))) : g;
-        const float e = a.edge[idx];
-        const float m = a.mask ? a.mask[idx] : 1.f;
-        const float pos = -e * logf(p + 0.001f), neg = -(1.f - e) * logf(1.f - p + 0.001f);
-        acc[0] = e * m; acc[1] = (1.f - e) * m; acc[2] = pos; acc[3] = neg;
-        const float keep = m != 0.f ? 1.f : 0.f;
-        acc[4] = pos * keep; acc[5] = neg * keep;
-        acc[6] = m == 0.f ? 1.f : 0.f; acc[7] = m == 1.f ? 1.f : 0.f; acc[8] = (m != 0.f && m != 1.f) ? 1.f : 0.f; acc[9] = m;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const double s = wave_sum_d((double)acc[i]);
+        const double s = wave_sum_d(acc[i]);
         if (lane == 0) sred[wave][i] = s;
     }
     __syncthreads();
+    // every block of an image meets on the same 6 words and every block of the launch on the last 4: device-scope
+    // atomics on one address serialise (~8 ns each), so there is one set per FWD_TILES tiles and none for exact zeros
     if (threadIdx.x < 10) {
         const double s = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
-        if (threadIdx.x < 6) atomicAdd(&a.sums[(long)b * 6 + threadIdx.x], s);
-        else atomicAdd(&a.sums[(long)a.B * 6 + (threadIdx.x - 6)], s);
+        if (s != 0.0) {
+            if (threadIdx.x < 6) atomicAdd(&a.sums[(long)b * 6 + threadIdx.x], s);
+            else atomicAdd(&a.sums[(long)a.B * 6 + (threadIdx.x - 6)], s);
+        }
     }
 }
 
@@ -282,7 +293,7 @@ int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal,
     if (hipMemsetAsync(sums, 0, sizeof(double) * (B * 6 + 4), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     EdgeArgs a{}; a.pred = pred; a.edge = edge; a.normal = normal; a.mask = mask; a.sums = sums; a.gmap = gmap;
     a.B = B; a.H = H; a.W = W; a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.thresh = thresh;
-    hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3((W + TX - 1) / TX, ((H + TY - 1) / TY + FWD_TILES - 1) / FWD_TILES, B), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
 // loss_this (nullable) <- weight * balanced BCE;  *loss_acc (nullable) += out_scale * loss;  coef: [2B + 1] floats
