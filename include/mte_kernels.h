@@ -195,6 +195,16 @@ int mte_hysteresis_propagate(unsigned char* state, int* flags, int sweeps, int B
 int mte_hysteresis_finish(const float* img, const unsigned char* state, const int* info, float* out, int B, int H, int W,
                           mte_stream_t stream);
 
+/* ---- chamfer edge metrics (edge half): chamfer_distance of utils/edge.py:19-64 (= edge.py:29-71), mask=None.
+ * im_pred / im_gt: float [B,H,W] edge images on the 0..255 scale (a pixel is an edge iff v/255 > 0.5).  out[b] = (c_dist,
+ * percentage) as doubles: mean exact Euclidean distance from the predicted edge pixels to the nearest ground-truth edge
+ * pixel and the share of them closer than edge_to_edge_thresh (NaN when nothing is predicted, +inf distances when the
+ * ground truth has no edge pixel -- scipy's result for that case is not reproduced).  dist_map (nullable) receives the
+ * distance transform, cond_map (nullable) the reference's -1 / 0 / 1 map.  workspace: mte_chamfer_workspace_bytes(B,H,W). */
+long mte_chamfer_workspace_bytes(int B, int H, int W);
+int mte_chamfer_distance(const float* im_pred, const float* im_gt, int B, int H, int W, double edge_to_edge_thresh,
+                         void* workspace, long workspace_bytes, double* out, float* dist_map, float* cond_map, mte_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,8 @@ class MteError(RuntimeError):
 
 RETURNS = {}
 # entry points that return a value (capability / size queries) instead of an error code
-QUERIES = ("mte_conv2d_patch_supported", "mte_conv2d_patch_pack_elems", "mte_depth_metrics_workspace_bytes")
+QUERIES = ("mte_conv2d_patch_supported", "mte_conv2d_patch_pack_elems", "mte_depth_metrics_workspace_bytes",
+           "mte_chamfer_workspace_bytes")
 
 
 def parse_header(path=HEADER):
