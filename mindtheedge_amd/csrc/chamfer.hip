@@ -14,24 +14,41 @@ namespace {
 
 constexpr unsigned EDT_INF = 1u << 30;
 
-__device__ __forceinline__ bool is_edge(float v) { return (double)v / 255.0 > 0.5; }
+// v/255 > 0.5 in double (edge.py:30-32) <=> v > 127.5 for every float32 v (127.5 is exact, the quotient is monotone)
+__device__ __forceinline__ bool is_edge(float v) { return v > 127.5f; }
 
-// one thread per column: distance along the column to the nearest ground-truth edge pixel, squared (EDT_INF if none)
-__global__ __launch_bounds__(256) void edt_columns_kernel(const float* __restrict__ gt, unsigned* __restrict__ g2, int H, int W) {
-    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (x >= W) return;
+constexpr int EC = 64, ES = 16;                               // columns per block x row segments per column (1024 threads)
+
+// distance along the column to the nearest ground-truth edge pixel, squared (EDT_INF if none).  A column is cut into ES
+// segments scanned in parallel; the segments exchange their first / last edge row through LDS.
+__global__ __launch_bounds__(EC * ES) void edt_columns_kernel(const float* __restrict__ gt, unsigned* __restrict__ g2, int H, int W) {
+    __shared__ int s_first[ES][EC], s_last[ES][EC];
+    const int c = threadIdx.x % EC, seg = threadIdx.x / EC;
+    const int x = blockIdx.x * EC + c, b = blockIdx.y;
+    const int per = (H + ES - 1) / ES, r0 = seg * per, r1 = min(H, r0 + per);
+    const bool live = x < W;
     const float* src = gt + (long)b * H * W + x;
     unsigned* dst = g2 + (long)b * H * W + x;
-    int last = -1;
-    for (int y = 0; y < H; ++y) {                              // nearest edge above (or at) y
-        if (is_edge(src[(long)y * W])) last = y;
-        dst[(long)y * W] = last < 0 ? EDT_INF : (unsigned)((y - last) * (y - last));
+    int first = -1, last = -1;
+    if (live)
+        for (int y = r0; y < r1; ++y)
+            if (is_edge(src[(long)y * W])) { if (first < 0) first = y; last = y; }
+    s_first[seg][c] = first; s_last[seg][c] = last;
+    __syncthreads();
+    if (!live) return;
+    int above = -1, below = -1;                               // nearest edge rows outside this segment
+    for (int k = 0; k < seg; ++k) if (s_last[k][c] >= 0) above = s_last[k][c];
+    for (int k = ES - 1; k > seg; --k) if (s_first[k][c] >= 0) below = s_first[k][c];
+    int near = above;
+    for (int y = r0; y < r1; ++y) {                            // nearest edge at or above y
+        if (is_edge(src[(long)y * W])) near = y;
+        dst[(long)y * W] = near < 0 ? EDT_INF : (unsigned)((y - near) * (y - near));
     }
-    last = -1;
-    for (int y = H - 1; y >= 0; --y) {                         // nearest edge below
-        if (is_edge(src[(long)y * W])) last = y;
-        if (last >= 0) {
-            const unsigned d = (unsigned)((last - y) * (last - y));
+    near = below;
+    for (int y = r1 - 1; y >= r0; --y) {                       // nearest edge at or below y
+        if (is_edge(src[(long)y * W])) near = y;
+        if (near >= 0) {
+            const unsigned d = (unsigned)((near - y) * (near - y));
             if (d < dst[(long)y * W]) dst[(long)y * W] = d;
         }
     }
@@ -96,7 +113,7 @@ extern "C" int mte_chamfer_distance(const float* im_pred, const float* im_gt, in
     double* acc = (double*)workspace;                                                       // [B][4], 8-byte aligned first
     unsigned* g2 = (unsigned*)((char*)workspace + (long)B * 4 * 8);
     if (hipMemsetAsync(acc, 0, (size_t)B * 4 * 8, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    hipLaunchKernelGGL(edt_columns_kernel, dim3(cdiv(W, 256), B), dim3(256), 0, stream, im_gt, g2, H, W);
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(cdiv(W, EC), B), dim3(EC * ES), 0, stream, im_gt, g2, H, W);
     hipLaunchKernelGGL(edt_rows_chamfer_kernel, dim3(H, B), dim3(256), (size_t)W * 4, stream, im_pred, g2, acc, dist_map, cond_map, H, W,
                        edge_to_edge_thresh);
     hipLaunchKernelGGL(chamfer_final_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream, acc, out, B);
