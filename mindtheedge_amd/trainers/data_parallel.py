@@ -60,7 +60,7 @@ class FlatParameters:
 class BucketedAllReduce:
     """Overlapped gradient averaging over a FlatParameters gradient buffer."""
 
-    def __init__(self, flat, process_group=None, bucket_bytes=32 << 20):
+    def __init__(self, flat, process_group=None, bucket_bytes=32 << 20, force=False):
         self.flat, self.group = flat, process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []                                   # (start, end, n_tensors)
@@ -78,7 +78,8 @@ class BucketedAllReduce:
         self._works = []
         self._hooks = []
         self._stream = None         # collectives are issued from here (see _launch)
-        if self.world > 1:
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())   # force: single-rank RCCL tests
+        if self.active:
             for p in flat.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
             if getattr(flat, "sink", None) is not None:
@@ -116,7 +117,7 @@ class BucketedAllReduce:
         if self.flat.grad.is_cuda:
             from .. import kernels as K
             K.join_side_stream()
-        if self.world > 1:
+        if self.active:
             for b, (s, e, n) in enumerate(self.buckets):
                 if self._ready[b] != n:
                     self._launch(s, e)

@@ -99,3 +99,72 @@ def test_two_ranks_gradient_sink_feeds_bucketed_allreduce():
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _rccl_worker(port, q):
+    """One rank, backend 'nccl' (= RCCL): the real collective library under the bucketed all-reduce -- issued from the
+    reduction stream while backward is still running, waited in FusedAdam.step.  With one rank the sum is the identity, so
+    three optimizer steps must match the same steps without a reducer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from mindtheedge_amd import kernels as K
+        from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
+        from mindtheedge_amd.models.SemiSupEdgeModel import SemiSupEdgeModel
+        from mindtheedge_amd.losses.grad_loss import GradLoss
+        from mindtheedge_amd.trainers.data_parallel import FlatParameters, BucketedAllReduce, FusedAdam, broadcast_parameters
+        from mindtheedge_amd.utils.synthetic import synthetic_batch
+        from oracle import packnet_oracle as po
+        K.set_compute_dtype("fp32")
+        finals, grads, launched = [], [], 0
+        for with_reducer in (False, True):
+            net = PackNetSAN01(dropout=None, version="1A")
+            net.load_state_dict(po.fixture_params(), strict=True)
+            net = net.cuda()
+            model = SemiSupEdgeModel(supervised_loss_weight=1.0, depth_edges_loss_weight=1.0, supervised_method="sparse-silog",
+                                     supervised_num_scales=1, edges_depth_edge_loss_all_scales=True, flip_lr_prob=0.0)
+            model.add_depth_net(net)
+            model.add_edge_loss(GradLoss("cross_entropy", True, [], 10.0, 1.0))
+            model.train()
+            flat = FlatParameters(net.parameters())
+            broadcast_parameters(flat)
+            red = BucketedAllReduce(flat, bucket_bytes=8 << 20, force=True) if with_reducer else None
+            opt = FusedAdam(flat, lr=1e-4, reducer=red)
+            batch = synthetic_batch(2, 64, 128, seed=77, device=torch.device("cuda", 0))
+            for it in range(3):
+                opt.zero_grad()
+                model(batch)["loss"].sum().backward()
+                if red is not None:
+                    launched = max(launched, len(red._works))
+                if it == 0:                                   # the reduced gradient itself, before Adam's sign-like update
+                    if red is not None:
+                        assert red.finish() == 1.0
+                    K.join_side_stream()
+                    torch.cuda.synchronize()
+                    grads.append(flat.grad.clone())
+                opt.step()
+            torch.cuda.synchronize()
+            finals.append(flat.flat.clone())
+        gerr = float((grads[0] - grads[1]).abs().max() / grads[0].abs().max())
+        perr = float((finals[0] - finals[1]).abs().max())      # Adam moves a parameter by <= lr per step whatever the gradient noise
+        q.put("ok" if (gerr < 1e-4 and perr <= 3.5e-4 and launched >= 3) else "gerr=%g perr=%g launched=%d" % (gerr, perr, launched))
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_single_rank_bucketed_allreduce_from_reduction_stream():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=280)
+    p.join(30)
+    assert res == "ok", res
