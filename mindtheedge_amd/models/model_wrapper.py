@@ -131,8 +131,9 @@ class ModelWrapper(nn.Module):
                     use_gt_scale='gt' in mode)
         if 'edge' in batch and not getattr(self, '_warned_edges', False):
             self._warned_edges = True
-            warnings.warn("edge precision/recall/F1 (cv2.Canny + chamfer, reference :354-442) are not computed by this "
-                          "build (SURVEY.md 8 f-3: OpenCV arithmetic, parity unpinned)")
+            warnings.warn("edge precision/recall/F1 are not computed here: the cv2.Canny step that extracts edges from the "
+                          "predicted depth (reference :396-400) is OpenCV arithmetic and not part of this build; feed your "
+                          "edge images to mindtheedge_amd.utils.edge.compute_edge_metrics for the chamfer part (:426-440)")
         return {'metrics': metrics, 'inv_depth': inv_depth_pp}
 
     def validation_step(self, batch, *args):
