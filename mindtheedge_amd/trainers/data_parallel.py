@@ -30,7 +30,7 @@ class FlatParameters:
         for p in order:
             offs.append(total)
             total += (p.numel() + align - 1) // align * align
-        self.params, self.offsets, self.total = order, offs, total
+        self.params, self.offsets, self.total, self.reverse = order, offs, total, reverse
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, o in zip(order, offs):
@@ -156,16 +156,58 @@ class FusedAdam(torch.optim.Optimizer):
         if self.flatp.grad.is_cuda:
             K.prefetch_weight_packs()                       # next step's kernel-ready weight packs, off the critical path
 
+    def _natural(self):
+        """(parameter, flat offset) in depth_net.parameters() order -- the index space of torch.optim.Adam's state."""
+        return list(reversed(list(zip(self.flatp.params, self.flatp.offsets)))) if self.flatp.reverse else \
+            list(zip(self.flatp.params, self.flatp.offsets))
+
     def state_dict(self):
-        return {'steps': self.steps, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
-                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+        """torch.optim.Adam's layout ({'state': {i: {'step','exp_avg','exp_avg_sq'}}, 'param_groups': [...]}, parameter
+        indices in depth_net.parameters() order), so that a checkpoint written here resumes in the reference
+        (models/model_checkpoint.py:71-81 stores optimizer.state_dict()) and vice versa."""
+        nat = self._natural()
+        state = {}
+        if self.steps > 0:
+            for i, (p, o) in enumerate(nat):
+                n = p.numel()
+                state[i] = {'step': torch.tensor(float(self.steps)), 'exp_avg': self.exp_avg[o:o + n].view(p.shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        g = self.param_groups[0]
+        group = {'lr': g['lr'], 'betas': tuple(g['betas']), 'eps': g['eps'], 'weight_decay': 0.0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'name': g.get('name', 'Depth'), 'params': list(range(len(nat)))}
+        for k in ('initial_lr',):
+            if k in g:
+                group[k] = g[k]
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.steps = sd['steps']
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
+        if 'state' not in sd:                                   # flat layout written by earlier builds of this package
+            self.steps = sd['steps']
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        else:
+            nat = self._natural()
+            groups = sd['param_groups']
+            idx = [i for g in groups if g.get('name', 'Depth') == 'Depth' for i in g['params']] or list(groups[0]['params'])
+            if len(idx) != len(nat):
+                raise ValueError("optimizer state holds {} 'Depth' parameters, this network has {}".format(len(idx), len(nat)))
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            steps = 0
+            for i, (p, o) in zip(idx, nat):
+                st = sd['state'].get(i)
+                if st is None:
+                    continue
+                if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                    raise ValueError("optimizer state {} has shape {}, parameter has {}".format(i, tuple(st['exp_avg'].shape), tuple(p.shape)))
+                n = p.numel()
+                self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                steps = max(steps, int(float(st['step'])))
+            self.steps = steps                                  # torch keeps a step per tensor; they advance together here
+        for g, s_ in zip(self.param_groups, sd['param_groups']):
+            g.update({k: v for k, v in s_.items() if k in ('lr', 'betas', 'eps', 'initial_lr')})
 
 
 def broadcast_parameters(flat, src=0, group=None):

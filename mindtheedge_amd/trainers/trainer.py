@@ -54,6 +54,9 @@ class Trainer:
             history.append(self.train(train_dataloader, module, optimizer))
             module.current_epoch += 1
             scheduler.step()
+            if self.checkpoint and self.is_rank_0:               # the reference's layout, one file per epoch (no top-k policy)
+                from ..models.model_checkpoint import save_checkpoint
+                save_checkpoint(os.path.join(str(self.checkpoint), 'epoch={}.ckpt'.format(module.current_epoch)), module)
         return history
 
     def train(self, dataloader, module, optimizer):

@@ -41,10 +41,41 @@ def load_class_args_create(filename, paths, args={}, concat=True):
     return filter_args_create(load_class(filename, paths, concat), args)
 
 
+class _CfgStub(dict):
+    """Stands in for yacs.config.CfgNode when a reference checkpoint's 'config' entry is unpickled without yacs."""
+    __getattr__ = dict.get
+
+
+class _TolerantPickle:
+    """pickle module for torch.load: classes of packages this image lacks (yacs) become plain dict stand-ins, so the
+    tensors of a checkpoint written by the reference can still be read."""
+    import pickle as _p
+    __name__ = 'pickle'
+    load, loads, dump, dumps = _p.load, _p.loads, _p.dump, _p.dumps
+    PickleError, UnpicklingError, Pickler = _p.PickleError, _p.UnpicklingError, _p.Pickler
+
+    class Unpickler(_p.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                if module.split('.')[0] in ('yacs',):
+                    return _CfgStub
+                raise
+
+
+def read_checkpoint(path):
+    """torch.load of a `.ckpt` written by this package or by the reference (models/model_checkpoint.py:71-81)."""
+    import torch
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception:
+        return torch.load(path, map_location='cpu', weights_only=False, pickle_module=_TolerantPickle)
+
+
 def load_network(network, path, prefixes=''):
     """Prefix-stripped, shape-checked, non-strict checkpoint load (reference load.py:117-166)."""
-    import torch
-    ckpt = torch.load(path, map_location='cpu')
+    ckpt = read_checkpoint(path)
     sd = ckpt.get('state_dict', ckpt)
     own = network.state_dict()
     picked = {}

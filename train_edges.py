@@ -19,6 +19,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20, help='steps per epoch for --synthetic')
     ap.add_argument('--epochs', type=int, default=1)
     ap.add_argument('--data', type=str, default=None)
+    ap.add_argument('--resume', type=str, default=None, help='.ckpt in the reference layout (model_checkpoint.py:71-81) to resume from')
+    ap.add_argument('--save', type=str, default=None, help='write <save>/epoch=N.ckpt after every epoch (rank 0)')
     args = ap.parse_args()
     assert args.file.endswith('.yaml'), 'You need to provide a .yaml file'
     import torch
@@ -29,8 +31,10 @@ def main():
     config = load_config(args.file)
     config.model.depth_net.checkpoint_path = config.model.depth_net.checkpoint_path if os.path.exists(
         config.model.depth_net.checkpoint_path or '') else ''
-    trainer = Trainer(**config.arch)
-    wrapper = ModelWrapper(config)
+    from mindtheedge_amd.models.model_checkpoint import load_checkpoint
+    save_dir = args.save or (os.path.dirname(config.checkpoint.filepath) if config.checkpoint.filepath else None)
+    trainer = Trainer(**{**config.arch, 'checkpoint': save_dir})
+    wrapper = ModelWrapper(config, resume=load_checkpoint(args.resume) if args.resume else None)
     H, W = tuple(config.datasets.augmentation.image_shape) if not isinstance(config.datasets.augmentation.image_shape, str) \
         else eval(config.datasets.augmentation.image_shape)
     if args.data:
