@@ -42,22 +42,39 @@ class Trainer:
     def is_rank_0(self):
         return self.proc_rank == 0
 
-    def fit(self, module, train_dataloader, epochs=None):
+    def fit(self, module, train_dataloader, epochs=None, val_dataloaders=None):
         if self.device is None:
             raise RuntimeError("mindtheedge_amd trains on MI355X GPUs only")
         module.to(self.device)
         optimizer, scheduler = module.configure_optimizers()
         history = []
+        if val_dataloaders and self.validate_first:
+            history.append({'validation': self.validate(val_dataloaders, module)})
         for epoch in range(module.current_epoch, epochs if epochs is not None else self.max_epochs):
             if hasattr(getattr(train_dataloader, 'sampler', None), 'set_epoch'):
                 train_dataloader.sampler.set_epoch(epoch)
             history.append(self.train(train_dataloader, module, optimizer))
             module.current_epoch += 1
             scheduler.step()
+            if val_dataloaders:
+                history[-1]['validation'] = self.validate(val_dataloaders, module)
             if self.checkpoint and self.is_rank_0:               # the reference's layout, one file per epoch (no top-k policy)
                 from ..models.model_checkpoint import save_checkpoint
                 save_checkpoint(os.path.join(str(self.checkpoint), 'epoch={}.ckpt'.format(module.current_epoch)), module)
         return history
+
+    def validate(self, dataloaders, module):
+        """Reference CommonTrainer.validate (trainers/common_trainer.py:187-210): every validation dataset in turn,
+        ``module.validation_step`` per batch, ``module.validation_epoch_end`` per dataset -> [metrics dict per dataset].
+        The per-batch metrics stay on the device; the epoch end reads them once."""
+        was_training = module.training
+        module.eval()
+        results = []
+        for n, dataloader in enumerate(dataloaders):
+            outputs = [module.validation_step(sample_to_cuda(batch, self.device), i, n) for i, batch in enumerate(dataloader)]
+            results.append(module.validation_epoch_end(outputs))
+        module.train(was_training)
+        return results
 
     def train(self, dataloader, module, optimizer):
         module.train()

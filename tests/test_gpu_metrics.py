@@ -136,3 +136,32 @@ def test_evaluate_depth_matches_oracle_on_network_output():
     summary = wrap.validation_epoch_end([{"idx": None, **out["metrics"]}, {"idx": None, **out["metrics"]}])
     assert abs(summary["depth-abs_rel_pp_gt"] - float(out["metrics"]["depth_pp_gt"][0])) < 1e-6
     assert len(summary) == 28
+
+
+def test_trainer_validate_loop():
+    """Trainer.validate over two synthetic validation sets: per-batch metrics stay on the device, one dict per dataset."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.trainers.trainer import Trainer
+    from mindtheedge_amd.utils.config import load_config
+    from mindtheedge_amd.utils.synthetic import synthetic_batch
+    K.set_compute_dtype("bf16")
+    cfg = load_config(None, {"model": {"loss": {"supervised_method": "sparse-silog", "supervised_num_scales": 1, "supervised_loss_weight": 1.0,
+                                                  "edges_depth_edge_loss_all_scales": True}, "params": {"crop": "garg"}}})
+    torch.manual_seed(3)
+    wrap = ModelWrapper(cfg).cuda()
+    wrap.train()
+
+    def loader(seed, n):
+        out = []
+        for i in range(n):
+            b = synthetic_batch(2, 64, 128, seed=seed + i, device=torch.device("cpu"))
+            b["depth"] = _kitti_like(2, 61, 120, 64, 128, seed=seed + i, holes=0.5)[0]
+            b.pop("edge", None)
+            out.append(b)
+        return out
+    res = Trainer(max_epochs=1).validate([loader(1, 2), loader(9, 1)], wrap)
+    assert wrap.training and len(res) == 2
+    for r in res:
+        assert len(r) == 28 and all(np.isfinite(v) for v in r.values())
+        assert 0.0 <= r["depth-a1_pp_gt"] <= r["depth-a2_pp_gt"] <= r["depth-a3_pp_gt"] <= 1.0
