@@ -205,6 +205,18 @@ long mte_chamfer_workspace_bytes(int B, int H, int W);
 int mte_chamfer_distance(const float* im_pred, const float* im_gt, int B, int H, int W, double edge_to_edge_thresh,
                          void* workspace, long workspace_bytes, double* out, float* dist_map, float* cond_map, mte_stream_t stream);
 
+/* ---- Canny step of the validation edge metrics (models/model_wrapper.py:376-400).  PARITY UNPINNED: restates OpenCV's
+ * published cv2.Canny (apertureSize 3, L1 gradient) -- see oracle/canny_oracle.py.
+ * mte_canny_begin: vis = uint8(depth * (255 / max(depth))) per image (vis_u8 nullable, B*H*W bytes), 3x3 Sobel, non-maximum
+ *   suppression, and classification for n_pairs (<= 4) threshold pairs `thresholds[2*p], thresholds[2*p+1]` (HOST ints)
+ *   into state[n_pairs][B][H][W] bytes (0 none, 1 candidate, 2 edge).  max_ws: B unsigned ints of scratch.
+ * mte_canny_propagate: hysteresis sweeps over the `maps` = n_pairs*B state maps; same flags protocol as mte_hysteresis_propagate.
+ * mte_canny_finish: edges[maps][H][W] floats, 255 on edges, 0 elsewhere (the scale mte_chamfer_distance expects). */
+int mte_canny_begin(const float* depth, int B, int H, int W, int n_pairs, const int* thresholds, unsigned* max_ws,
+                    unsigned char* vis_u8, unsigned char* state, mte_stream_t stream);
+int mte_canny_propagate(unsigned char* state, int* flags, int sweeps, int maps, int H, int W, mte_stream_t stream);
+int mte_canny_finish(const unsigned char* state, float* edges, int maps, int H, int W, mte_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

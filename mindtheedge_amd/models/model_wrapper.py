@@ -129,11 +129,18 @@ class ModelWrapper(nn.Module):
                 metrics[self.metrics_name + mode] = compute_depth_metrics(
                     self.config.model.params, gt=batch['depth'], pred=depth_pp if 'pp' in mode else depth,
                     use_gt_scale='gt' in mode)
-        if 'edge' in batch and not getattr(self, '_warned_edges', False):
-            self._warned_edges = True
-            warnings.warn("edge precision/recall/F1 are not computed here: the cv2.Canny step that extracts edges from the "
-                          "predicted depth (reference :396-400) is OpenCV arithmetic and not part of this build; feed your "
-                          "edge images to mindtheedge_amd.utils.edge.compute_edge_metrics for the chamfer part (:426-440)")
+        if 'edge' in batch:
+            # reference :354-371 + compute_edge_metrics :373-440: Canny on the FIRST image's predicted depth (three settings)
+            # against its ground-truth edge image -> (precision, recall, F1) x 3.  The Canny step restates OpenCV's
+            # published algorithm and is parity-unpinned (oracle/canny_oracle.py); the chamfer part is pinned.
+            from ..utils.edge import compute_edge_metrics_from_depth
+            gt_edge = batch['edge'][0, 0].float() * 255
+            if tuple(gt_edge.shape) == tuple(depth.shape[-2:]):
+                metrics['edges'] = compute_edge_metrics_from_depth(depth[0, 0], gt_edge)
+            elif not getattr(self, '_warned_edges', False):
+                self._warned_edges = True
+                warnings.warn("edge metrics skipped: the ground-truth edge image and the prediction differ in size and the "
+                              "reference's cv2.resize(INTER_LINEAR) step (:386-387) is not part of this build")
         return {'metrics': metrics, 'inv_depth': inv_depth_pp}
 
     def validation_step(self, batch, *args):
@@ -154,8 +161,20 @@ class ModelWrapper(nn.Module):
             dist.all_reduce(total)
             dist.all_reduce(count)
         mean = (total / count).cpu()
-        return {'{}-{}{}'.format(self.metrics_name, key, mode): float(mean[i, j])
-                for i, mode in enumerate(self.metrics_modes) for j, key in enumerate(self.metrics_keys)}
+        out = {'{}-{}{}'.format(self.metrics_name, key, mode): float(mean[i, j])
+               for i, mode in enumerate(self.metrics_modes) for j, key in enumerate(self.metrics_keys)}
+        edge_rows = [o['edges'] for o in output_data_batch if 'edges' in o]
+        if edge_rows:                                        # (precision, recall, F1) x the three Canny settings, reference :431-438
+            etotal = torch.stack(edge_rows).sum(0)
+            ecount = torch.tensor(float(len(edge_rows)), device=etotal.device, dtype=etotal.dtype)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(etotal)
+                dist.all_reduce(ecount)
+            emean = (etotal / ecount).cpu()
+            for k in range(emean.numel() // 3):
+                for j, key in enumerate(('precision', 'recall', 'f1')):
+                    out['edges-{}_{}'.format(key, k)] = float(emean[3 * k + j])
+        return out
 
     def depth(self, rgb, **kwargs):
         return self.model.depth_net(rgb=rgb, **kwargs)

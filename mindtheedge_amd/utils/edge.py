@@ -74,3 +74,51 @@ def compute_edge_metrics(edge_images, gt_edge, edge_to_edge_thresh=5):
     for im in edge_images:
         out.extend(edge_precision_recall_f1(im, gt_edge, edge_to_edge_thresh))
     return torch.stack([o.reshape(()) for o in out])
+
+
+CANNY_THRESHOLDS = ((10, 20), (20, 40), (30, 60))       # models/model_wrapper.py:398-400
+
+
+def canny_from_depth(depth, thresholds=CANNY_THRESHOLDS, return_vis=False):
+    """Edge images of a predicted depth map as ModelWrapper.compute_edge_metrics extracts them (model_wrapper.py:396-400):
+    ``vis = uint8(depth * (255 / depth.max()))`` per image, then ``cv2.Canny(vis, lo, hi)`` for every threshold pair.
+    depth: CUDA [H,W] or [B,H,W] -> float32 [P,B,H,W] (or [P,H,W]) with 255 on edges.
+
+    PARITY UNPINNED: this is OpenCV's published Canny (apertureSize 3, L1 gradient) restated without OpenCV at hand
+    (oracle/canny_oracle.py); it is tested against that restatement and known answers only."""
+    import ctypes
+    from .. import kernels as K
+    (d,), squeeze = _edge_maps(depth)
+    B, H, W = d.shape
+    P = len(thresholds)
+    if not 1 <= P <= 4:
+        raise ValueError("1..4 threshold pairs")
+    th = (ctypes.c_int * (2 * P))(*[int(v) for pair in thresholds for v in pair])
+    max_ws = torch.empty(B, dtype=torch.int32, device=d.device)
+    vis = torch.empty((B, H, W), dtype=torch.uint8, device=d.device) if return_vis else None
+    state = torch.empty((P, B, H, W), dtype=torch.uint8, device=d.device)
+    sweeps = 8
+    flags = torch.empty(sweeps + 1, dtype=torch.int32, device=d.device)
+    K.lib.mte_canny_begin(d.data_ptr(), B, H, W, P, ctypes.addressof(th), max_ws.data_ptr(), vis.data_ptr() if return_vis else None,
+                          state.data_ptr(), K._stream())
+    while True:
+        K.lib.mte_canny_propagate(state.data_ptr(), flags.data_ptr(), sweeps, P * B, H, W, K._stream())
+        if int(flags[sweeps].item()) == 0:              # one host read per 8 sweeps, as in utils/tools.py::hysteresis
+            break
+    edges = torch.empty((P, B, H, W), dtype=torch.float32, device=d.device)
+    K.lib.mte_canny_finish(state.data_ptr(), edges.data_ptr(), P * B, H, W, K._stream())
+    if squeeze:
+        edges, vis = edges[:, 0], (vis[0] if return_vis else None)
+    return (edges, vis) if return_vis else edges
+
+
+def compute_edge_metrics_from_depth(depth, gt_edge, edge_to_edge_thresh=5):
+    """ModelWrapper.compute_edge_metrics for depth models (model_wrapper.py:376-440) on ONE [H,W] depth map and its
+    ground-truth edge image (0..255 scale): three Canny settings x (precision, recall, F1) -> float64 device tensor [9].
+    Shapes must agree (the reference's cv2.resize branch is not built).  The Canny step is parity-unpinned."""
+    if depth.dim() != 2 or gt_edge.dim() != 2:
+        raise ValueError("one [H,W] depth map and one [H,W] edge image, as the reference evaluates them")
+    if depth.shape != gt_edge.shape:
+        raise NotImplementedError("prediction and ground-truth edge image differ in size: cv2.resize(INTER_LINEAR) is not built")
+    edges = canny_from_depth(depth)
+    return compute_edge_metrics([edges[p] for p in range(edges.shape[0])], gt_edge, edge_to_edge_thresh)

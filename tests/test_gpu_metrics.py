@@ -133,9 +133,17 @@ def test_evaluate_depth_matches_oracle_on_network_output():
     for mode in ("", "_pp", "_gt", "_pp_gt"):
         want = mo.compute_depth_metrics(gt.numpy(), depth_pp if "pp" in mode else depth, crop="garg", use_gt_scale="gt" in mode)
         np.testing.assert_allclose(out["metrics"]["depth" + mode].cpu().numpy(), want, rtol=5e-5, atol=1e-7)
+    # edge metrics of the first image: Canny (parity-unpinned restatement) x 3 settings -> chamfer both ways
+    from oracle import canny_oracle as co
+    from oracle import edge_oracle as eo
+    gt_edge = batch["edge"][0, 0].cpu().numpy() * 255
+    want_e = []
+    for e in co.edges_from_depth(depth[0, 0]):
+        want_e.extend(eo.precision_recall_f1(e, gt_edge))
+    np.testing.assert_allclose(out["metrics"]["edges"].cpu().numpy(), np.array(want_e, np.float64), rtol=1e-12, equal_nan=True)
     summary = wrap.validation_epoch_end([{"idx": None, **out["metrics"]}, {"idx": None, **out["metrics"]}])
     assert abs(summary["depth-abs_rel_pp_gt"] - float(out["metrics"]["depth_pp_gt"][0])) < 1e-6
-    assert len(summary) == 28
+    assert len(summary) == 28 + 9 and "edges-f1_2" in summary
 
 
 def test_trainer_validate_loop():
