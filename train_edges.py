@@ -10,6 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see mindtheedge_amd/__init__.py: side stream / RCCL streams need their own hardware queues
 
 
 def main():
