@@ -214,6 +214,9 @@ int mte_chamfer_distance(const float* im_pred, const float* im_gt, int B, int H,
  * mte_canny_finish: edges[maps][H][W] floats, 255 on edges, 0 elsewhere (the scale mte_chamfer_distance expects). */
 int mte_canny_begin(const float* depth, int B, int H, int W, int n_pairs, const int* thresholds, unsigned* max_ws,
                     unsigned char* vis_u8, unsigned char* state, mte_stream_t stream);
+ /* mte_resize_linear: cv2.resize(float32 [B,h,w] -> [B,H,W], INTER_LINEAR) as used in front of the Canny step
+ * (models/model_wrapper.py:386-387); restated from OpenCV's resize.cpp, PARITY UNPINNED like the rest of this block. */
+int mte_resize_linear(const float* src, int B, int h, int w, float* dst, int H, int W, mte_stream_t stream);
 int mte_canny_propagate(unsigned char* state, int* flags, int sweeps, int maps, int H, int W, mte_stream_t stream);
 int mte_canny_finish(const unsigned char* state, float* edges, int maps, int H, int W, mte_stream_t stream);
 

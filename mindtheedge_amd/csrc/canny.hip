@@ -81,6 +81,30 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const float* __restrict_
         state[((long)p * B + b) * H * W + o] = (is_max && m > pr.low[p]) ? (m > pr.high[p] ? 2 : 1) : 0;
 }
 
+// cv2.resize(src, (W, H), interpolation=INTER_LINEAR) on float32 (model_wrapper.py:386-387), restated from OpenCV's resize.cpp:
+// half-pixel centres, source index clamped with the fraction zeroed at the borders, rows interpolated first, then columns
+__global__ __launch_bounds__(256) void resize_linear_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, int H, int W) {
+    const int b = blockIdx.y;
+    const long n = (long)H * W;
+    const float sx_scale = (float)((double)w / W), sy_scale = (float)((double)h / H);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int dy = (int)(i / W), dx = (int)(i - (long)dy * W);
+        float fx = (float)((dx + 0.5) * (double)sx_scale - 0.5), fy = (float)((dy + 0.5) * (double)sy_scale - 0.5);
+        int sx = (int)floorf(fx), sy = (int)floorf(fy);
+        fx -= (float)sx; fy -= (float)sy;
+        if (sx < 0) { sx = 0; fx = 0.f; }
+        if (sx >= w - 1) { sx = w - 1; fx = 0.f; }
+        if (sy < 0) { sy = 0; fy = 0.f; }
+        if (sy >= h - 1) { sy = h - 1; fy = 0.f; }
+        const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
+        const float* p = src + (long)b * h * w;
+        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+        const float r0 = p[(long)sy * w + sx] * a0 + p[(long)sy * w + sx1] * a1;
+        const float r1 = p[(long)sy1 * w + sx] * a0 + p[(long)sy1 * w + sx1] * a1;
+        dst[(long)b * n + i] = r0 * b0 + r1 * b1;
+    }
+}
+
 __global__ __launch_bounds__(256) void canny_finish_kernel(const unsigned char* __restrict__ state, float* __restrict__ edges, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) edges[i] = state[i] == 2 ? 255.f : 0.f;
 }
@@ -101,6 +125,13 @@ extern "C" int mte_canny_begin(const float* depth, int B, int H, int W, int n_pa
     int bx = cdiv((long)H * W, 256 * 8); if (bx > 256) bx = 256;
     hipLaunchKernelGGL(image_max_kernel, dim3(bx, B), dim3(256), 0, stream, depth, max_ws, H * W);
     hipLaunchKernelGGL(canny_nms_kernel, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(256), 0, stream, depth, max_ws, vis_u8, state, B, H, W, pr);
+    return mte_check_launch();
+}
+
+extern "C" int mte_resize_linear(const float* src, int B, int h, int w, float* dst, int H, int W, hipStream_t stream) {
+    if (!src || !dst || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MTE_ERR_ARG;
+    long g = ((long)H * W + 256 * 4 - 1) / (256 * 4); if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((unsigned)g, B), dim3(256), 0, stream, src, dst, h, w, H, W);
     return mte_check_launch();
 }
 

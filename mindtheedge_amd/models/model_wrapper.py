@@ -4,7 +4,6 @@
 (:215-225), ``validation_epoch_end`` (:255-277) with the metrics computed on the device.
 Dataloaders, metric printing and the Canny/chamfer edge metrics (OpenCV) are out of scope."""
 import random
-import warnings
 from collections import OrderedDict
 
 import torch
@@ -131,16 +130,12 @@ class ModelWrapper(nn.Module):
                     use_gt_scale='gt' in mode)
         if 'edge' in batch:
             # reference :354-371 + compute_edge_metrics :373-440: Canny on the FIRST image's predicted depth (three settings)
-            # against its ground-truth edge image -> (precision, recall, F1) x 3.  The Canny step restates OpenCV's
-            # published algorithm and is parity-unpinned (oracle/canny_oracle.py); the chamfer part is pinned.
+            # (resized to the edge image's size) against its ground-truth edge image -> (precision, recall, F1) x 3.  The
+            # resize and Canny steps restate OpenCV's published algorithms and are parity-unpinned (oracle/canny_oracle.py);
+            # the chamfer part is pinned.
             from ..utils.edge import compute_edge_metrics_from_depth
             gt_edge = batch['edge'][0, 0].float() * 255
-            if tuple(gt_edge.shape) == tuple(depth.shape[-2:]):
-                metrics['edges'] = compute_edge_metrics_from_depth(depth[0, 0], gt_edge)
-            elif not getattr(self, '_warned_edges', False):
-                self._warned_edges = True
-                warnings.warn("edge metrics skipped: the ground-truth edge image and the prediction differ in size and the "
-                              "reference's cv2.resize(INTER_LINEAR) step (:386-387) is not part of this build")
+            metrics['edges'] = compute_edge_metrics_from_depth(depth[0, 0], gt_edge)
         return {'metrics': metrics, 'inv_depth': inv_depth_pp}
 
     def validation_step(self, batch, *args):

@@ -112,13 +112,26 @@ def canny_from_depth(depth, thresholds=CANNY_THRESHOLDS, return_vis=False):
     return (edges, vis) if return_vis else edges
 
 
+def resize_linear(img, shape):
+    """cv2.resize(img, (shape[1], shape[0]), interpolation=cv2.INTER_LINEAR) for float maps [H,W] / [B,H,W] on the device
+    (model_wrapper.py:386-387).  Parity-unpinned restatement of OpenCV's resize (oracle/canny_oracle.py::resize_linear)."""
+    from .. import kernels as K
+    (x,), squeeze = _edge_maps(img)
+    B, h, w = x.shape
+    H, W = int(shape[0]), int(shape[1])
+    out = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+    K.lib.mte_resize_linear(x.data_ptr(), B, h, w, out.data_ptr(), H, W, K._stream())
+    return out[0] if squeeze else out
+
+
 def compute_edge_metrics_from_depth(depth, gt_edge, edge_to_edge_thresh=5):
     """ModelWrapper.compute_edge_metrics for depth models (model_wrapper.py:376-440) on ONE [H,W] depth map and its
     ground-truth edge image (0..255 scale): three Canny settings x (precision, recall, F1) -> float64 device tensor [9].
-    Shapes must agree (the reference's cv2.resize branch is not built).  The Canny step is parity-unpinned."""
+    The depth is first resized to the edge image's size like the reference does (cv2.resize, INTER_LINEAR).  The resize
+    and the Canny step are parity-unpinned restatements of OpenCV; the chamfer part is pinned."""
     if depth.dim() != 2 or gt_edge.dim() != 2:
         raise ValueError("one [H,W] depth map and one [H,W] edge image, as the reference evaluates them")
     if depth.shape != gt_edge.shape:
-        raise NotImplementedError("prediction and ground-truth edge image differ in size: cv2.resize(INTER_LINEAR) is not built")
+        depth = resize_linear(depth, gt_edge.shape)
     edges = canny_from_depth(depth)
     return compute_edge_metrics([edges[p] for p in range(edges.shape[0])], gt_edge, edge_to_edge_thresh)

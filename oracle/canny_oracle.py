@@ -23,6 +23,28 @@ import numpy as np
 TG22 = int(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
 
 
+def resize_linear(img, W, H):
+    """cv2.resize(img, (W, H), interpolation=cv2.INTER_LINEAR) on a float32 image (model_wrapper.py:386-387), restated from
+    OpenCV's resize.cpp: half-pixel centres, fractions zeroed where the source index is clamped, rows first then columns."""
+    src = np.asarray(img, np.float32)
+    h, w = src.shape
+
+    def taps(n_dst, n_src):
+        scale = np.float32(np.float64(n_src) / n_dst)
+        f = ((np.arange(n_dst) + 0.5) * np.float64(scale) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        s[lo], f[lo] = 0, 0
+        hi = s >= n_src - 1
+        s[hi], f[hi] = n_src - 1, 0
+        return s, np.minimum(s + 1, n_src - 1), (np.float32(1) - f).astype(np.float32), f
+    x0, x1, a0, a1 = taps(W, w)
+    y0, y1, b0, b1 = taps(H, h)
+    rows = (src[:, x0] * a0[None, :] + src[:, x1] * a1[None, :]).astype(np.float32)
+    return (rows[y0] * b0[:, None] + rows[y1] * b1[:, None]).astype(np.float32)
+
+
 def depth_to_u8(depth):
     """model_wrapper.py:396-397 (float32 array times a float32 factor, truncated)."""
     d = np.asarray(depth, np.float32)

@@ -70,5 +70,23 @@ def test_edge_metrics_from_depth_chain():
         want.extend(eo.precision_recall_f1(e, gt))
     np.testing.assert_allclose(got, np.array(want, np.float64), rtol=1e-12)
     assert got[3] == 1.0 and got[4] == 1.0 and got[5] == 1.0                             # identical edge images for (20, 40)
-    with pytest.raises(NotImplementedError):
-        compute_edge_metrics_from_depth(torch.from_numpy(d).cuda(), torch.zeros(100, 100).cuda())
+    # KITTI-like: 192x640 prediction against a 187x621 edge image -> resized first (cv2.resize INTER_LINEAR restatement)
+    gt2 = co.canny(co.depth_to_u8(co.resize_linear(d, 621, 187)), 20, 40)
+    got2 = compute_edge_metrics_from_depth(torch.from_numpy(d).cuda(), torch.from_numpy(gt2).cuda()).cpu().numpy()
+    want2 = []
+    for e in co.edges_from_depth(co.resize_linear(d, 621, 187)):
+        want2.extend(eo.precision_recall_f1(e, gt2))
+    np.testing.assert_allclose(got2, np.array(want2, np.float64), rtol=1e-12)
+
+
+@pytest.mark.parametrize("h,w,H,W", [(384, 1280, 375, 1242), (12, 20, 31, 47), (9, 9, 9, 9), (5, 7, 1, 1), (1, 1, 4, 6), (40, 64, 20, 32)])
+def test_resize_linear_matches_restatement(h, w, H, W):
+    from mindtheedge_amd.utils.edge import resize_linear
+    g = np.random.default_rng(h * 7 + W)
+    src = (g.random((h, w)) * 80).astype(np.float32)
+    got = resize_linear(torch.from_numpy(src).cuda(), (H, W)).cpu().numpy()
+    np.testing.assert_array_equal(got, co.resize_linear(src, W, H))
+    if (h, w) == (H, W):
+        np.testing.assert_array_equal(got, src)
+    if (h, w, H, W) == (40, 64, 20, 32):                     # exact 2x reduction: every output is the mean of a 2x2 block
+        np.testing.assert_allclose(got, src.reshape(20, 2, 32, 2).mean((1, 3)), rtol=1e-6)
