@@ -220,6 +220,23 @@ int mte_resize_linear(const float* src, int B, int h, int w, float* dst, int H, 
 int mte_canny_propagate(unsigned char* state, int* flags, int sweeps, int maps, int H, int W, mte_stream_t stream);
 int mte_canny_finish(const unsigned char* state, float* edges, int maps, int H, int W, mte_stream_t stream);
 
+/* ---- sparse auxiliary (SAN) branch, inference only.  PARITY UNPINNED: dense-equivalent of the
+ * MinkowskiEngine operators the reference uses (networks/layers/minkowski_encoder.py:11-132, minkowski.py:33-79); see
+ * oracle/san_oracle.py.  Features are zero-filled NHWC activations (bf16 / fp32), the active set is a byte mask [B,H,W].
+ * mte_sparsify_depth: mask = depth > 0, feat channel 0 = depth on the mask, channels 1..7 = 0 (feat has >= 8 channels/pixel)
+ * mte_sparse_maxpool3s2: MinkowskiMaxPooling(3, stride 2): mask_out = any of the 2x2 block, value = max over the active
+ *   cells of the centred 3x3 window; H and W even
+ * mte_sparse_bn_relu: out = mask ? relu(batchnorm_eval(a [+ b] [+ c])) : 0   (b, c nullable)
+ * mte_san_fuse: out = skip * w[0] + sparse + bias[0]   (networks/depth/PackNetSAN01.py:254-258) */
+int mte_sparsify_depth(const float* depth, void* feat, long ldf, unsigned char* mask, int B, int H, int W, int dtype, mte_stream_t stream);
+int mte_sparse_maxpool3s2(const void* in, long ldi, const unsigned char* mask_in, void* out, long ldo, unsigned char* mask_out,
+                          int B, int H, int W, int C, int dtype, mte_stream_t stream);
+int mte_sparse_bn_relu(const void* a, long lda, const void* b, long ldb, const void* c, long ldc, const unsigned char* mask,
+                       const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                       void* out, long ldo, long npix, int C, int dtype, mte_stream_t stream);
+int mte_san_fuse(const void* skip, long ld_skip, const void* sparse, long ld_sparse, const float* w, const float* bias,
+                 void* out, long ldo, long npix, int C, int dtype, mte_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,7 +108,7 @@ class _SparseBranchPlaceholder(nn.Module):
 
 class PackNetSAN01(nn.Module):
     def __init__(self, dropout=None, version=None, freeze_encoder=False, freeze_decoder=False, freeze_san=False,
-                 input_channels=3, is_depth_aux_net=False, output_channels=1, **kwargs):
+                 input_channels=3, is_depth_aux_net=False, output_channels=1, with_san=False, **kwargs):
         super().__init__()
         self.version = version[1:]
         self.in_channels = input_channels
@@ -128,7 +128,15 @@ class PackNetSAN01(nn.Module):
         self.decoder = Decoder(self.version, output_channels, ni, n1, n2, n3, n4, n5, unpack_kernel, iconv_kernel, num_3d_feat)
         if freeze_decoder:
             self.freeze_weights(self.decoder.parameters())
-        self.mconvs = _SparseBranchPlaceholder()
+        # The reference always owns the sparse branch (34 M parameters) although SemiSupEdgeModel never runs it; here it is
+        # materialised on request (with_san=True, inference with a LiDAR input) so that the training path's parameter set,
+        # flat optimizer buffers and fixtures stay those of the 218 dense tensors.  PARITY UNPINNED, see minkowski_encoder.py.
+        if with_san:
+            from ..layers.minkowski_encoder import MinkowskiEncoder
+            self.mconvs = MinkowskiEncoder([n1, n2, n3, n4, n5], with_uncertainty=False)
+        else:
+            self.mconvs = _SparseBranchPlaceholder()
+        self.with_san = bool(with_san)
         self.weight = nn.Parameter(torch.ones(5), requires_grad=not freeze_san)
         self.bias = nn.Parameter(torch.zeros(5), requires_grad=not freeze_san)
         self.init_weights()
@@ -146,12 +154,29 @@ class PackNetSAN01(nn.Module):
             p.requires_grad = False
 
     def run_network(self, rgb, input_depth=None):
-        if input_depth is not None:
-            raise NotImplementedError("the sparse LiDAR (SAN) branch is out of scope of this build (SURVEY.md 8(f-1))")
+        if input_depth is not None and not self.with_san:
+            raise NotImplementedError("construct PackNetSAN01(with_san=True) to use input_depth: the sparse LiDAR (SAN) branch "
+                                      "is only materialised on request (SURVEY.md 8 f-1, parity unpinned)")
         bufs = skip_dst = None
-        if rgb.is_cuda and rgb.shape[2] % 32 == 0 and rgb.shape[3] % 32 == 0 and not os.environ.get("MTE_NO_CONCAT_PLACEMENT"):
+        if input_depth is None and rgb.is_cuda and rgb.shape[2] % 32 == 0 and rgb.shape[3] % 32 == 0 \
+                and not os.environ.get("MTE_NO_CONCAT_PLACEMENT"):
             bufs, skip_dst = self.decoder.concat_buffers(rgb.shape[0], rgb.shape[2], rgb.shape[3], rgb.device)
         x5p, skips = self.encoder(rgb, skip_out=skip_dst)
+        if input_depth is not None:
+            # reference :248-258: every pyramid level below full resolution becomes skip * w + sparse features + b
+            from ..layers.minkowski_encoder import san_fuse
+            self.mconvs.prep(input_depth)
+            skips = list(skips)
+            for level in range(5):
+                dense = skips[level + 1] if level < 4 else x5p
+                sparse = self.mconvs(dense)
+                if tuple(sparse.shape) != tuple(dense.shape):
+                    raise RuntimeError("sparse level {} is {} but the encoder feature is {}".format(level, tuple(sparse.shape), tuple(dense.shape)))
+                fused = san_fuse(dense, sparse, self.weight, self.bias, level)
+                if level < 4:
+                    skips[level + 1] = fused
+                else:
+                    x5p = fused
         return [self.decoder(x5p, skips, bufs), skips + [x5p]]
 
     def forward(self, rgb, input_depth=None, rgb_edge=None, output_features=False, **kwargs):
@@ -163,8 +188,8 @@ class PackNetSAN01(nn.Module):
                 out[0] = out[0] * rgb_edge            # as the reference: list * tensor is an upstream bug; kept failing loudly
             return {'inv_depths': out}
         if input_depth is not None:
-            raise NotImplementedError("training with input_depth needs the SAN branch (SURVEY.md 8(f-1)); "
-                                      "SemiSupEdgeModel never uses its outputs, so drop the key from the batch")
+            raise NotImplementedError("training with input_depth needs a backward pass through the SAN branch, which is built "
+                                      "for inference only (SURVEY.md 8 f-1); SemiSupEdgeModel never uses its outputs, so drop the key")
         inv_depths, feats = self.run_network(rgb)
         output = {'inv_depths': inv_depths}
         if output_features:
