@@ -171,8 +171,8 @@ class ModelWrapper(nn.Module):
                     out['edges-{}_{}'.format(key, k)] = float(emean[3 * k + j])
         return out
 
-    def depth(self, rgb, **kwargs):
-        return self.model.depth_net(rgb=rgb, **kwargs)
+    def depth(self, *args, **kwargs):
+        return self.model.depth_net(*args, **kwargs)
 
     def forward(self, *args, **kwargs):
         return self.model(*args, **kwargs)

@@ -117,3 +117,35 @@ def test_degenerate_shapes_and_errors():
         tools.hysteresis(torch.zeros(4, 4))
     with pytest.raises(ValueError):
         tools.non_max_suppression(torch.zeros(1, 1, 4, 4).cuda())
+
+
+def test_annotate_frame_driver_core():
+    """infer_edge_estimation.annotate_frame: RGB pass + RGB+LiDAR pass (SAN branch) + post-processing, all on device."""
+    import infer_edge_estimation as iee
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.utils.config import load_config
+    K.set_compute_dtype("bf16")
+    cfg = load_config(None, {"model": {"depth_net": {"with_san": True}, "loss": {"supervised_method": "sparse-silog", "supervised_num_scales": 1,
+                                                                                  "supervised_loss_weight": 1.0, "edges_depth_edge_loss_all_scales": True}}})
+    torch.manual_seed(2)
+    wrap = ModelWrapper(cfg).cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    image = torch.rand(1, 3, 64, 128, generator=g).cuda()
+    lidar = ((torch.rand(1, 1, 64, 128, generator=g) < 0.1).float() * 40.0).cuda()
+    out = iee.annotate_frame(wrap, image, lidar)
+    assert set(out) == {"regular", "lidar"} and len(out["regular"]) == len(out["lidar"]) == 4
+    seen = []                                                          # the network outputs the driver post-processed
+    hook = wrap.model.depth_net.register_forward_hook(lambda m, a, r: seen.append([t.float().clone() for t in r["inv_depths"][0]]))
+    out = iee.annotate_frame(wrap, image, lidar)
+    hook.remove()
+    assert len(seen) == 2
+    for key, preds in (("regular", seen[0]), ("lidar", seen[1])):
+        for s, (e, n) in enumerate(out[key]):
+            assert e.shape == (1, 64 >> s, 128 >> s) and n.dtype == torch.uint8
+            we, wn = do.annotate((preds[s][0, 0].cpu().numpy() / 2).astype(np.float32))
+            same(e[0], we)
+            np.testing.assert_array_equal(n[0].cpu().numpy(), wn)
+    assert not torch.equal(seen[0][0], seen[1][0])                     # the LiDAR pass differs from the RGB pass
+    single = iee.annotate_frame(wrap, image, None, multiscale=False, nms=False, hysteresis=False, normals=False)
+    assert set(single) == {"regular"} and len(single["regular"]) == 1 and single["regular"][0][1] is None
