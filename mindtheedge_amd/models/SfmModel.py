@@ -30,6 +30,11 @@ class SfmModel(BaseModel):
 
     def depth_net_flipping(self, batch, flip, output_features=False):
         batch_input = {key: batch[key] for key in self._input_keys if key in batch}
+        # the reference also forwards 'input_depth' (SemiSupEdgeModel.py:44).  While training, the RGB+LiDAR pass it triggers
+        # never reaches the loss and is skipped here; in eval mode it IS the prediction the reference validates, and it is
+        # taken when the network owns the sparse branch (PackNetSAN01(with_san=True), parity unpinned)
+        if not self.training and 'input_depth' in batch and getattr(self.depth_net, 'with_san', False):
+            batch_input['input_depth'] = batch['input_depth']
         batch_input['output_features'] = output_features
         if flip:
             return flip_output(self.depth_net(**flip_batch_input(batch_input)))

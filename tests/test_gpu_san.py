@@ -105,3 +105,33 @@ def test_packnetsan_with_lidar_input_matches_composition():
     net.train()
     with pytest.raises(NotImplementedError):
         net(rgb, input_depth=d)
+
+
+def test_validation_uses_the_lidar_pass_when_the_branch_exists():
+    """Reference behaviour: in eval mode SemiSupEdgeModel forwards batch['input_depth'] (SemiSupEdgeModel.py:44), so
+    evaluate_depth validates the RGB+LiDAR prediction.  Without the branch (default build) the key is ignored."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.utils.config import load_config
+    from mindtheedge_amd.utils.synthetic import synthetic_batch
+    K.set_compute_dtype("fp32")
+    base = {"model": {"loss": {"supervised_method": "sparse-silog", "supervised_num_scales": 1, "supervised_loss_weight": 1.0,
+                               "edges_depth_edge_loss_all_scales": True}}}
+    batch = synthetic_batch(1, 64, 128, seed=3, device=torch.device("cuda", 0))
+    batch.pop("edge")
+    batch["input_depth"] = _lidar(1, 64, 128, seed=8).cuda()
+    outs = {}
+    for with_san in (False, True):
+        cfg = load_config(None, {**base, "model": {**base["model"], "depth_net": {"with_san": with_san}}})
+        torch.manual_seed(5)
+        wrap = ModelWrapper(cfg).cuda().eval()
+        if with_san:
+            _randomise(wrap.depth_net.mconvs, seed=2)
+        with torch.no_grad():
+            outs[with_san] = wrap.model(dict(batch))["inv_depths"][0][0].float().cpu()
+            if with_san:
+                direct = wrap.depth_net(batch["rgb"], input_depth=batch["input_depth"])["inv_depths"][0][0].float().cpu()
+                assert rel_err(outs[True], direct) < 1e-4
+                m = wrap.evaluate_depth(dict(batch))["metrics"]
+                assert set(m) == {"depth", "depth_pp", "depth_gt", "depth_pp_gt"}
+    assert rel_err(outs[True], outs[False]) > 1e-4
