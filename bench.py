@@ -7,7 +7,8 @@
 One "step" = zero_grad + forward (dropout 0.5, random whole-batch flip) + silog/edge loss + backward + bucketed RCCL
 gradient all-reduce (N > 1) + fused Adam, on a synthetic batch of 8 frames per GPU that is already resident in HBM
 (SURVEY.md 8(d) recipe).  Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel family
-(MFMA implicit-GEMM convolutions; algorithmic FLOPs / HIP-event time measured inside the timed region) and, at N = 1,
+(MFMA implicit-GEMM convolutions; algorithmic FLOPs / HIP-event time of every launch), "roofline_hbm": the same for the
+HBM-bound GroupNorm+ELU family (algorithmic bytes / HIP-event time against 8 TB/s), and, at N = 1,
 "cpu_baseline": the CPU oracle (oracle/) timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -57,6 +58,9 @@ class ConvTimer:
         self._orig = {}
         for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad"):
             self._orig[name] = getattr(lib, name)
+        self.hbm_records = []           # (name, e0, e1, algorithmic bytes) of the GroupNorm+ELU passes (HBM-bound family)
+        for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd"):
+            self._orig[name] = getattr(lib, name)
 
     def install(self):
         K = self.K
@@ -65,7 +69,7 @@ class ConvTimer:
         class Proxy:
             def __getattr__(self_, name):
                 fn = getattr(outer._lib, name)
-                if name not in outer._orig or not outer.enabled:
+                if name not in outer._orig or not outer.enabled or name.startswith("mte_gn_") != (outer.enabled == "hbm"):
                     return fn
 
                 def timed(*args):
@@ -73,6 +77,19 @@ class ConvTimer:
                     e0.record()
                     fn(*args)
                     e1.record()
+                    if name.startswith("mte_gn_"):
+                        # algorithmic bytes: every tensor the pass must touch once (2 B/element in bf16)
+                        if name == "mte_gn_stats":          # (y1, ld1, y2, ld2, scale2, stats, B, HW, C, dtype, stream)
+                            has2, (B_, HW_, C_, dt_) = bool(args[2]), args[6:10]
+                            tensors = 1 + has2                                  # read y1 (+ y2)
+                        elif name == "mte_gn_elu_fwd":      # (y1, ld1, y2, ld2, scale2, stats, gamma, beta, z, ldz, B, HW, C, eps, dtype, stream)
+                            has2, (B_, HW_, C_), dt_ = bool(args[2]), args[10:13], args[14]
+                            tensors = 1 + has2 + 1                              # read y1 (+ y2), write z
+                        else:                               # (dz, lddz, y1, ld1, y2, ld2, scale2, stats, gamma, beta, red, d1, ldd1, d2, ldd2, ..., B, HW, C, eps, dtype, stream)
+                            has2, hasd2, (B_, HW_, C_), dt_ = bool(args[4]), bool(args[13]), args[18:21], args[22]
+                            tensors = 2 * (2 + has2) + 1 + hasd2                # reduce + apply each read dz, y1 (+ y2); write d1 (+ d2)
+                        outer.hbm_records.append((name, e0, e1, float(tensors) * B_ * HW_ * C_ * (2 if dt_ == 0 else 4)))
+                        return
                     if name == "mte_conv2d_igemm":
                         shp = args[7:14]           # (x, ldx, w, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, ...)
                     elif name == "mte_conv2d_patch_fwd":
@@ -84,6 +101,10 @@ class ConvTimer:
                 return timed
         self._lib = K.lib
         K.lib = Proxy()
+
+    def hbm_summary(self):
+        t = sum(e0.elapsed_time(e1) for _, e0, e1, _ in self.hbm_records) * 1e-3
+        return len(self.hbm_records), t, sum(r[3] for r in self.hbm_records)
 
     def summary(self):
         out = {}
@@ -267,12 +288,13 @@ def main():
     if timer:
         # the weight-gradient side stream is switched off for these steps: with kernels of two streams sharing the CUs an
         # event pair measures contention, not the kernel
-        timer.enabled = True
         K.use_wgrad_side_stream(False)
         ksteps = min(args.steps, 3)
-        for _ in range(ksteps):
-            step()
-        sync()
+        for family in ("conv", "hbm"):           # separate steps per family: the event pairs of one must not space out the other
+            timer.enabled = family
+            for _ in range(ksteps):
+                step()
+            sync()
         timer.enabled = False
         K.use_wgrad_side_stream(not os.environ.get("MTE_NO_SIDE_STREAM"))
     if dist_on:
@@ -321,6 +343,14 @@ def main():
                                    "algorithmic_flops_per_step": alg / ksteps, "executed_flops_per_step": tot_f / ksteps,
                                    "by_kernel": {k: {"launches_per_step": v[0] / ksteps, "ms_per_step": v[1] / ksteps * 1e3,
                                                      "executed_tflops": v[2] / v[1] / 1e12 if v[1] > 0 else None} for k, v in s.items()}}
+            hn, ht, hb = timer.hbm_summary()
+            if ht > 0:
+                # second roofline object: the HBM-bound GroupNorm+ELU family (26 of the 84 GB a step moves), same method --
+                # algorithmic bytes of the timed launches / HIP-event time, against the 8 TB/s HBM3E peak
+                res["roofline_hbm"] = {"bound": "hbm", "kernel": "GroupNorm(16)+ELU family (mte_gn_stats, mte_gn_elu_fwd, mte_gn_elu_bwd)",
+                                       "achieved": hb / ht / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / ht / 1e9 / HBM_PEAK_GBS,
+                                       "traffic": None, "launches_per_step": hn / ksteps, "ms_per_step": ht / ksteps * 1e3,
+                                       "algorithmic_bytes_per_step": hb / ksteps, "timed_steps": ksteps}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W, args.cpu_steps)
         print(json.dumps(res))
