@@ -116,7 +116,7 @@ class ConvTimer:
         return out
 
 
-def pmc_traffic_per_launch(args, B, H, W):
+def pmc_traffic_per_launch(args, B, H, W, key="conv_family_bytes_per_launch"):
     """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in
     separate runs by tools/pmc_traffic.sh as MI355X_MICROARCH.md prescribes; bench.py cannot read PMCs itself).  Only
     reported for the workload the passes were taken on."""
@@ -127,7 +127,7 @@ def pmc_traffic_per_launch(args, B, H, W):
         d = json.load(f)
     if (d.get("mode"), d.get("batch"), d.get("height"), d.get("width"), d.get("dtype")) != (args.mode, B, H, W, args.dtype):
         return None
-    return d["conv_family_bytes_per_launch"]
+    return d.get(key)
 
 
 def conv_flops_per_image(H, W):
@@ -349,7 +349,8 @@ def main():
                 # algorithmic bytes of the timed launches / HIP-event time, against the 8 TB/s HBM3E peak
                 res["roofline_hbm"] = {"bound": "hbm", "kernel": "GroupNorm(16)+ELU family (mte_gn_stats, mte_gn_elu_fwd, mte_gn_elu_bwd)",
                                        "achieved": hb / ht / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / ht / 1e9 / HBM_PEAK_GBS,
-                                       "traffic": None, "launches_per_step": hn / ksteps, "ms_per_step": ht / ksteps * 1e3,
+                                       "traffic": pmc_traffic_per_launch(args, B, H, W, "gn_family_bytes_per_launch"),
+                                       "launches_per_step": hn / ksteps, "ms_per_step": ht / ksteps * 1e3,
                                        "algorithmic_bytes_per_step": hb / ksteps, "timed_steps": ksteps}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W, args.cpu_steps)
