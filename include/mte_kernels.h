@@ -237,6 +237,16 @@ int mte_sparse_bn_relu(const void* a, long lda, const void* b, long ldb, const v
 int mte_san_fuse(const void* skip, long ld_skip, const void* sparse, long ld_sparse, const float* w, const float* bias,
                  void* out, long ldo, long npix, int C, int dtype, mte_stream_t stream);
 
+/* ---- training-target preparation (data half)
+ * mte_edge_target_from_u8:   dst = src / 255                      (datasets/augmentations.py:186-188,199-201)
+ * mte_normal_target_from_u8: dst = (360 * (src/255) - 180) * pi/180   (datasets/gta_dataset.py:407-409,417-418), float64 inside
+ * mte_resize_depth_preserve: resize_depth_preserve (datasets/augmentations.py:58-100) of float [B,h,w] sparse maps into
+ *   [B,H,W]: valid = value > 0, target = (int(y*H/h), int(x*W/w)), last source pixel in raster order wins, zeros elsewhere.
+ *   winner_ws: B*H*W ints of scratch. */
+int mte_edge_target_from_u8(const unsigned char* src, float* dst, long n, mte_stream_t stream);
+int mte_normal_target_from_u8(const unsigned char* src, float* dst, long n, mte_stream_t stream);
+int mte_resize_depth_preserve(const float* src, int B, int h, int w, float* dst, int H, int W, int* winner_ws, mte_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
