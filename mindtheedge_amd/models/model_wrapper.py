@@ -39,7 +39,9 @@ def setup_depth_edge_loss(config):
 def setup_model(config, prepared, **kwargs):
     model = load_class(config.model.name, paths=['models'])(**{**config.model.loss, **kwargs})
     if 'depth_net' in model.network_requirements:
-        model.add_depth_net(setup_depth_net(config.model.depth_net, prepared))
+        # the depth-edge estimator runs the RGB+LiDAR pass: its network owns the sparse branch (with_san is not a reference key)
+        extra = {'with_san': True} if config.model.name.startswith('EdgeEstimation') and 'with_san' not in config.model.depth_net else {}
+        model.add_depth_net(setup_depth_net(config.model.depth_net, prepared, **extra))
     if 'pose_net' in model.network_requirements:
         raise NotImplementedError("pose networks are outside this build's scope")
     if config.edges.train_depth_edges:

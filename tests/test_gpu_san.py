@@ -135,3 +135,26 @@ def test_validation_uses_the_lidar_pass_when_the_branch_exists():
                 m = wrap.evaluate_depth(dict(batch))["metrics"]
                 assert set(m) == {"depth", "depth_pp", "depth_gt", "depth_pp_gt"}
     assert rel_err(outs[True], outs[False]) > 1e-4
+
+
+def test_edge_estimation_lidar_model_eval():
+    """registry name of the annotation config; eval forward = network(rgb, lidar/200) with the full-resolution map halved."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.utils.config import load_config
+    K.set_compute_dtype("fp32")
+    cfg = load_config(None, {"model": {"name": "EdgeEstimationLIDARModel", "loss": {"edges_depth_edge_loss_all_scales": True}}, "edges": {"train_depth_edges": False}})
+    torch.manual_seed(7)
+    wrap = ModelWrapper(cfg).cuda().eval()
+    assert wrap.depth_net.with_san
+    _randomise(wrap.depth_net.mconvs, seed=3)
+    rgb = torch.rand(1, 3, 64, 128, generator=torch.Generator().manual_seed(2)).cuda()
+    lidar = _lidar(1, 64, 128, seed=5).cuda()
+    with torch.no_grad():
+        out = wrap.model({"rgb": rgb, "input_depth": lidar.clone()})["inv_depths"][0]
+        ref = wrap.depth_net(rgb, input_depth=lidar / 200.0)["inv_depths"][0]
+    assert rel_err(out[0].float().cpu(), ref[0].float().cpu() / 2) < 1e-4
+    assert rel_err(out[1].float().cpu(), ref[1].float().cpu()) < 1e-4          # only the full-resolution scale is halved in eval
+    wrap.train()
+    with pytest.raises(NotImplementedError):
+        wrap.model({"rgb": rgb, "input_depth": lidar})
