@@ -53,7 +53,7 @@ int mte_set_option(int option, int value);
  *   0 igemm loader (1 buffer-descriptor LDS-DMA [default], 2 pointer LDS-DMA, 0 register staging)
  *   1 conv3d kernels (0 gather, 1 LDS-tiled, 2 + four-plane unpack data gradient [default]; 100/101 large/half-size tiles)
  *   2 / 3 GroupNorm launch geometry (min rows per thread / target workgroups)
- *   4 wgrad kernel (1 LDS-DMA ring [default], 0 register-staged)      6 igemm tiles (0 128x128, 1 + 256x128, 2 + 256x256 [default])
+ *   4 wgrad kernel (1 LDS-DMA ring [default], 0 register-staged)      6 igemm tiles (0 128x128, 1 + 256x128, 2 + 256x256, 3 + 192x96 [default])
  *   7 min tiles for the big igemm tiles (224)   8 wgrad 8/16-wave tiles (1)   9 wgrad workgroup target (512)
  *   11 patch conv: 0/1 tall 16x32 tiles, >= 100 = workgroup target of the patch wgrad (512) */
 int mte_debug_set(int key, int value);

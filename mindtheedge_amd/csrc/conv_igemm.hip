@@ -68,6 +68,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int A_CH = BM * 4 / NTHR;                 // 16-B chunks of the A tile per thread
+    static_assert(BM * 4 % NTHR == 0, "the A tile must split evenly over the threads");
     constexpr int B_CH = (BN * 4 + NTHR - 1) / NTHR;         // (BN = 32: only threads < 128 load)
     constexpr int ST = DMA ? 4 : 2;                    // LDS ring depth
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -465,7 +466,7 @@ launched:
 }
 
 int g_igemm_big_min_tiles = 224;
-int g_igemm_big = 2;                                 // development knob (mte_debug_set(6, v)): 256 x 128 tiles where they pay
+int g_igemm_big = 3;                                 // development knob (mte_debug_set(6, v)): 0 128x128 only, 1 + 256x128, 2 + 256x256, 3 + 192x96
 
 template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st, int* stats_done) {
     if constexpr (sizeof(T) == 2) {
@@ -488,6 +489,10 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
             (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160)))   // (96: below it choose_splits does split)
             return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st, stats_done);   // 256 x 256, 16 waves
+        // 65..96 columns (the 72-channel decoder concat as data-gradient N): a 192 x 96 tile of 6 waves wastes a quarter of
+        // the MFMA work instead of the 44 % a 128-wide tile does
+        if (g_igemm_big >= 3 && dma_ok && !a.out_f32 && a.N > 64 && a.N <= 96 && ((a.M + 191) / 192) >= g_igemm_big_min_tiles)
+            return launch_igemm<T, 2, 3, 3, 1>(a, 0, st, stats_done);
         if (g_igemm_big && dma_ok && !a.out_f32 && a.N > 64 && tiles_big >= g_igemm_big_min_tiles)
             return launch_igemm<T, 4, 2, 2, 2>(a, 0, st, stats_done);
     }

@@ -165,7 +165,7 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape):
         finally:
             K.use_conv_epilogue_stats(False)
             K._splitk_workspace = orig
-            K.lib.mte_debug_set(6, 2)
+            K.lib.mte_debug_set(6, 3)
             K.lib.mte_debug_set(7, 224)
 
     K.use_patch_kernels(False)
@@ -203,5 +203,42 @@ def test_big_tile_split_k_matches_small_tiles(shape):
         assert rel_err(outs[0], outs[1]) < 8e-3
         assert float(outs[0].abs().mean()) > 0.1                 # (not trivially zero)
     finally:
-        K.lib.mte_debug_set(6, 2)
+        K.lib.mte_debug_set(6, 3)
+        K.use_patch_kernels(True)
+
+
+@pytest.mark.parametrize("shape", [(32, 72, 3, 2, 24, 40), (64, 88, 3, 1, 30, 33), (96, 96, 1, 2, 16, 48), (32, 72, 3, 1, 17, 31)])
+def test_igemm_192x96_tiles_match_128x128_tiles(shape):
+    """The 6-wave 192x96-tile instantiation (65..96 output columns: the 72-channel decoder concat as data-gradient N)
+    against the 4-wave 128x128 one: same K order and accumulation chain per output -> bit-identical, with and without
+    accumulation into the destination."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W = shape
+
+    def run(big):
+        K.lib.mte_debug_set(6, big)
+        K.lib.mte_debug_set(7, 1)
+        orig, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)
+        try:
+            g = torch.Generator().manual_seed(5 + cin + cout)
+            w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+            b = (torch.rand(cout, generator=g) - 0.5).cuda()
+            xa = K.image_to_act(torch.rand(B, cin, H, W, generator=g).cuda() * 2 - 1)
+            wf, _ = K.WeightPack().get(w, xa.dtype, False)
+            y = K.conv_forward(xa, wf, b, cout, k, k)
+            acc = K.conv_forward(xa, wf, None, cout, k, k, out=y.clone(memory_format=torch.preserve_format), accumulate=True)
+            torch.cuda.synchronize()
+            return y.float().cpu(), acc.float().cpu()
+        finally:
+            K._splitk_workspace = orig
+            K.lib.mte_debug_set(6, 3)
+            K.lib.mte_debug_set(7, 224)
+
+    K.use_patch_kernels(False)
+    try:
+        y0, a0 = run(0)
+        y3, a3 = run(3)
+        assert torch.equal(y3, y0) and torch.equal(a3, a0)
+        assert float(y0.abs().mean()) > 0.05
+    finally:
         K.use_patch_kernels(True)
