@@ -188,3 +188,43 @@ def test_network_outputs_with_conv_epilogue_statistics():
     finally:
         K.use_conv_epilogue_stats(False)
         K.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_dee_rgb_only_training_step_matches_reference(dtype, tol):
+    """EdgeEstimationLIDARModel trained without a LiDAR input (reference EdgeEstimationLIDARModel.py:135-160 with
+    edge_lidar_loss = 0): BCE directly on inv_depth/2 at four scales, halved -- against the reference's own step
+    (tests/golden/make_golden_dee_model.py)."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.models.EdgeEstimationLIDARModel import EdgeEstimationLIDARModel
+    from mindtheedge_amd.losses.grad_loss import GradLoss
+    g = load_golden("model_dee_rgb_64x128")
+    net = _net(dtype)
+    try:
+        model = EdgeEstimationLIDARModel(supervised_loss_weight=0.0, weight_rgbd=1.0, edges_depth_edge_loss_all_scales=True,
+                                         upsample_depth_maps=False, flip_lr_prob=0.0)
+        model.add_depth_net(net)
+        model.add_edge_loss(GradLoss("cross_entropy", True, [], 10.0, 1.0))
+        model.train()
+        batch = {k[6:]: v.cuda() for k, v in g.items() if k.startswith("batch.")}
+        out = model(batch)
+        assert rel_err(out["loss"].reshape(-1).cpu(), g["loss"].reshape(-1)) < tol
+        assert rel_err(out["metrics"]["edge_loss"].cpu(), g["edge_loss"]) < tol
+        assert rel_err(out["inv_depths"][0].float().cpu(), g["prob0"]) < (tol if dtype == "fp32" else 5e-2)
+        assert rel_err(out["inv_depths"][3].float().cpu(), g["prob3"]) < (tol if dtype == "fp32" else 5e-2)
+        out["loss"].sum().backward()
+        grads = dict(net.named_parameters())
+        gtol = 5e-3 if dtype == "fp32" else 0.25
+        for k, v in g.items():
+            if k.startswith("grad."):
+                assert rel_err(grads[k[5:]].grad.cpu(), v) < gtol, k
+        bad = []
+        for n, ss in zip([str(n) for n in g["grad_names"]], g["grad_sumsq"].tolist()):
+            got = float((grads[n].grad.double() ** 2).sum())
+            if abs(got - ss) > 2 * gtol * max(ss, 1e-10):
+                bad.append((n, got, ss))
+        assert not bad, bad[:8]
+        with pytest.raises(NotImplementedError):
+            model({**batch, "input_depth": batch["edge"]})
+    finally:
+        K.set_compute_dtype("bf16")
