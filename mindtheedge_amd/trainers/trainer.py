@@ -87,7 +87,8 @@ class Trainer:
             output['loss'].backward()
             optimizer.step()
             m = output['metrics']
-            run += torch.stack([output['loss'].detach().sum(), m['supervised_loss'].sum(), m['edge_loss'].sum()])
+            zero = run.new_zeros(())
+            run += torch.stack([output['loss'].detach().sum(), m.get('supervised_loss', zero).sum(), m.get('edge_loss', zero).sum()])
             n += 1
             if self.is_rank_0 and self.log_every and n % self.log_every == 0:
                 last = (run / n).tolist()                       # the only host sync
