@@ -101,10 +101,12 @@ def canny_from_depth(depth, thresholds=CANNY_THRESHOLDS, return_vis=False):
     flags = torch.empty(sweeps + 1, dtype=torch.int32, device=d.device)
     K.lib.mte_canny_begin(d.data_ptr(), B, H, W, P, ctypes.addressof(th), max_ws.data_ptr(), vis.data_ptr() if return_vis else None,
                           state.data_ptr(), K._stream())
-    while True:
+    for _ in range(H * W // sweeps + 2):            # every sweep that is not the last turns at least one pixel: a hard bound
         K.lib.mte_canny_propagate(state.data_ptr(), flags.data_ptr(), sweeps, P * B, H, W, K._stream())
         if int(flags[sweeps].item()) == 0:              # one host read per 8 sweeps, as in utils/tools.py::hysteresis
             break
+    else:
+        raise K.MteError("Canny hysteresis did not reach a fixed point")
     edges = torch.empty((P, B, H, W), dtype=torch.float32, device=d.device)
     K.lib.mte_canny_finish(state.data_ptr(), edges.data_ptr(), P * B, H, W, K._stream())
     if squeeze:

@@ -54,10 +54,12 @@ def hysteresis(img, t_low=0.3, t_high=0.7):
     flags = torch.empty(SWEEPS + 1, dtype=torch.int32, device=x.device)
     out = torch.empty_like(x)
     K.lib.mte_hysteresis_begin(x.data_ptr(), state.data_ptr(), info.data_ptr(), B, H, W, float(t_low), float(t_high), K._stream())
-    while True:
+    for _ in range(H * W // SWEEPS + 2):            # every sweep that is not the last turns at least one pixel: a hard bound
         K.lib.mte_hysteresis_propagate(state.data_ptr(), flags.data_ptr(), SWEEPS, B, H, W, K._stream())
         if int(flags[SWEEPS].item()) == 0:          # the only host read: did the last sweep of this batch still change pixels?
             break
+    else:
+        raise K.MteError("hysteresis did not reach a fixed point")
     K.lib.mte_hysteresis_finish(x.data_ptr(), state.data_ptr(), info.data_ptr(), out.data_ptr(), B, H, W, K._stream())
     return out[0] if squeeze else out
 
