@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--input', type=str, nargs='*', default=[], help='.npy images [3,H,W] or [H,W,3] in [0,1] (or uint8)')
     ap.add_argument('--output', type=str, default='results')
     ap.add_argument('--synthetic', type=int, default=0, help='number of synthetic frames of the configured shape')
+    ap.add_argument('--graph', action='store_true', help='replay the forward from a HIP graph (single frames are launch-bound)')
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -46,8 +47,18 @@ def main():
         images.append(torch.from_numpy(a / (255.0 if a.max() > 1.5 else 1.0)))
     g = torch.Generator().manual_seed(0)
     images += [torch.rand(3, H, W, generator=g) for _ in range(args.synthetic)]
+    graphed = None
     for ctr, img in enumerate(images):
-        depth = infer_depth(wrapper, img.unsqueeze(0).cuda())
+        frame = img.unsqueeze(0).cuda()
+        if args.graph:
+            from mindtheedge_amd.utils.depth import inv2depth
+            from mindtheedge_amd.utils.graph import GraphedDepth
+            if graphed is None or tuple(graphed.rgb.shape) != tuple(frame.shape):
+                wrapper.eval()
+                graphed = GraphedDepth(wrapper.depth_net, frame)
+            depth = inv2depth(graphed(frame)['inv_depths'][0][0])
+        else:
+            depth = infer_depth(wrapper, frame)
         np.save(os.path.join(args.output, '%08d_regular.npy' % ctr), depth[0, 0].cpu().numpy())
     print('wrote %d depth maps to %s' % (len(images), args.output))
 

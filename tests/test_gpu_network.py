@@ -228,3 +228,33 @@ def test_dee_rgb_only_training_step_matches_reference(dtype, tol):
             model({**batch, "input_depth": batch["edge"]})
     finally:
         K.set_compute_dtype("bf16")
+
+
+def test_graph_replay_of_the_inference_forward():
+    """HIP-graph capture of the eval forward (utils/graph.py): replays follow the input buffer and agree with the eager
+    forward (fp32 mode: to split-K summation-order noise)."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.utils.graph import GraphedDepth
+    net = _net("fp32")
+    try:
+        net.eval()
+        g = torch.Generator().manual_seed(0)
+        a = torch.rand(1, 3, 64, 128, generator=g).cuda()
+        b = torch.rand(1, 3, 64, 128, generator=g).cuda()
+        graphed = GraphedDepth(net, a)
+        out_a = [t.float().clone() for t in graphed(a)["inv_depths"][0]]
+        out_b = [t.float().clone() for t in graphed(b)["inv_depths"][0]]
+        with torch.no_grad():
+            want_a = net(a)["inv_depths"][0]
+            want_b = net(b)["inv_depths"][0]
+        for s in range(4):
+            assert rel_err(out_a[s].cpu(), want_a[s].float().cpu()) < 1e-4
+            assert rel_err(out_b[s].cpu(), want_b[s].float().cpu()) < 1e-4
+        assert rel_err(out_a[0].cpu(), out_b[0].cpu()) > 1e-3
+        with pytest.raises(ValueError):
+            graphed(torch.rand(2, 3, 64, 128).cuda())
+        net.train()
+        with pytest.raises(ValueError):
+            GraphedDepth(net, a)
+    finally:
+        K.set_compute_dtype("bf16")
