@@ -21,23 +21,28 @@ for (name, grid, lds), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[
 iv = []
 with open(path) as f:
     for r in csv.DictReader(f):
-        iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
+                   r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]))
 iv.sort()
 # drop the warm-up/initialisation part: keep the last 60 % of kernels
 iv = iv[int(len(iv) * 0.4):]
-busy, cur_s, cur_e, gaps = 0, iv[0][0], iv[0][1], []
-for s_, e_ in iv[1:]:
+busy, cur_s, cur_e, gaps, where, last = 0, iv[0][0], iv[0][1], [], [], iv[0][2]
+for s_, e_, nm in iv[1:]:
     if s_ > cur_e:
         busy += cur_e - cur_s
         gaps.append(s_ - cur_e)
-        cur_s, cur_e = s_, e_
+        where.append((s_ - cur_e, last, nm))
+        cur_s, cur_e, last = s_, e_, nm
     else:
-        cur_e = max(cur_e, e_)
+        if e_ > cur_e:
+            cur_e, last = e_, nm
 busy += cur_e - cur_s
 span = cur_e - iv[0][0]
 print("steady-state window: span %.2f ms, busy %.2f ms (%.1f %%), idle %.2f ms in %d gaps" % (span * 1e-6, busy * 1e-6, 100.0 * busy / span, (span - busy) * 1e-6, len(gaps)))
 gaps.sort(reverse=True)
 print("largest gaps (us):", [round(g * 1e-3, 1) for g in gaps[:12]])
+for g_, a_, b_ in sorted(where, reverse=True)[:8]:
+    print("   gap %7.1f us between %-48s and %s" % (g_ * 1e-3, a_, b_))
 import bisect
 for lim in (2, 5, 10, 20, 50):
     sel = [g for g in gaps if g * 1e-3 <= lim]
