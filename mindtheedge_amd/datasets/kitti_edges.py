@@ -111,3 +111,113 @@ def prepare_edge_sample(edge_maps_u8, normal_maps_u8, shape):
         rad = normal_target(n)
         out[key] = (rad if tuple(rad.shape) == tgt else resize_linear(rad, tgt)).unsqueeze(0)
     return out
+
+
+# ---- a reader on top of the formats above -------------------------------------------------------------------------------
+# File decoding is host I/O (PIL / numpy, the reference uses PIL and cv2.imread); everything after it -- sparse resizes,
+# target scaling, de-quantisation -- runs on the device through the functions above.  Not rebuilt: colour jitter, random
+# crops, context frames, the .bin velodyne projection (pass depth / lidar maps as 16-bit PNG or .npy).
+
+def _read_gray_u8(path):
+    """cv2.imread(path)[:, :, 0] of the reference for the 8-bit single-channel annotation PNGs."""
+    import numpy as np
+    from PIL import Image
+    if path.endswith('.npy'):
+        return np.load(path)
+    a = np.array(Image.open(path))
+    return a if a.ndim == 2 else a[:, :, -1 if a.shape[2] >= 3 else 0]      # OpenCV channel 0 is blue = PIL's channel 2
+
+
+def read_png_depth(path):
+    """KITTI 16-bit depth PNG -> float32 metres, -1 where there is no return (reference kitti_dataset.py:40-46)."""
+    import numpy as np
+    from PIL import Image
+    if path.endswith('.npy'):
+        return np.load(path).astype(np.float32)
+    png = np.array(Image.open(path), dtype=int)
+    assert png.max() > 255, 'Wrong .png depth file'
+    depth = png.astype(np.float32) / 256.
+    depth[png == 0] = -1.
+    return depth
+
+
+class KittiEdgeSplitDataset:
+    """One sample per split-file line: rgb (PIL-resized to ``image_shape`` like the reference's resize_image, /255),
+    depth (resize_depth_preserve), edge / edge_1..3 and normal / normal_1..3 targets.  ``__getitem__`` returns device
+    tensors shaped like the reference's collated sample with batch size 1 removed: rgb [3,H,W], depth [1,H,W], ..."""
+
+    def __init__(self, split_file, image_shape, device='cuda', root=''):
+        self.records = read_split(split_file)
+        self.shape = (int(image_shape[0]), int(image_shape[1]))
+        self.device = torch.device(device)
+        self.root = root
+
+    def __len__(self):
+        return len(self.records)
+
+    def _p(self, path):
+        return path if os.path.isabs(path) or not self.root else os.path.join(self.root, path)
+
+    def __getitem__(self, idx):
+        import numpy as np
+        from PIL import Image
+        rec = self.records[idx]
+        H, W = self.shape
+        img = Image.open(self._p(rec['rgb'])).convert('RGB')
+        if img.size != (W, H):
+            img = img.resize((W, H), Image.LANCZOS)                       # transforms.Resize(shape, ANTIALIAS), augmentations.py:16-35
+        rgb = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device).permute(2, 0, 1).float() / 255.0
+        sample = {'idx': idx, 'rgb': rgb}
+        if rec.get('depth'):
+            d = torch.from_numpy(read_png_depth(self._p(rec['depth']))).to(self.device)
+            sample['depth'] = resize_depth_preserve(d, self.shape).unsqueeze(0)
+        edges, normals = [], []
+        if rec.get('edge'):
+            edges = [torch.from_numpy(np.ascontiguousarray(_read_gray_u8(p)).astype(np.uint8)).to(self.device)
+                     for p in multiscale_paths(self._p(rec['edge']))]
+        if rec.get('normal'):
+            normals = [torch.from_numpy(np.ascontiguousarray(_read_gray_u8(p)).astype(np.uint8)).to(self.device)
+                       for p in multiscale_paths(self._p(rec['normal']))]
+        sample.update(prepare_edge_sample(edges, normals, self.shape))
+        return sample
+
+
+def collate(samples):
+    out = {}
+    for k in samples[0]:
+        vals = [s[k] for s in samples]
+        out[k] = torch.stack(vals) if torch.is_tensor(vals[0]) else vals
+    return out
+
+
+class SplitLoader:
+    """Minimal epoch iterator: rank-strided, fixed order or shuffled per epoch (``set_epoch``), drops the ragged tail."""
+
+    def __init__(self, dataset, batch_size, rank=0, world=1, shuffle=True, seed=0):
+        self.ds, self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch = dataset, batch_size, rank, world, shuffle, seed, 0
+        self.sampler = self                                           # Trainer.fit calls loader.sampler.set_epoch(epoch)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return len(self.ds) // self.world // self.bs
+
+    def __iter__(self):
+        order = torch.randperm(len(self.ds), generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist() \
+            if self.shuffle else list(range(len(self.ds)))
+        mine = order[self.rank::self.world]
+        for i in range(len(self)):
+            yield collate([self.ds[j] for j in mine[i * self.bs:(i + 1) * self.bs]])
+
+
+def make_loader(config, rank, world):
+    """``train_edges.py --data mindtheedge_amd.datasets.kitti_edges:make_loader``: config.datasets.train.split[0] is the
+    8-column split file, config.datasets.train.path[0] (optional) the root folder of its relative paths."""
+    tr = config.datasets.train
+    shape = config.datasets.augmentation.image_shape
+    shape = eval(shape) if isinstance(shape, str) else tuple(shape)
+    root = (tr.get('path') or [''])[0] if isinstance(tr.get('path'), (list, tuple)) else (tr.get('path') or '')
+    split = tr['split'][0] if isinstance(tr['split'], (list, tuple)) else tr['split']
+    ds = KittiEdgeSplitDataset(split, shape, device=torch.device('cuda', torch.cuda.current_device()), root=root)
+    return SplitLoader(ds, int(tr.batch_size), rank, world)

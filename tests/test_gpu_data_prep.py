@@ -56,3 +56,53 @@ def test_prepare_edge_sample_shapes_and_errors():
         normal_target(torch.zeros(4, 4, dtype=torch.uint8))
     with pytest.raises(ValueError):
         normal_target(torch.zeros(4, 4).cuda())
+
+
+def test_split_dataset_end_to_end(tmp_path):
+    """PNG files + an 8-column split file on disk -> device batches with the reference's keys, scales and value ranges,
+    then one training step of the model on such a batch."""
+    from PIL import Image
+    from mindtheedge_amd.datasets.kitti_edges import KittiEdgeSplitDataset, SplitLoader
+    H, W = 64, 128
+    g = np.random.default_rng(0)
+    lines = []
+    for i in range(3):
+        Image.fromarray((g.random((H + 10, W + 20, 3)) * 255).astype(np.uint8)).save(os.path.join(tmp_path, "rgb%d.png" % i))
+        depth = ((g.random((H, W)) < 0.1) * (1 + 79 * g.random((H, W))) * 256).astype(np.uint16)
+        depth[0, 0] = 300 * 256 // 256 + 300                                   # keep max > 255
+        Image.fromarray(depth).save(os.path.join(tmp_path, "depth%d.png" % i))
+        for s in range(4):
+            e = ((g.random((H >> s, W >> s)) < 0.05) * 255).astype(np.uint8)
+            Image.fromarray(e).save(os.path.join(tmp_path, "%08d_lidar_00%d.png" % (i, s)))
+            os.makedirs(os.path.join(tmp_path, "normals"), exist_ok=True)
+            Image.fromarray(g.integers(0, 256, (H >> s, W >> s), dtype=np.uint8)).save(os.path.join(tmp_path, "normals", "%08d_lidar_00%d.png" % (i, s)))
+        lines.append("rgb%d.png depth%d.png %08d_lidar_000.png depth%d.png None None None normals/%08d_lidar_000.png\n" % (i, i, i, i, i))
+    split = os.path.join(tmp_path, "split.txt")
+    open(split, "w").writelines(lines)
+    ds = KittiEdgeSplitDataset(split, (H, W), root=str(tmp_path))
+    assert len(ds) == 3
+    s0 = ds[0]
+    assert s0["rgb"].shape == (3, H, W) and 0.0 <= float(s0["rgb"].min()) and float(s0["rgb"].max()) <= 1.0
+    d_png = np.array(Image.open(os.path.join(tmp_path, "depth0.png")), dtype=int)
+    want_d = do.resize_depth_preserve(np.where(d_png == 0, -1.0, d_png / 256.0).astype(np.float32), (H, W)).astype(np.float32)
+    np.testing.assert_array_equal(s0["depth"][0].cpu().numpy(), want_d)
+    for s in range(4):
+        sfx = "" if s == 0 else "_%d" % s
+        e_png = np.array(Image.open(os.path.join(tmp_path, "00000000_lidar_00%d.png" % s)))
+        np.testing.assert_array_equal(s0["edge" + sfx][0].cpu().numpy(), (e_png / 255.0).astype(np.float32))
+        n_png = np.array(Image.open(os.path.join(tmp_path, "normals", "00000000_lidar_00%d.png" % s)))
+        np.testing.assert_array_equal(s0["normal" + sfx][0].cpu().numpy(), do.normal_from_u8(n_png).astype(np.float32))
+    loader = SplitLoader(ds, 2, shuffle=False)
+    batches = list(loader)
+    assert len(batches) == 1 and batches[0]["rgb"].shape == (2, 3, H, W) and batches[0]["edge_2"].shape == (2, 1, H // 4, W // 4)
+    # a training step on the loaded batch
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.utils.config import load_config
+    K.set_compute_dtype("bf16")
+    cfg = load_config(None, {"model": {"loss": {"supervised_method": "sparse-silog", "supervised_num_scales": 1, "supervised_loss_weight": 1.0,
+                                                  "edges_depth_edge_loss_all_scales": True, "flip_lr_prob": 0.0}}})
+    wrap = ModelWrapper(cfg).cuda().train()
+    out = wrap.training_step(batches[0])
+    assert torch.isfinite(out["loss"]).all()
+    out["loss"].sum().backward()
