@@ -106,3 +106,10 @@ def test_split_dataset_end_to_end(tmp_path):
     out = wrap.training_step(batches[0])
     assert torch.isfinite(out["loss"]).all()
     out["loss"].sum().backward()
+    # the train_edges.py --data hook, two ranks' shares are disjoint
+    from mindtheedge_amd.datasets.kitti_edges import make_loader
+    cfg2 = load_config(None, {"datasets": {"augmentation": {"image_shape": (H, W)}, "train": {"batch_size": 1, "split": [split], "path": [str(tmp_path)]}}})
+    l0, l1 = make_loader(cfg2, 0, 2), make_loader(cfg2, 1, 2)
+    i0 = [b["idx"][0] for b in l0]
+    i1 = [b["idx"][0] for b in l1]
+    assert len(i0) == len(i1) == 1 and set(i0).isdisjoint(i1)
