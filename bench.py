@@ -61,6 +61,9 @@ class ConvTimer:
         self.hbm_records = []           # (name, e0, e1, algorithmic bytes) of the GroupNorm+ELU passes (HBM-bound family)
         for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd"):
             self._orig[name] = getattr(lib, name)
+        self.loss_records = []          # the fused depth-edge loss stencils ("reported as HBM GB/s vs 8.0 TB/s")
+        for name in ("mte_edge_loss_fwd", "mte_edge_loss_bwd"):
+            self._orig[name] = getattr(lib, name)
 
     def install(self):
         K = self.K
@@ -69,7 +72,8 @@ class ConvTimer:
         class Proxy:
             def __getattr__(self_, name):
                 fn = getattr(outer._lib, name)
-                if name not in outer._orig or not outer.enabled or name.startswith("mte_gn_") != (outer.enabled == "hbm"):
+                hbm_family = name.startswith("mte_gn_") or name.startswith("mte_edge_loss_")
+                if name not in outer._orig or not outer.enabled or hbm_family != (outer.enabled == "hbm"):
                     return fn
 
                 def timed(*args):
@@ -77,6 +81,14 @@ class ConvTimer:
                     e0.record()
                     fn(*args)
                     e1.record()
+                    if name.startswith("mte_edge_loss_"):
+                        # fwd (pred, edge, normal, mask, sums, gmap, B, H, W, ...): reads pred + edge (+ normal, + mask) = 4 B each;
+                        # bwd (pred, edge, normal, mask, coef, gout, dpred, B, H, W, ...): the same reads + 4 B gradient write
+                        fwd_ = name.endswith("_fwd")
+                        B_, H_, W_ = args[6:9] if fwd_ else args[7:10]
+                        maps = 2 + bool(args[2]) + bool(args[3]) + (0 if fwd_ else 1)
+                        outer.loss_records.append((name, e0, e1, 4.0 * maps * B_ * H_ * W_))
+                        return
                     if name.startswith("mte_gn_"):
                         # algorithmic bytes: every tensor the pass must touch once (2 B/element in bf16)
                         if name == "mte_gn_stats":          # (y1, ld1, y2, ld2, scale2, stats, B, HW, C, dtype, stream)
@@ -105,6 +117,10 @@ class ConvTimer:
     def hbm_summary(self):
         t = sum(e0.elapsed_time(e1) for _, e0, e1, _ in self.hbm_records) * 1e-3
         return len(self.hbm_records), t, sum(r[3] for r in self.hbm_records)
+
+    def loss_summary(self):
+        t = sum(e0.elapsed_time(e1) for _, e0, e1, _ in self.loss_records) * 1e-3
+        return len(self.loss_records), t, sum(r[3] for r in self.loss_records)
 
     def summary(self):
         out = {}
@@ -352,6 +368,11 @@ def main():
                                        "traffic": pmc_traffic_per_launch(args, B, H, W, "gn_family_bytes_per_launch"),
                                        "launches_per_step": hn / ksteps, "ms_per_step": ht / ksteps * 1e3,
                                        "algorithmic_bytes_per_step": hb / ksteps, "timed_steps": ksteps}
+                ln, lt, lb = timer.loss_summary()
+                if lt > 0:      # the fused Sobel / direction-select / balanced-BCE stencils of the depth-edge loss, 4 scales fwd + bwd
+                    res["roofline_hbm"]["edge_loss_stencils"] = {"achieved": lb / lt / 1e9, "unit": "GB/s", "frac": lb / lt / 1e9 / HBM_PEAK_GBS,
+                                                                  "launches_per_step": ln / ksteps, "ms_per_step": lt / ksteps * 1e3,
+                                                                  "algorithmic_bytes_per_step": lb / ksteps}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W, args.cpu_steps)
         print(json.dumps(res))
