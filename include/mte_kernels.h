@@ -148,6 +148,7 @@ int mte_add_channels(const void* a, long lda, const void* b, long ldb, void* out
 
 /* ---- depth-edge loss: inv2depth + GradLayer + GradLoss('cross_entropy')
  *      (utils/depth.py:104-121; losses/grad_loss.py:20-31,65-95,122-219) */
+long mte_edge_loss_sums_elems(int B, int H, int W);   /* doubles `sums` must hold: B*6 + 4 results, then per-workgroup partial sums */
 int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal, const float* mask, double* sums, float* gmap,
                       int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, mte_stream_t stream);
 int mte_edge_loss_finalize(const double* sums, int B, long numel, float weight, float pos_to_neg, int has_mask,

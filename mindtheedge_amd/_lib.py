@@ -21,7 +21,7 @@ class MteError(RuntimeError):
 RETURNS = {}
 # entry points that return a value (capability / size queries) instead of an error code
 QUERIES = ("mte_conv2d_patch_supported", "mte_conv2d_patch_pack_elems", "mte_depth_metrics_workspace_bytes",
-           "mte_chamfer_workspace_bytes")
+           "mte_chamfer_workspace_bytes", "mte_edge_loss_sums_elems")
 
 
 def parse_header(path=HEADER):

@@ -74,7 +74,7 @@ __device__ __forceinline__ void sobel4(const float* sd, int ly, int lx, float& s
     slr = (n[5] - n[1]) + 2.f * (n[8] - n[0]) + (n[7] - n[3]);
 }
 
-constexpr int FWD_TILES = 8;            // output tiles per block (stacked in y): one set of atomics per 8 tiles
+constexpr int FWD_TILES = 2;            // output tiles per block (stacked in y)
 
 __global__ __launch_bounds__(256) void edge_loss_fwd_kernel(EdgeArgs a) {
     __shared__ float sd[(TY + 2) * (TX + 2)];
@@ -123,15 +123,29 @@ __global__ __launch_bounds__(256) void edge_loss_fwd_kernel(EdgeArgs a) {
         if (lane == 0) sred[wave][i] = s;
     }
     __syncthreads();
-    // every block of an image meets on the same 6 words and every block of the launch on the last 4: device-scope
-    // atomics on one address serialise (~8 ns each), so there is one set per FWD_TILES tiles and none for exact zeros
+    // no atomics: thousands of workgroups adding into the same 6 + 4 words serialise (~8 ns each), so every workgroup stores
+    // its ten partial sums and edge_sums_reduce_kernel adds them up in a fixed order (deterministic as a bonus)
     if (threadIdx.x < 10) {
-        const double s = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
-        if (s != 0.0) {
-            if (threadIdx.x < 6) atomicAdd(&a.sums[(long)b * 6 + threadIdx.x], s);
-            else atomicAdd(&a.sums[(long)a.B * 6 + (threadIdx.x - 6)], s);
-        }
+        const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.sums[(long)a.B * 6 + 4 + blk * 10 + threadIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
     }
+}
+
+// sums[o] for o < 6B: per-image sums of partial k = o % 6; the last 4: mask statistics over the whole launch
+__global__ __launch_bounds__(256) void edge_sums_reduce_kernel(double* __restrict__ sums, int B, int per_image) {
+    __shared__ double sred[4];
+    const int o = blockIdx.x;
+    const double* part = sums + (long)B * 6 + 4;
+    long first, count;
+    int k;
+    if (o < B * 6) { first = (long)(o / 6) * per_image; count = per_image; k = o % 6; }
+    else { first = 0; count = (long)B * per_image; k = 6 + (o - B * 6); }
+    double acc = 0.0;
+    for (long t = threadIdx.x; t < count; t += 256) acc += part[(first + t) * 10 + k];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[o] = sred[0] + sred[1] + sred[2] + sred[3];
 }
 
 // one block: sums -> loss (accumulated into *loss_acc with factor out_scale) and backward coefficients
@@ -285,15 +299,24 @@ __global__ void silog_bwd_kernel(const float* __restrict__ inv, const float* __r
 
 extern "C" {
 
-// Forward pass of one scale.  sums: [B*6 + 4] doubles (zeroed here).  gmap nullable.
+static inline void edge_fwd_grid(int H, int W, int& gx, int& gy) { gx = (W + TX - 1) / TX; gy = ((H + TY - 1) / TY + FWD_TILES - 1) / FWD_TILES; }
+
+// doubles the caller must provide as `sums`: the B*6 + 4 results followed by the per-workgroup partial sums
+long mte_edge_loss_sums_elems(int B, int H, int W) {
+    int gx, gy; edge_fwd_grid(H, W, gx, gy);
+    return (long)B * 6 + 4 + (long)B * gx * gy * 10;
+}
+
+// Forward pass of one scale.  sums: mte_edge_loss_sums_elems(B, H, W) doubles (content on entry ignored).  gmap nullable.
 int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal, const float* mask, double* sums, float* gmap,
                       int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!pred || !edge || !sums) return MTE_ERR_ARG;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * (B * 6 + 4), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     EdgeArgs a{}; a.pred = pred; a.edge = edge; a.normal = normal; a.mask = mask; a.sums = sums; a.gmap = gmap;
     a.B = B; a.H = H; a.W = W; a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.thresh = thresh;
-    hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3((W + TX - 1) / TX, ((H + TY - 1) / TY + FWD_TILES - 1) / FWD_TILES, B), dim3(256), 0, stream, a);
+    int gx, gy; edge_fwd_grid(H, W, gx, gy);
+    hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3(gx, gy, B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(edge_sums_reduce_kernel, dim3(B * 6 + 4), dim3(256), 0, stream, sums, B, gx * gy);
     return mte_check_launch();
 }
 // loss_this (nullable) <- weight * balanced BCE;  *loss_acc (nullable) += out_scale * loss;  coef: [2B + 1] floats

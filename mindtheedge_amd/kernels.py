@@ -1105,7 +1105,7 @@ class EdgeLossFn(torch.autograd.Function):
         normal = None if normal is None else normal.contiguous().float()
         mask = None if mask is None else mask.contiguous().float()
         dev = pred.device
-        sums = torch.empty((B * 6 + 4,), dtype=torch.float64, device=dev)
+        sums = torch.empty((lib.mte_edge_loss_sums_elems(B, H, W),), dtype=torch.float64, device=dev)
         coef = torch.empty((2 * B + 1,), dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         gmap = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_gmap else None
