@@ -1,38 +1,33 @@
-"""BaseModel API of the packnet_sfm model wrapper (reference: packnet_sfm/models/base_model.py:7-97)."""
+"""The small bookkeeping surface every packnet_sfm model exposes to ModelWrapper / the trainer (reference:
+packnet_sfm/models/base_model.py:7-97): which networks a model needs (``network_requirements``), which batch keys
+training needs (``train_requirements``), the batch keys forwarded to the depth network (``_input_keys``), and read-only
+views of the detached ``logs`` / ``losses`` dictionaries."""
 import torch.nn as nn
 
 
+def _read_only(attr):
+    return property(lambda self: getattr(self, attr))
+
+
 class BaseModel(nn.Module):
+    logs = _read_only('_logs')
+    losses = _read_only('_losses')
+    network_requirements = _read_only('_network_requirements')
+    train_requirements = _read_only('_train_requirements')
+
     def __init__(self, **kwargs):
         super().__init__()
-        self._logs = {}
-        self._losses = {}
-        self._network_requirements = []
-        self._train_requirements = []
+        self._logs, self._losses = {}, {}
+        self._network_requirements, self._train_requirements = [], []
         self._input_keys = ['rgb']
-
-    @property
-    def logs(self):
-        return self._logs
-
-    @property
-    def losses(self):
-        return self._losses
 
     def add_loss(self, key, val):
         self._losses[key] = val.detach()
 
-    @property
-    def network_requirements(self):
-        return self._network_requirements
-
-    @property
-    def train_requirements(self):
-        return self._train_requirements
-
     def add_net(self, network_module, network_name):
-        assert network_name in self._network_requirements, "Network module not required!"
+        if network_name not in self._network_requirements:
+            raise AssertionError("Network module not required!")
         setattr(self, network_name, network_module)
 
     def forward(self, batch, return_logs=False, **kwargs):
-        raise NotImplementedError("Please implement forward function in your own subclass model.")
+        raise NotImplementedError("subclasses implement forward(batch)")
