@@ -139,6 +139,7 @@ class PackNetSAN01(nn.Module):
         self.with_san = bool(with_san)
         self.weight = nn.Parameter(torch.ones(5), requires_grad=not freeze_san)
         self.bias = nn.Parameter(torch.zeros(5), requires_grad=not freeze_san)
+        self.weight._mte_flat_tail = self.bias._mte_flat_tail = True     # used only with input_depth: see trainers/data_parallel.py
         self.init_weights()
 
     def init_weights(self):

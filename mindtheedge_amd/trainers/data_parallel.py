@@ -25,12 +25,17 @@ class FlatParameters:
         if not params:
             raise ValueError("no trainable parameters")
         order = list(reversed(params)) if reverse else list(params)
+        # parameters that normally receive no gradient (PackNetSAN01's SAN fusion scalars without a LiDAR input) go to the tail:
+        # in the first bucket they would keep it from ever completing during backward, and its all-reduce would run exposed
+        order = [p for p in order if not getattr(p, '_mte_flat_tail', False)] + [p for p in order if getattr(p, '_mte_flat_tail', False)]
         dev = order[0].device
         offs, total = [], 0
         for p in order:
             offs.append(total)
             total += (p.numel() + align - 1) // align * align
         self.params, self.offsets, self.total, self.reverse = order, offs, total, reverse
+        self.natural_params = params                       # the order the caller gave (torch.optim's state index space)
+        self.offset_of = {id(p): o for p, o in zip(order, offs)}
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, o in zip(order, offs):
@@ -158,8 +163,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _natural(self):
         """(parameter, flat offset) in depth_net.parameters() order -- the index space of torch.optim.Adam's state."""
-        return list(reversed(list(zip(self.flatp.params, self.flatp.offsets)))) if self.flatp.reverse else \
-            list(zip(self.flatp.params, self.flatp.offsets))
+        return [(p, self.flatp.offset_of[id(p)]) for p in self.flatp.natural_params]
 
     def state_dict(self):
         """torch.optim.Adam's layout ({'state': {i: {'step','exp_avg','exp_avg_sq'}}, 'param_groups': [...]}, parameter
