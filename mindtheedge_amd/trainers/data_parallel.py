@@ -65,7 +65,7 @@ class FlatParameters:
 class BucketedAllReduce:
     """Overlapped gradient averaging over a FlatParameters gradient buffer."""
 
-    def __init__(self, flat, process_group=None, bucket_bytes=32 << 20, force=False):
+    def __init__(self, flat, process_group=None, bucket_bytes=32 << 20, force=False, tail_bytes=2 << 20):
         self.flat, self.group = flat, process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []                                   # (start, end, n_tensors)
@@ -78,6 +78,18 @@ class BucketedAllReduce:
             if end - start >= cap or i + 1 == len(flat.params):
                 self.buckets.append((start, end, count))
                 start, count = end, 0
+        # The last bucket (the first layers of the encoder) completes only when backward ends, so its all-reduce is the one
+        # that cannot hide: keep that exposed message small by cutting the final bucket where ~2 MB of gradients remain.
+        if self.buckets and self.buckets[-1][2] > 1:
+            s0, e0, n0 = self.buckets[-1]
+            first = len(flat.params) - n0
+            for j in range(first + 1, len(flat.params)):
+                if (flat.total - flat.offsets[j]) * 4 <= tail_bytes and (flat.offsets[j] - s0) * 4 >= tail_bytes:
+                    self.buckets[-1] = (s0, flat.offsets[j], j - first)
+                    self.buckets.append((flat.offsets[j], e0, n0 - (j - first)))
+                    for p in flat.params[j:]:
+                        self.bucket_of[id(p)] = len(self.buckets) - 1
+                    break
         self._ready = [0] * len(self.buckets)
         self._seen = set()          # a parameter may be announced by both the gradient sink and its autograd hook
         self._works = []
