@@ -1,0 +1,32 @@
+"""GPU (-m gpu): bench.py prints exactly one JSON line on stdout with the keys the driver's contract names (a short run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=580, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job images / max-over-ranks time
+    assert 50 < d["value"] < 2000
+    for name, bound, unit in (("roofline", "mfma", "TFLOP/s"), ("roofline_hbm", "hbm", "GB/s")):
+        o = d[name]
+        assert o["bound"] == bound and o["unit"] == unit and o["peak"] > 0
+        assert abs(o["frac"] - o["achieved"] / o["peak"]) < 1e-9 and 0 < o["frac"] < 1
+        assert o["traffic"] is None or o["traffic"] > 0
