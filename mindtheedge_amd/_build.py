@@ -1,4 +1,5 @@
 """Builds libmte_hip.so (gfx950 only) in-tree with hipcc.  Cross-compiles without a GPU."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -17,11 +18,27 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _digest(paths, extra=""):
+    """Content hash of the inputs of one build product (sources + flags), so that staleness does not depend on
+    file times: a fresh checkout / a pushed snapshot whose objects do not match its sources recompiles."""
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, digest):
+    stamp = target + ".sha256"
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != digest
+
+
+def _stamp(target, digest):
+    with open(target + ".sha256", "w") as f:
+        f.write(digest + "\n")
 
 
 def build(force=False, verbose=False):
@@ -31,8 +48,9 @@ def build(force=False, verbose=False):
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src, hdr]):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+        dig = _digest([src, hdr], " ".join(FLAGS))
+        if force or _stale(obj, dig):
+            jobs.append(([hipcc] + FLAGS + ["-c", src, "-o", obj], obj, dig))
 
     def run(cmd):
         if verbose:
@@ -41,12 +59,19 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
 
+    def compile_one(job):
+        cmd, obj, dig = job
+        run(cmd)
+        _stamp(obj, dig)
+
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            list(ex.map(run, jobs))
+            list(ex.map(compile_one, jobs))
     objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
+    lib_dig = _digest(objs, "link")
+    if force or jobs or _stale(LIB, lib_dig):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        _stamp(LIB, lib_dig)
     return LIB
 
 
