@@ -38,7 +38,8 @@ def main():
     wrapper = ModelWrapper(config).cuda()
     os.makedirs(args.output, exist_ok=True)
     shape = config.datasets.augmentation.image_shape
-    H, W = eval(shape) if isinstance(shape, str) else tuple(shape)
+    import ast
+    H, W = ast.literal_eval(shape) if isinstance(shape, str) else tuple(shape)
     images = []
     for p in args.input:
         a = np.load(p).astype(np.float32)

@@ -185,16 +185,33 @@ class _ZeroArena:
         nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) & ~255
         if nbytes > self.CHUNK // 4:
             return torch.zeros(shape, dtype=dtype, device=device)
+        capturing = torch.cuda.is_current_stream_capturing()
         key = (str(device), torch.cuda.current_stream().cuda_stream)
         c = self.chunks.get(key)
-        if c is None or c[1] + nbytes > self.CHUNK:
-            c = self.chunks[key] = [torch.zeros((self.CHUNK,), dtype=torch.uint8, device=device), 0]
+        # Under HIP-graph capture a chunk must have been created INSIDE the running capture: only then is its one fill a node
+        # of this graph and the buffers are zero again at every replay.  A chunk left over from eager work or from an
+        # earlier capture (same capture stream, other graph) has no fill node here: buffers carved from it would accumulate
+        # on stale statistics from the second replay on.
+        if c is None or c[1] + nbytes > self.CHUNK or (capturing and c[2] != self.capture_id) or (not capturing and c[2] is not None):
+            c = self.chunks[key] = [torch.zeros((self.CHUNK,), dtype=torch.uint8, device=device), 0,
+                                    self.capture_id if capturing else None]
         out = c[0][c[1]:c[1] + nbytes].view(dtype)[:n].view(shape)
         c[1] += nbytes
         return out
 
+    capture_id = 0
+
+    def begin_capture(self):
+        """call right before a HIP-graph capture starts: chunks of earlier captures are never carved again"""
+        self.capture_id += 1
+
 
 _arena = _ZeroArena()
+
+
+def begin_graph_capture():
+    """Library-side state a HIP-graph capture must not inherit (see _ZeroArena.zeros)."""
+    _arena.begin_capture()
 
 
 def _zeros(shape, dtype, device):

@@ -64,9 +64,15 @@ class ModelWrapper(nn.Module):
         self.metrics_keys = ('abs_rel', 'sqr_rel', 'rmse', 'rmse_log', 'a1', 'a2', 'a3')
         self.metrics_modes = ('', '_pp', '_gt', '_pp_gt')
         self.model = setup_model(config, prepared=resume is not None)
+        self._train_dataloader = self._val_dataloaders = None
+        self.trainer = None
         if resume and 'state_dict' in resume:
-            self.load_state_dict(resume['state_dict'])
-            self.current_epoch = resume.get('epoch', 0)
+            # reference :88-94: prefix-stripped, shape-checked, NON-strict (a checkpoint written by the reference always
+            # carries the sparse-branch tensors model.depth_net.mconvs.*, which this network only owns when with_san=True);
+            # 'epoch' is the 0-based index of the epoch that had finished when the file was written -> resume at epoch + 1
+            self.model = load_network(self.model, resume['state_dict'], 'model')
+            if 'epoch' in resume:
+                self.current_epoch = resume['epoch'] + 1
 
     @property
     def depth_net(self):
@@ -84,7 +90,8 @@ class ModelWrapper(nn.Module):
         """Adam over depth_net.parameters() (param group 'Depth') + StepLR, as the reference; the optimizer is the
         fused flat Adam and carries the bucketed RCCL gradient averaging when torch.distributed is initialised."""
         import torch.distributed as dist
-        from ..trainers.data_parallel import FlatParameters, BucketedAllReduce, FusedAdam, broadcast_parameters
+        from ..trainers.data_parallel import (FlatParameters, BucketedAllReduce, FusedAdam, broadcast_parameters,
+                                              reference_parameter_names)
         opt_cfg = self.config.model.optimizer
         if opt_cfg.name != 'Adam' or opt_cfg.depth.get('weight_decay', 0.0) not in (0, 0.0):
             raise NotImplementedError("the shipped configs use Adam without weight decay")
@@ -94,6 +101,7 @@ class ModelWrapper(nn.Module):
             broadcast_parameters(flat, group=process_group)
             reducer = BucketedAllReduce(flat, process_group)
         optimizer = FusedAdam(flat, lr=opt_cfg.depth.lr, reducer=reducer, name='Depth')
+        optimizer.set_index_space(reference_parameter_names(self.depth_net), dict(self.depth_net.named_parameters()))
         sched = getattr(torch.optim.lr_scheduler, self.config.model.scheduler.name)
         scheduler = sched(optimizer, **filter_args(sched, self.config.model.scheduler))
         if self.resume:
@@ -104,6 +112,19 @@ class ModelWrapper(nn.Module):
         self.optimizer, self.scheduler = optimizer, scheduler
         return optimizer, scheduler
 
+    # dataset readers are outside this build's scope: the entry point hands the loaders over and the
+    # trainer asks for them the way the reference's does (trainers/common_trainer.py:66-67)
+    def set_dataloaders(self, train=None, val=None):
+        self._train_dataloader, self._val_dataloaders = train, val
+
+    def train_dataloader(self):
+        if self._train_dataloader is None:
+            raise RuntimeError("no training data: call set_dataloaders(train=...) (train_edges.py --synthetic / --data)")
+        return self._train_dataloader
+
+    def val_dataloader(self):
+        return self._val_dataloaders or []
+
     def training_step(self, batch, *args):
         batch = stack_batch(batch)
         output = self.model(batch, progress=self.progress)
@@ -113,7 +134,8 @@ class ModelWrapper(nn.Module):
     def evaluate_depth(self, batch, args=None):
         """Depth metrics of one validation batch, entirely on the device: prediction, prediction on the mirrored
         input, flip-TTA fusion, and the 7 metrics x 4 modes ('', '_pp', '_gt', '_pp_gt') -- reference :328-352.
-        The metrics stay DEVICE tensors (float32[7]); nothing here synchronises with the host."""
+        The depth metrics stay DEVICE tensors (float32[7]) and never synchronise with the host; the optional edge metrics
+        (batch carries 'edge') read one convergence flag per 8 hysteresis sweeps of the Canny step."""
         inv_depths = self.model(batch)['inv_depths'][0]
         inv_depth = inv_depths[0][:, 0:1, :, :]
         depth = inv2depth(inv_depth)
@@ -150,23 +172,26 @@ class ModelWrapper(nn.Module):
         import torch.distributed as dist
         names = [self.metrics_name + m for m in self.metrics_modes]
         rows = [torch.stack([o[n] for n in names]) for o in output_data_batch if all(n in o for n in names)]
-        if not rows:
-            return {}
-        total = torch.stack(rows).sum(0)
-        count = torch.tensor(float(len(rows)), device=total.device)
+        dev = rows[0].device if rows else (torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else 'cpu')
+        total = torch.stack(rows).sum(0) if rows else torch.zeros((len(names), len(self.metrics_keys)), device=dev)
+        count = torch.tensor(float(len(rows)), device=dev)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(total)
+            dist.all_reduce(total)                           # every rank takes part, also one whose shard was empty
             dist.all_reduce(count)
+        if float(count) == 0.0:
+            return {}
         mean = (total / count).cpu()
         out = {'{}-{}{}'.format(self.metrics_name, key, mode): float(mean[i, j])
                for i, mode in enumerate(self.metrics_modes) for j, key in enumerate(self.metrics_keys)}
         edge_rows = [o['edges'] for o in output_data_batch if 'edges' in o]
-        if edge_rows:                                        # (precision, recall, F1) x the three Canny settings, reference :431-438
-            etotal = torch.stack(edge_rows).sum(0)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if edge_rows or multi:                               # (precision, recall, F1) x the three Canny settings, reference :431-438
+            etotal = torch.stack(edge_rows).double().sum(0) if edge_rows else torch.zeros(9, dtype=torch.float64, device=dev)
             ecount = torch.tensor(float(len(edge_rows)), device=etotal.device, dtype=etotal.dtype)
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if multi:                                        # unconditional: a rank without edge rows must not leave the others waiting
                 dist.all_reduce(etotal)
                 dist.all_reduce(ecount)
+        if (edge_rows or multi) and float(ecount) > 0:
             emean = (etotal / ecount).cpu()
             for k in range(emean.numel() // 3):
                 for j, key in enumerate(('precision', 'recall', 'f1')):

@@ -65,8 +65,15 @@ class FlatParameters:
 class BucketedAllReduce:
     """Overlapped gradient averaging over a FlatParameters gradient buffer."""
 
-    def __init__(self, flat, process_group=None, bucket_bytes=32 << 20, force=False, tail_bytes=2 << 20):
+    def __init__(self, flat, process_group=None, bucket_bytes=32 << 20, force=False, tail_bytes=2 << 20, message_bytes=32 << 20):
         self.flat, self.group = flat, process_group
+        # A bucket never splits a tensor, so the 151 MB pack5.conv weight makes a 182 MB bucket: its all-reduce goes out as
+        # <= message_bytes pieces (xGMI is point-to-point: a ring step moves message/world per link, and 32 MB pieces keep the
+        # pipeline of RCCL's ring busy while letting later, smaller buckets interleave instead of queueing behind one giant
+        # message).  SURVEY.md 7: "bucket must split tensors".
+        self.message_elems = max(1, message_bytes // 4)
+        self.launch_log = []        # per step: (bucket index, first element, elements, messages) in launch order
+        self.exposed_events = None  # (start, end) device events around the wait in finish(): the exposed all-reduce time
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []                                   # (start, end, n_tensors)
         cap = max(1, bucket_bytes // 4)
@@ -110,12 +117,23 @@ class BucketedAllReduce:
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b][2]:
             s, e, _ = self.buckets[b]
-            self._launch(s, e)
+            self._launch(s, e, b)
 
-    def _launch(self, s, e):
-        g = self.flat.grad[s:e]
-        if not g.is_cuda:
-            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+    def _messages(self, s, e):
+        """[start, end) of a bucket cut into all-reduce messages of at most message_elems elements"""
+        out = []
+        while s < e:
+            n = min(self.message_elems, e - s)
+            out.append((s, s + n))
+            s += n
+        return out
+
+    def _launch(self, s, e, b=-1):
+        msgs = self._messages(s, e)
+        self.launch_log.append((b, s, e - s, len(msgs)))
+        if not self.flat.grad.is_cuda:
+            for ms, me in msgs:
+                self._works.append(dist.all_reduce(self.flat.grad[ms:me], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         # The bucket's gradients were produced on the main stream AND on the weight-gradient side stream.  Order the
         # collective after both from a third stream, so that the main stream (the rest of backward) never stalls on
@@ -126,7 +144,8 @@ class BucketedAllReduce:
         self._stream.wait_stream(torch.cuda.current_stream())
         K.side_streams_wait_into(self._stream)
         with torch.cuda.stream(self._stream):
-            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for ms, me in msgs:
+                self._works.append(dist.all_reduce(self.flat.grad[ms:me], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Wait for every launched collective; reduce buckets whose hooks never completed (unused parameters).
@@ -137,12 +156,35 @@ class BucketedAllReduce:
         if self.active:
             for b, (s, e, n) in enumerate(self.buckets):
                 if self._ready[b] != n:
-                    self._launch(s, e)
+                    self._launch(s, e, b)
+            timed = self.flat.grad.is_cuda
+            if timed:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             for w in self._works:
                 w.wait()
-        self._works, self._ready = [], [0] * len(self.buckets)
+            if timed:
+                ev1.record()                                # ev0 -> ev1 on the main stream = time the step waits for RCCL
+                self.exposed_events = (ev0, ev1)
+        self.last_launches = self.launch_log
+        self._works, self._ready, self.launch_log = [], [0] * len(self.buckets), []
         self._seen.clear()
         return 1.0 / self.world
+
+    def exposed_ms(self):
+        """Device time the last finish() spent waiting for outstanding collectives (synchronises)."""
+        if self.exposed_events is None:
+            return 0.0
+        self.exposed_events[1].synchronize()
+        return float(self.exposed_events[0].elapsed_time(self.exposed_events[1]))
+
+    def describe(self):
+        """Static layout + the last step's launch order, for bench.py's JSON line."""
+        return {"buckets_mb": [round((e - s) * 4 / 2**20, 2) for s, e, _ in self.buckets],
+                "message_mb": round(self.message_elems * 4 / 2**20, 2),
+                "messages_per_bucket": [len(self._messages(s, e)) for s, e, _ in self.buckets],
+                "launch_order": [b for b, _, _, _ in getattr(self, "last_launches", [])],
+                "launch_offsets_mb": [round(s * 4 / 2**20, 2) for _, s, _, _ in getattr(self, "last_launches", [])]}
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -173,25 +215,45 @@ class FusedAdam(torch.optim.Optimizer):
         if self.flatp.grad.is_cuda:
             K.prefetch_weight_packs()                       # next step's kernel-ready weight packs, off the critical path
 
-    def _natural(self):
-        """(parameter, flat offset) in depth_net.parameters() order -- the index space of torch.optim.Adam's state."""
-        return [(p, self.flatp.offset_of[id(p)]) for p in self.flatp.natural_params]
+    def set_index_space(self, names, local_names):
+        """Number the optimizer state like the reference's ``torch.optim.Adam(depth_net.parameters())`` does.
+
+        names: every parameter name of the reference network in ``depth_net.parameters()`` order -- frozen tensors and the
+        sparse-branch (``mconvs.*``) tensors included, whether or not this build materialises them (reference
+        models/model_wrapper.py:149-154 passes ALL of depth_net.parameters()).  local_names: {name: parameter} of the
+        tensors that live in the flat buffers.  Without it the state is numbered by position in the flat parameter list."""
+        self._index_names = list(names)
+        self._local = {n: p for n, p in local_names.items() if id(p) in self.flatp.offset_of}
+
+    def _space(self):
+        """[(index-space name or None, parameter or None, flat offset)] in the reference's numbering."""
+        if getattr(self, '_index_names', None) is None:
+            return [(None, p, self.flatp.offset_of[id(p)]) for p in self.flatp.natural_params]
+        out = []
+        for n in self._index_names:
+            p = self._local.get(n)
+            out.append((n, p, self.flatp.offset_of[id(p)] if p is not None else -1))
+        return out
 
     def state_dict(self):
-        """torch.optim.Adam's layout ({'state': {i: {'step','exp_avg','exp_avg_sq'}}, 'param_groups': [...]}, parameter
-        indices in depth_net.parameters() order), so that a checkpoint written here resumes in the reference
-        (models/model_checkpoint.py:71-81 stores optimizer.state_dict()) and vice versa."""
-        nat = self._natural()
+        """torch.optim.Adam's layout ({'state': {i: {'step','exp_avg','exp_avg_sq'}}, 'param_groups': [...]}).  Indices are
+        positions in the reference's ``depth_net.parameters()`` (see set_index_space): 'params' has one entry per reference
+        parameter, state entries exist for the tensors this build trains -- exactly what the reference's own Adam holds, since
+        its sparse-branch tensors never receive a gradient on the RGB-only path and so never get state either
+        (models/model_checkpoint.py:71-81 stores optimizer.state_dict())."""
+        space = self._space()
         state = {}
         if self.steps > 0:
-            for i, (p, o) in enumerate(nat):
+            for i, (_, p, o) in enumerate(space):
+                if p is None:
+                    continue
                 n = p.numel()
                 state[i] = {'step': torch.tensor(float(self.steps)), 'exp_avg': self.exp_avg[o:o + n].view(p.shape).clone(),
                             'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape).clone()}
         g = self.param_groups[0]
         group = {'lr': g['lr'], 'betas': tuple(g['betas']), 'eps': g['eps'], 'weight_decay': 0.0, 'amsgrad': False,
                  'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
-                 'name': g.get('name', 'Depth'), 'params': list(range(len(nat)))}
+                 'name': g.get('name', 'Depth'), 'params': list(range(len(space)))}
         for k in ('initial_lr',):
             if k in g:
                 group[k] = g[k]
@@ -203,20 +265,26 @@ class FusedAdam(torch.optim.Optimizer):
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         else:
-            nat = self._natural()
+            space = self._space()
             groups = sd['param_groups']
             idx = [i for g in groups if g.get('name', 'Depth') == 'Depth' for i in g['params']] or list(groups[0]['params'])
-            if len(idx) != len(nat):
-                raise ValueError("optimizer state holds {} 'Depth' parameters, this network has {}".format(len(idx), len(nat)))
+            if len(idx) != len(space):
+                # a dictionary numbered over the trainable tensors only (earlier builds of this package)
+                trainable = [(n, p, o) for n, p, o in space if p is not None]
+                if len(idx) != len(trainable):
+                    raise ValueError("optimizer state holds {} 'Depth' parameters; this network numbers {} ({} of them trained here)"
+                                     .format(len(idx), len(space), len(trainable)))
+                space = trainable
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
             steps = 0
-            for i, (p, o) in zip(idx, nat):
+            for i, (name, p, o) in zip(idx, space):
                 st = sd['state'].get(i)
-                if st is None:
+                if st is None or p is None:                     # no state yet / a tensor this build does not hold (mconvs.*)
                     continue
                 if tuple(st['exp_avg'].shape) != tuple(p.shape):
-                    raise ValueError("optimizer state {} has shape {}, parameter has {}".format(i, tuple(st['exp_avg'].shape), tuple(p.shape)))
+                    raise ValueError("optimizer state {} ({}) has shape {}, parameter has {}".format(
+                        i, name, tuple(st['exp_avg'].shape), tuple(p.shape)))
                 n = p.numel()
                 self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
                 self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
@@ -224,6 +292,20 @@ class FusedAdam(torch.optim.Optimizer):
             self.steps = steps                                  # torch keeps a step per tensor; they advance together here
         for g, s_ in zip(self.param_groups, sd['param_groups']):
             g.update({k: v for k, v in s_.items() if k in ('lr', 'betas', 'eps', 'initial_lr')})
+
+
+def reference_parameter_names(depth_net):
+    """Parameter names of the REFERENCE PackNetSAN01 in ``parameters()`` order: encoder, decoder, mconvs, weight, bias
+    (networks/depth/PackNetSAN01.py:186-210).  A network built without the sparse branch gets the branch's names from a
+    meta-device instance (no memory), so optimizer indices agree with checkpoints written by the reference."""
+    names = [n for n, _ in depth_net.named_parameters()]
+    if getattr(depth_net, 'with_san', True) or not hasattr(depth_net, 'mconvs'):
+        return names
+    with torch.device('meta'):
+        from ..networks.layers.minkowski_encoder import MinkowskiEncoder
+        branch = ['mconvs.' + n for n, _ in MinkowskiEncoder([32, 64, 128, 256, 512], with_uncertainty=False).named_parameters()]
+    tail = [n for n in names if n in ('weight', 'bias')]
+    return [n for n in names if n not in ('weight', 'bias')] + branch + tail
 
 
 def broadcast_parameters(flat, src=0, group=None):

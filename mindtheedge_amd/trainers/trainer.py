@@ -42,11 +42,18 @@ class Trainer:
     def is_rank_0(self):
         return self.proc_rank == 0
 
-    def fit(self, module, train_dataloader, epochs=None, val_dataloaders=None):
+    def fit(self, module, train_dataloader=None, epochs=None, val_dataloaders=None):
+        """``fit(module)`` as the reference (trainers/common_trainer.py:42-91): the module hands over its optimizer, scheduler
+        and dataloaders (``module.train_dataloader()`` / ``module.val_dataloader()``); the loaders may also be passed in."""
         if self.device is None:
             raise RuntimeError("mindtheedge_amd trains on MI355X GPUs only")
+        module.trainer = self
         module.to(self.device)
         optimizer, scheduler = module.configure_optimizers()
+        if train_dataloader is None:
+            train_dataloader = module.train_dataloader()
+        if val_dataloaders is None:
+            val_dataloaders = module.val_dataloader() if hasattr(module, 'val_dataloader') else None
         history = []
         if val_dataloaders and self.validate_first:
             history.append({'validation': self.validate(val_dataloaders, module)})
@@ -54,13 +61,15 @@ class Trainer:
             if hasattr(getattr(train_dataloader, 'sampler', None), 'set_epoch'):
                 train_dataloader.sampler.set_epoch(epoch)
             history.append(self.train(train_dataloader, module, optimizer))
-            module.current_epoch += 1
-            scheduler.step()
             if val_dataloaders:
                 history[-1]['validation'] = self.validate(val_dataloaders, module)
-            if self.checkpoint and self.is_rank_0:               # the reference's layout, one file per epoch (no top-k policy)
+            # as the reference (:80-91): save BEFORE the epoch counter advances, so 'epoch' in the file is the 0-based index of
+            # the epoch that just finished and a resume continues at epoch + 1 (one file per epoch, no top-k policy)
+            if self.checkpoint and self.is_rank_0:
                 from ..models.model_checkpoint import save_checkpoint
                 save_checkpoint(os.path.join(str(self.checkpoint), 'epoch={}.ckpt'.format(module.current_epoch)), module)
+            module.current_epoch += 1
+            scheduler.step()
         return history
 
     def validate(self, dataloaders, module):

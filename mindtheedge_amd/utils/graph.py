@@ -23,6 +23,7 @@ class GraphedDepth:
                 self.net(self.rgb)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        K.begin_graph_capture()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = self.net(self.rgb)
 

@@ -46,37 +46,58 @@ class _CfgStub(dict):
     __getattr__ = dict.get
 
 
-class _TolerantPickle:
-    """pickle module for torch.load: classes of packages this image lacks (yacs) become plain dict stand-ins, so the
-    tensors of a checkpoint written by the reference can still be read."""
+class _AllowListPickle:
+    """pickle module for torch.load with an ALLOW-LIST unpickler: tensors / storages / plain containers / numpy scalars, and
+    the reference's yacs ``CfgNode`` (its 'config' entry) mapped to a dict stand-in, so yacs is not needed.  Any other
+    global raises UnpicklingError: an untrusted .ckpt cannot name code to run."""
     import pickle as _p
     __name__ = 'pickle'
     load, loads, dump, dumps = _p.load, _p.loads, _p.dump, _p.dumps
     PickleError, UnpicklingError, Pickler = _p.PickleError, _p.UnpicklingError, _p.Pickler
+    _OK = {('collections', 'OrderedDict'), ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_parameter'),
+           ('torch', 'Size'), ('torch', 'device'), ('torch.serialization', '_get_layout'), ('_codecs', 'encode'),
+           ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy', 'dtype'),
+           ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy', 'ndarray'),
+           ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'complex')}
 
     class Unpickler(_p.Unpickler):
         def find_class(self, module, name):
-            try:
+            if module.split('.')[0] == 'yacs' and name == 'CfgNode':
+                return _CfgStub
+            if (module, name) in _AllowListPickle._OK or (module == 'torch' and (name.endswith('Storage') or name in _TORCH_DTYPES)):
                 return super().find_class(module, name)
-            except (ImportError, AttributeError):
-                if module.split('.')[0] in ('yacs',):
-                    return _CfgStub
-                raise
+            raise _AllowListPickle._p.UnpicklingError("checkpoint names the global %s.%s, which is not on the allow-list "
+                                                      "(pass unsafe=True / MTE_UNSAFE_CKPT=1 only for a file you trust)" % (module, name))
 
 
-def read_checkpoint(path):
-    """torch.load of a `.ckpt` written by this package or by the reference (models/model_checkpoint.py:71-81)."""
+_TORCH_DTYPES = ('float32', 'float64', 'float16', 'bfloat16', 'int64', 'int32', 'int16', 'int8', 'uint8', 'bool')
+
+
+def read_checkpoint(path, unsafe=False):
+    """torch.load of a `.ckpt` written by this package or by the reference (models/model_checkpoint.py:71-81).
+
+    First the weights-only unpickler; a file it rejects because of a non-tensor class (the reference's 'config' entry is a
+    yacs CfgNode) is read again through an allow-list unpickler (_AllowListPickle).  Anything else in the file raises, and
+    a truncated / corrupt file is reported, not re-parsed permissively.  ``unsafe=True`` (or MTE_UNSAFE_CKPT=1) opts into
+    the full unpickler."""
+    import os
+    import pickle
     import torch
+    if unsafe or os.environ.get('MTE_UNSAFE_CKPT') == '1':
+        return torch.load(path, map_location='cpu', weights_only=False)
     try:
         return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception:
-        return torch.load(path, map_location='cpu', weights_only=False, pickle_module=_TolerantPickle)
+    except pickle.UnpicklingError:
+        return torch.load(path, map_location='cpu', weights_only=False, pickle_module=_AllowListPickle)
 
 
 def load_network(network, path, prefixes=''):
     """Prefix-stripped, shape-checked, non-strict checkpoint load (reference load.py:117-166)."""
-    ckpt = read_checkpoint(path)
-    sd = ckpt.get('state_dict', ckpt)
+    if isinstance(path, str):
+        ckpt = read_checkpoint(path)
+        sd = ckpt.get('state_dict', ckpt)
+    else:                                        # a state dict (reference :139-140: the resume path passes one)
+        sd = path
     own = network.state_dict()
     picked = {}
     for key, val in sd.items():

@@ -84,3 +84,92 @@ def test_reference_style_checkpoint_with_foreign_config_class(tmp_path):
     load_network(dst, path, ['depth_net', 'disp_network'])
     for k, v in src.state_dict().items():
         assert torch.equal(dst.state_dict()[k], v)
+
+
+def _packnet_cfg(extra=None):
+    from mindtheedge_amd.utils.config import load_config
+    cfg = {"model": {"loss": {"supervised_method": "sparse-silog", "supervised_num_scales": 1, "supervised_loss_weight": 1.0,
+                              "edges_depth_edge_loss_all_scales": True, "flip_lr_prob": 0.0},
+                     "depth_net": {"dropout": 0.0}}}
+    if extra:
+        cfg["model"]["depth_net"].update(extra)
+    return load_config(None, cfg)
+
+
+def test_reference_numbering_of_the_real_network():
+    """The reference's Adam numbers ALL of depth_net.parameters(): encoder, decoder, the 70 sparse-branch tensors, then the
+    two fusion 5-vectors (networks/depth/PackNetSAN01.py:186-210, models/model_wrapper.py:149-154)."""
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.trainers.data_parallel import reference_parameter_names
+    w = ModelWrapper(_packnet_cfg())
+    names = reference_parameter_names(w.depth_net)
+    assert len(names) == 218 + 70 and names[-2:] == ['weight', 'bias']
+    first_branch = next(i for i, n in enumerate(names) if n.startswith('mconvs.'))
+    assert first_branch == 216 and all(n.startswith('mconvs.') for n in names[216:286])
+    assert all(n.startswith('encoder.') or n.startswith('decoder.') for n in names[:216])
+
+
+def test_resume_from_a_reference_written_checkpoint(tmp_path):
+    """A .ckpt as the reference writes it: state_dict with model.depth_net.mconvs.* tensors, 'epoch' = index of the finished
+    epoch, Adam state numbered over all 288 parameters with state only where gradients arrived, a frozen encoder."""
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.trainers.data_parallel import reference_parameter_names
+    src = ModelWrapper(_packnet_cfg())
+    names = reference_parameter_names(src.depth_net)
+    dense = dict(src.depth_net.named_parameters())
+    sd = {'model.depth_net.' + k: v.detach().clone() + 0.25 for k, v in src.depth_net.state_dict().items()}
+    sd['model.depth_net.mconvs.mconvs.0.layer3.0.kernel'] = torch.zeros(25, 1, 64)      # the branch this build does not own
+    state = {}
+    for i, n in enumerate(names):
+        if n in dense and n not in ('weight', 'bias'):
+            state[i] = {'step': torch.tensor(5.0), 'exp_avg': torch.full_like(dense[n], float(i)),
+                        'exp_avg_sq': torch.full_like(dense[n], 2.0 * i)}
+    group = {'lr': 5e-5, 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0.0, 'amsgrad': False, 'name': 'Depth',
+             'params': list(range(len(names)))}
+    ckpt = {'config': {}, 'epoch': 3, 'state_dict': sd, 'optimizer': {'state': state, 'param_groups': [group]}}
+    w = ModelWrapper(_packnet_cfg(), resume=ckpt)                 # non-strict: the mconvs key must not raise
+    assert w.current_epoch == 4
+    got = w.depth_net.state_dict()
+    assert all(torch.equal(got[k], sd['model.depth_net.' + k]) for k in got)
+    w.configure_optimizers()
+    opt = w.optimizer
+    assert opt.steps == 5 and opt.param_groups[0]['lr'] == 5e-5
+    local = dict(w.depth_net.named_parameters())
+    for i, n in enumerate(names):
+        if i in state:
+            p = local[n]
+            o = opt.flatp.offset_of[id(p)]
+            assert float(opt.exp_avg[o]) == float(i) and float(opt.exp_avg_sq[o + p.numel() - 1]) == 2.0 * i, n
+    out = opt.state_dict()
+    assert out['param_groups'][0]['params'] == list(range(288)) and set(out['state']) == set(state) | {286, 287}
+    # a frozen encoder must not shift the numbering (the reference numbers frozen tensors too)
+    wf = ModelWrapper(_packnet_cfg({"freeze_encoder": True}), resume=ckpt)
+    wf.configure_optimizers()
+    dec = next(i for i, n in enumerate(names) if n.startswith('decoder.'))
+    p = dict(wf.depth_net.named_parameters())[names[dec]]
+    assert float(wf.optimizer.exp_avg[wf.optimizer.flatp.offset_of[id(p)]]) == float(dec)
+    assert wf.optimizer.state_dict()['param_groups'][0]['params'] == list(range(288))
+
+
+def test_untrusted_checkpoint_cannot_run_code(tmp_path):
+    """read_checkpoint keeps to an allow-list: a pickle that names an arbitrary callable is refused, a truncated file is an error."""
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % os.path.join(tmp_path, "pwned"),))
+
+    bad = os.path.join(tmp_path, "evil.ckpt")
+    torch.save({"state_dict": {}, "config": Evil()}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        read_checkpoint(bad)
+    assert not os.path.exists(os.path.join(tmp_path, "pwned"))
+    good = os.path.join(tmp_path, "good.ckpt")
+    torch.save({"state_dict": {"w": torch.ones(3)}, "epoch": 2}, good)
+    assert read_checkpoint(good)["epoch"] == 2
+    with open(good, "rb") as f:
+        blob = f.read()
+    with open(bad, "wb") as f:
+        f.write(blob[: len(blob) // 2])
+    with pytest.raises(Exception):
+        read_checkpoint(bad)

@@ -36,18 +36,24 @@ def test_save_resume_roundtrip(tmp_path):
     batch = synthetic_batch(1, 64, 128, seed=5, device=torch.device("cuda", 0))
     for _ in range(2):
         _step(a, batch)
+    # the reference writes the file when epoch 0 has finished, BEFORE the counter and the scheduler advance
+    # (trainers/common_trainer.py:80-91): 'epoch' = 0, and a resume continues at epoch 1
+    a.current_epoch = 0
+    path = save_checkpoint(os.path.join(tmp_path, "run", "epoch=0.ckpt"), a)
+    a.current_epoch += 1
     a.scheduler.step()
-    a.current_epoch = 1
-    path = save_checkpoint(os.path.join(tmp_path, "run", "epoch=1.ckpt"), a)
     ckpt = load_checkpoint(path)
     assert set(ckpt) == {"config", "epoch", "state_dict", "optimizer", "scheduler"}
     assert all(k.startswith("model.depth_net.") for k in ckpt["state_dict"]) and len(ckpt["state_dict"]) == 218
     assert set(ckpt["optimizer"]) == {"state", "param_groups"} and len(ckpt["optimizer"]["state"]) == 218
-    assert ckpt["optimizer"]["param_groups"][0]["name"] == "Depth"
+    assert ckpt["optimizer"]["param_groups"][0]["name"] == "Depth" and ckpt["epoch"] == 0
+    # indices are the reference's depth_net.parameters() numbering: 216 dense + 70 sparse-branch slots + weight, bias
+    assert len(ckpt["optimizer"]["param_groups"][0]["params"]) == 218 + 70
 
     b = _wrapper(resume=ckpt)
     b.train()
     assert b.current_epoch == 1 and b.optimizer.steps == 2
+    b.scheduler.step()                                   # the trainer's scheduler step of the finished epoch
     assert b.optimizer.param_groups[0]["lr"] == a.optimizer.param_groups[0]["lr"] == 0.0002 * 0.5
     sa, sb = a.state_dict(), b.state_dict()
     assert all(torch.equal(sa[k], sb[k]) for k in sa)

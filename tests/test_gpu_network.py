@@ -258,3 +258,29 @@ def test_graph_replay_of_the_inference_forward():
             GraphedDepth(net, a)
     finally:
         K.set_compute_dtype("bf16")
+
+
+def test_second_graph_capture_does_not_reuse_stale_zero_buffers():
+    """Two shapes captured in turn (infer_edges.py --graph sees a new frame size): GroupNorm statistics buffers of the second
+    graph must be re-zeroed by ITS replays -- several replays of each graph against the eager forward."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.utils.graph import GraphedDepth
+    net = _net("fp32")
+    try:
+        net.eval()
+        g = torch.Generator().manual_seed(3)
+        frames = {(64, 128): [torch.rand(1, 3, 64, 128, generator=g).cuda() for _ in range(3)],
+                  (96, 160): [torch.rand(1, 3, 96, 160, generator=g).cuda() for _ in range(3)]}
+        graphs = {}
+        for shape, fs in frames.items():                       # capture 1, then capture 2 on the same capture stream
+            graphs[shape] = GraphedDepth(net, fs[0])
+        for rnd in range(2):
+            for shape, fs in frames.items():
+                for f in fs:                                   # >= 2 replays per graph: stale statistics would pile up
+                    got = [t.float().clone() for t in graphs[shape](f)["inv_depths"][0]]
+                    with torch.no_grad():
+                        want = net(f)["inv_depths"][0]
+                    for s in range(4):
+                        assert rel_err(got[s].cpu(), want[s].float().cpu()) < 1e-4, (rnd, shape, s)
+    finally:
+        K.set_compute_dtype("bf16")

@@ -30,21 +30,26 @@ def main():
     from mindtheedge_amd.trainers.trainer import Trainer
     from mindtheedge_amd.utils.synthetic import SyntheticLoader
     config = load_config(args.file)
-    config.model.depth_net.checkpoint_path = config.model.depth_net.checkpoint_path if os.path.exists(
-        config.model.depth_net.checkpoint_path or '') else ''
+    if config.model.depth_net.checkpoint_path and not os.path.exists(config.model.depth_net.checkpoint_path):
+        print('WARNING: depth_net.checkpoint_path %r does not exist -- training from the xavier initialisation'
+              % config.model.depth_net.checkpoint_path, file=sys.stderr)
+        config.model.depth_net.checkpoint_path = ''
     from mindtheedge_amd.models.model_checkpoint import load_checkpoint
     save_dir = args.save or (os.path.dirname(config.checkpoint.filepath) if config.checkpoint.filepath else None)
     trainer = Trainer(**{**config.arch, 'checkpoint': save_dir})
     wrapper = ModelWrapper(config, resume=load_checkpoint(args.resume) if args.resume else None)
+    import ast
     H, W = tuple(config.datasets.augmentation.image_shape) if not isinstance(config.datasets.augmentation.image_shape, str) \
-        else eval(config.datasets.augmentation.image_shape)
+        else ast.literal_eval(config.datasets.augmentation.image_shape)
     if args.data:
         mod, fn = args.data.split(':')
         loader = getattr(importlib.import_module(mod), fn)(config, trainer.proc_rank, trainer.world_size)
     else:
         assert args.synthetic, 'no dataset: pass --synthetic or --data module:callable'
         loader = SyntheticLoader(config.datasets.train.batch_size, H, W, args.steps, trainer.device, trainer.proc_rank)
-    hist = trainer.fit(wrapper, loader, epochs=args.epochs)
+    wrapper.set_dataloaders(train=loader)
+    trainer.max_epochs = wrapper.current_epoch + args.epochs
+    hist = trainer.fit(wrapper)
     if trainer.is_rank_0:
         print(hist)
 
