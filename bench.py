@@ -62,7 +62,7 @@ class ConvTimer:
         for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd"):
             self._orig[name] = getattr(lib, name)
         self.loss_records = []          # the fused depth-edge loss stencils ("reported as HBM GB/s vs 8.0 TB/s")
-        for name in ("mte_edge_loss_fwd", "mte_edge_loss_bwd"):
+        for name in ("mte_edge_loss_fwd", "mte_edge_loss_bwd", "mte_edge_loss_multi_fwd", "mte_edge_loss_multi_bwd"):
             self._orig[name] = getattr(lib, name)
 
     def install(self):
@@ -81,6 +81,18 @@ class ConvTimer:
                     e0.record()
                     fn(*args)
                     e1.record()
+                    if name.startswith("mte_edge_loss_multi_"):
+                        # (scales, nscales, B, ...): ONE launch for all scales; fwd reads pred + edge + normal (12 B/px), bwd the same +
+                        # the gradient write (16 B/px); the fused silog adds the ground-truth depth read of scale 0 (4 B/px)
+                        import ctypes as _ct
+                        S_, B_ = args[1], args[2]
+                        sc_ = (outer.K._EdgeScale * S_).from_address(args[0])
+                        fwd_ = name.endswith("_fwd")
+                        px_ = sum(B_ * s_.H * s_.W for s_ in sc_)
+                        maps_ = 2 + bool(sc_[0].normal) + bool(sc_[0].mask) + (0 if fwd_ else 1)
+                        gt_ = args[9] if fwd_ else args[10]
+                        outer.loss_records.append((name, e0, e1, 4.0 * maps_ * px_ + (4.0 * B_ * sc_[0].H * sc_[0].W if gt_ else 0.0)))
+                        return
                     if name.startswith("mte_edge_loss_"):
                         # fwd (pred, edge, normal, mask, sums, gmap, B, H, W, ...): reads pred + edge (+ normal, + mask) = 4 B each;
                         # bwd (pred, edge, normal, mask, coef, gout, dpred, B, H, W, ...): the same reads + 4 B gradient write
@@ -94,8 +106,8 @@ class ConvTimer:
                         if name == "mte_gn_stats":          # (y1, ld1, y2, ld2, scale2, stats, B, HW, C, dtype, stream)
                             has2, (B_, HW_, C_, dt_) = bool(args[2]), args[6:10]
                             tensors = 1 + has2                                  # read y1 (+ y2)
-                        elif name == "mte_gn_elu_fwd":      # (y1, ld1, y2, ld2, scale2, stats, gamma, beta, z, ldz, B, HW, C, eps, dtype, stream)
-                            has2, (B_, HW_, C_), dt_ = bool(args[2]), args[10:13], args[14]
+                        elif name == "mte_gn_elu_fwd":      # (y1, ld1, y2, ld2, scale2, stats, stats_ready, gamma, beta, z, ldz, B, HW, C, eps, dtype, stream)
+                            has2, (B_, HW_, C_), dt_ = bool(args[2]), args[11:14], args[15]
                             tensors = 1 + has2 + 1                              # read y1 (+ y2), write z
                         else:                               # (dz, lddz, y1, ld1, y2, ld2, scale2, stats, gamma, beta, red, d1, ldd1, d2, ldd2, ..., B, HW, C, eps, dtype, stream)
                             has2, hasd2, (B_, HW_, C_), dt_ = bool(args[4]), bool(args[13]), args[18:21], args[22]
@@ -270,13 +282,30 @@ def main():
         reducer = BucketedAllReduce(flat, force=True) if dist_on else None
         opt = FusedAdam(flat, lr=1e-4, reducer=reducer)
 
-        def step():
+        def eager_step():
             opt.zero_grad()
             out = model(batch)
             out["loss"].backward()
             opt.step()
             return out["loss"]
+        step, launch_mode = eager_step, "eager"
+        if dist_on:
+            launch_mode = "eager (bucketed RCCL all-reduce is issued from grad-ready callbacks)"
+        elif os.environ.get("MTE_BENCH_EAGER"):
+            launch_mode = "eager (MTE_BENCH_EAGER)"
+        else:
+            # the whole step (zero_grad + forward + loss + backward + Adam + weight-pack prefetch, ~1000 launches) replayed from
+            # two HIP graphs, one per outcome of the host-side flip draw; falls back to the eager step in this process
+            from mindtheedge_amd.utils.graph import GraphedTrainStep
+            graphed = GraphedTrainStep(model, opt, batch)
+            if graphed.graphed:
+                step, launch_mode = (lambda: graphed()["loss"]), "hip_graph"
+            else:
+                launch_mode = "eager (capture failed: %s)" % graphed.error
+                print("bench.py: HIP-graph capture of the training step failed, running eagerly: %s" % graphed.error, file=sys.stderr)
     else:
+        launch_mode = "eager"
+        eager_step = None
         model.eval()
 
         def step():
@@ -306,10 +335,11 @@ def main():
         # event pair measures contention, not the kernel
         K.use_wgrad_side_stream(False)
         ksteps = min(args.steps, 3)
+        kstep = eager_step if eager_step is not None else step      # launch by launch: the event pairs need the eager path
         for family in ("conv", "hbm"):           # separate steps per family: the event pairs of one must not space out the other
             timer.enabled = family
             for _ in range(ksteps):
-                step()
+                kstep()
             sync()
         timer.enabled = False
         K.use_wgrad_side_stream(not os.environ.get("MTE_NO_SIDE_STREAM"))
@@ -332,7 +362,7 @@ def main():
                           "global_batch": B * world, "height": H, "width": W,
                           "parallelism": "dp%d (bucketed RCCL all-reduce overlapped with backward)" % world if world > 1 else "single GPU"},
                "final_loss" if args.mode == "train" else "mean_inv_depth": final,
-               "host_enqueue_ms_per_step": host_dt / args.steps * 1e3}
+               "host_enqueue_ms_per_step": host_dt / args.steps * 1e3, "step_launch": launch_mode}
         passes = 3.0 if args.mode == "train" else 1.0
         step_flops = conv_flops_per_image(H, W) * B * passes
         res["mfma_fraction_of_step"] = step_flops / (ms * 1e-3) / (BF16_DENSE_PEAK_TFLOPS * 1e12)

@@ -55,7 +55,9 @@ int mte_set_option(int option, int value);
  *   2 / 3 GroupNorm launch geometry (min rows per thread / target workgroups)
  *   4 wgrad kernel (1 LDS-DMA ring [default], 0 register-staged)      6 igemm tiles (0 128x128, 1 + 256x128, 2 + 256x256, 3 + 192x96 [default])
  *   7 min tiles for the big igemm tiles (224)   8 wgrad 8/16-wave tiles (1)   9 wgrad workgroup target (512)
- *   11 patch conv: 0/1 tall 16x32 tiles, >= 100 = workgroup target of the patch wgrad (512) */
+ *   11 patch conv: 0/1 tall 16x32 tiles, >= 100 = workgroup target of the patch wgrad (512)
+ *   13 GroupNorm single-pass slab kernels (1 [default], 0 = streaming kernels only)
+ *   14 GroupNorm second passes walk the samples in reverse order (Infinity-Cache reuse; 1 [default]) */
 int mte_debug_set(int key, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
  * pixels is split over workgroups; when their number fits stage_parts each one stores its PARTIAL gradient in its own part
@@ -91,7 +93,14 @@ int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, f
 #define MTE_GN_REP 16
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
                  int B, int HW, int C, int dtype, mte_stream_t stream);
-int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, const double* stats,
+/* mte_gn_elu_fwd: stats_ready = 1: `stats` holds the sums of mte_gn_stats (or of a conv epilogue).  stats_ready = 0 (allowed where
+ * mte_gn_fwd_is_single_pass(HW, C, y2 != NULL, dtype) returns 1: a (sample, group) slab fits one workgroup's registers): the
+ * kernel loads each slab ONCE, computes its statistics on chip, normalises and stores `stats` in the same format as an
+ * OUTPUT for the backward pass -- the forward is then one read + one write, and mte_gn_stats is not called.
+ * mte_gn_elu_bwd takes the matching one-pass route by itself where the slab of (y, dz) fits (low-resolution layers).
+ * development knob 13 (mte_debug_set): 0 = streaming two-pass kernels everywhere. */
+int mte_gn_fwd_is_single_pass(int HW, int C, int has_y2, int dtype);
+int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats, int stats_ready,
                    const float* gamma, const float* beta, void* z, long ldz,
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
 int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
@@ -148,7 +157,26 @@ int mte_add_channels(const void* a, long lda, const void* b, long ldb, void* out
 
 /* ---- depth-edge loss: inv2depth + GradLayer + GradLoss('cross_entropy')
  *      (utils/depth.py:104-121; losses/grad_loss.py:20-31,65-95,122-219) */
-long mte_edge_loss_sums_elems(int B, int H, int W);   /* doubles `sums` must hold: B*6 + 4 results, then per-workgroup partial sums */
+/* All scales of SemiSupEdgeModel.compute_edge_loss_with_all_scales (models/SemiSupEdgeModel.py:164-198) in ONE forward and ONE
+ * backward launch, optionally with the silog loss of scale 0 (models/SemiSupEdgeModel.py:144; losses/supervised_loss.py:57-69,
+ * 155-216) fused in -- it reads the same full-resolution inverse depth.  Workgroup = 64x32-pixel tile of one (scale, sample); the
+ * last workgroup to arrive adds the per-workgroup partial sums in a fixed order and computes alpha, the loss scalars and the
+ * backward coefficients on the device (no reduce / finalize launches, no host sync, deterministic sums).
+ *   scales : HOST array of nscales (<= 4) records; every map is fp32 [B,H,W]; normal / mask / gmap nullable; dpred = backward output
+ *   work   : mte_edge_loss_work_elems() doubles (content on entry ignored)
+ *   losses [nscales] <- weight * balanced BCE per scale;  coef [nscales][2B+1] <- backward coefficients
+ *   gt_depth (nullable; metric depth, 0 = invalid, at the size of scale 0): fused silog -> silog_loss[1], silog_aux[2]
+ *   backward: dpred_s <- gout[s] * d loss_s / d pred_s  (+ silog_gout[0] * d silog / d pred_0); gout / silog_gout: device, nullable = 1 */
+typedef struct { const float* pred; const float* edge; const float* normal; const float* mask; float* gmap; float* dpred; int H; int W; } mte_edge_scale;
+long mte_edge_loss_work_elems(const void* scales, int nscales, int B);
+int mte_edge_loss_multi_fwd(const void* scales, int nscales, int B, int from_inv, int is_grad, int is_sigmoid, float thresh,
+                            float weight, float pos_to_neg, const float* gt_depth, double* work, float* losses, float* coef,
+                            float* silog_loss, float* silog_aux, mte_stream_t stream);
+int mte_edge_loss_multi_bwd(const void* scales, int nscales, int B, int from_inv, int is_grad, int is_sigmoid, float thresh,
+                            const float* coef, const float* gout, const float* gt_depth, const float* silog_aux, const float* silog_gout,
+                            mte_stream_t stream);
+/* single-scale entry points (GradLoss / GradLayer called on their own): the same kernels with one scale */
+long mte_edge_loss_sums_elems(int B, int H, int W);   /* doubles `sums` must hold: B*6 + 4 results, the arrival ticket, the per-workgroup partial sums */
 int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal, const float* mask, double* sums, float* gmap,
                       int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, mte_stream_t stream);
 int mte_edge_loss_finalize(const double* sums, int B, long numel, float weight, float pos_to_neg, int has_mask,
@@ -163,6 +191,10 @@ int mte_silog_bwd(const float* inv, const float* depth, const float* aux, const 
 /* ---- optimizer: torch.optim.Adam step over a flat fp32 buffer (models/model_wrapper.py:142-180; trainers/common_trainer.py:125) */
 int mte_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   int step, float gscale, mte_stream_t stream);
+/* the same update with hyper = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read from DEVICE memory: no per-step host scalar in the launch,
+ * so the training step can be replayed from a HIP graph (utils/graph.py::GraphedTrainStep) */
+int mte_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2, float eps,
+                      float gscale, mte_stream_t stream);
 
 /* ---- validation depth metrics: fp32 [B,1,H,W] maps, no host synchronisation
  * mte_post_process_inv_depth = post_process_inv_depth (utils/depth.py:230-256); method 0 'mean', 1 'max', 2 'min'

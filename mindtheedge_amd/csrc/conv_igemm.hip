@@ -1177,6 +1177,8 @@ int mte_debug_set(int key, int value) {
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
     if (key == 1) return mtei_set_pack3d_lds(value);
     if (key == 2 || key == 3) return mtei_set_gn(key - 2, value);
+    if (key == 13) return mtei_set_gn(2, value);
+    if (key == 14) return mtei_set_gn(3, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
     if (key == 8) { g_wgrad_big = value; return MTE_OK; }

@@ -287,6 +287,33 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// the same update with lr / bias corrections read from device memory (hyper = {lr, 1 - b1^t, sqrt(1 - b2^t)}): the launch carries no
+// per-step host scalar, so it can be replayed from a HIP graph while the host refreshes `hyper` before each replay
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long n, const float* __restrict__ hyper, float b1, float b2, float eps, float gscale) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2];
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4_t pp = ((f32x4_t*)p)[i], gg = ((const f32x4_t*)g)[i], mm = ((f32x4_t*)m)[i], vv = ((f32x4_t*)v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gscale;
+            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) / bc2s + eps;
+            pp[k] -= (lr / bc1) * (mm[k] / denom);
+        }
+        ((f32x4_t*)p)[i] = pp; ((f32x4_t*)m)[i] = mm; ((f32x4_t*)v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float gk = g[i] * gscale;
+        const float mk = b1 * m[i] + (1.f - b1) * gk, vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        m[i] = mk; v[i] = vk;
+        p[i] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2s + eps));
+    }
+}
+
 inline int stream_grid(long n, int per = 256) { long g = (n + per - 1) / per; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 inline bool head_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <= 64 && (cb & (cb - 1)) == 0; }
 
@@ -395,6 +422,16 @@ int mte_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        (float)bc1, (float)sqrt(bc2), gscale);
+    return mte_check_launch();
+}
+
+// The same step with {lr, 1 - beta1^t, sqrt(1 - beta2^t)} in DEVICE memory (`hyper`, 3 floats written by the caller before the
+// launch): nothing in the launch changes from step to step, so a captured HIP graph of the training step stays valid.
+int mte_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2, float eps,
+                      float gscale, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!p || !g || !m || !v || !hyper || n <= 0) return MTE_ERR_ARG;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps, gscale);
     return mte_check_launch();
 }
 

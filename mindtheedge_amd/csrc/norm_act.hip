@@ -5,11 +5,21 @@
 //   residual tail ELU(GN(x_out + Dropout2d(conv1x1(x)))) of ResidualConv (layers01.py:62-73); scale2 is
 //   the per-(sample, channel) Dropout2d factor keep/(1-p) (null = no second input scaling).
 //
-// All kernels are HBM-bound streams: a thread owns one 16-byte channel chunk (8 bf16 / 4 f32 channels)
-// and walks pixels, so every wave instruction moves 1 KiB of contiguous NHWC bytes; statistics
-// accumulate in fp32 per thread, are combined per block through LDS and leave the block as one
-// double-precision atomic per (sample, group) -- GroupNorm statistics are per sample, so there is no
-// cross-GPU reduction anywhere in this file.
+// Two families, both HBM-bound by construction (GroupNorm statistics are per sample, so there is no cross-GPU
+// reduction anywhere in this file):
+//
+// * SLAB kernels (the lowest-resolution layers, 512 channels at 12x40; see GN_SLAB_MAX):
+//   one workgroup owns one (sample, group) slab -- HW pixels x C/16 channels, 30-240 KB -- loads it ONCE into
+//   registers, reduces on chip and writes the result: the forward is 1 read + 1 write instead of stats pass + apply
+//   pass (2 reads + 1 write), the backward 2 reads + 1 write instead of reduce pass + apply pass (4 reads + 1 write),
+//   with no global atomics on the data path.  The 16 group-workgroups of a sample are mapped to ONE XCD, so the
+//   128-byte lines that neighbouring groups share are fetched into one L2.
+// * STREAM kernels (everything larger): a thread owns one 16-byte channel chunk (8 bf16 / 4 f32 channels) and walks
+//   pixels, so every wave instruction moves 1 KiB of contiguous NHWC bytes; statistics accumulate in fp32 per
+//   thread, are combined per block through LDS and leave the block as one double-precision atomic per
+//   (sample, group).  The per-channel arithmetic is folded into affine constants (u = v*ka + kb for the ELU
+//   argument, dv = dyh*ka - (c0 + v*c1) for the backward) and every optional input is a template flag: the
+//   backward apply kernel went from 208 to <100 VGPRs (2 -> 5 waves per SIMD), which is what an HBM stream needs.
 #include "common.hpp"
 
 int g_mte_gn_prezeroed = 0;
@@ -30,10 +40,12 @@ struct GnArgs {
     void* d1; long ldd1;               // backward outputs
     void* d2; long ldd2;
     float* dbias;                      // optional [C]: per-channel sum of d1 (= gradient of the conv bias in front of the norm)
-    float* dgamma; float* dbeta;       // [C], written by block (0, 0) of the apply pass
+    float* dgamma; float* dbeta;       // [C]
     int B, HW, C;
     float eps;
     int blocks_per_sample;
+    int cps_shift;                     // slab kernels: log2(chunks per pixel inside one group)
+    int reverse;                       // stream kernels: walk the samples last-to-first (see gn_zigzag)
 };
 
 // Pixel rows are processed in batches of GN_U: all 16-byte loads of a batch are issued before any of its stores, so a
@@ -41,19 +53,21 @@ struct GnArgs {
 // otherwise serialises load -> store -> load and leaves these streams latency-bound).
 constexpr int GN_U = 4;
 
-template <typename T> struct RawRow { u32x4_t c1, c2; };
+template <bool HAS2> struct RawRow;
+template <> struct RawRow<false> { u32x4_t c1; };
+template <> struct RawRow<true> { u32x4_t c1, c2; };
 
-template <typename T>
-__device__ __forceinline__ void load_raw(const GnArgs& a, long pix, int ch0, RawRow<T>& r) {
+template <typename T, bool HAS2>
+__device__ __forceinline__ void load_raw(const GnArgs& a, long pix, int ch0, RawRow<HAS2>& r) {
     r.c1 = *(const u32x4_t*)((const T*)a.y1 + pix * a.ld1 + ch0);
-    if (a.y2) r.c2 = *(const u32x4_t*)((const T*)a.y2 + pix * a.ld2 + ch0);
+    if constexpr (HAS2) r.c2 = *(const u32x4_t*)((const T*)a.y2 + pix * a.ld2 + ch0);
 }
 // v = y1 + sc * y2 (sc = Dropout2d factor of this sample's channels, 1 when absent)
-template <typename T>
-__device__ __forceinline__ void finish_v(const GnArgs& a, const RawRow<T>& r, const float* sc, float* v) {
+template <typename T, bool HAS2>
+__device__ __forceinline__ void finish_v(const RawRow<HAS2>& r, const float* sc, float* v) {
     constexpr int P = Elem<T>::PER16;
     unpack16<T>(r.c1, v);
-    if (a.y2) {
+    if constexpr (HAS2) {
         float w[P];
         unpack16<T>(r.c2, w);
 #pragma unroll
@@ -63,22 +77,32 @@ __device__ __forceinline__ void finish_v(const GnArgs& a, const RawRow<T>& r, co
 template <typename T>
 __device__ __forceinline__ void load_scale2(const GnArgs& a, int b, int ch0, float* sc) {
 #pragma unroll
-    for (int i = 0; i < Elem<T>::PER16; ++i) sc[i] = (a.y2 && a.scale2) ? a.scale2[(long)b * a.C + ch0 + i] : 1.f;
+    for (int i = 0; i < Elem<T>::PER16; ++i) sc[i] = a.scale2 ? a.scale2[(long)b * a.C + ch0 + i] : 1.f;
+}
+__device__ __forceinline__ float elu_grad(float u) { return u > 0.f ? 1.f : __expf(u); }
+// The slab kernels sweep their register-resident chunks several times.  Without this the compiler keeps the UNPACKED floats
+// of the first sweep alive for the later ones (2x the registers of the packed chunks -> scratch spills at 1024 threads).
+template <bool HAS2> __device__ __forceinline__ void keep_packed(RawRow<HAS2>& r) {
+    asm volatile("" : "+v"(r.c1));
+    if constexpr (HAS2) asm volatile("" : "+v"(r.c2));
 }
 
+// =====================================================================================================================
+// STREAM kernels
+// =====================================================================================================================
 // thread -> (chunk column cc, pixel lane prow); block -> (pixel range of one sample)
 #define GN_THREAD_MAP()                                                            \
     constexpr int P = Elem<T>::PER16;                                              \
     const int cpr = a.C / P;                                                       \
     const int cc = threadIdx.x % cpr, prow = threadIdx.x / cpr, rstep = 256 / cpr; \
-    const int b = blockIdx.y;                                                      \
+    const int b = a.reverse ? a.B - 1 - (int)blockIdx.y : (int)blockIdx.y;         \
     const int ch0 = cc * P;                                                        \
     const int per_blk = (a.HW + a.blocks_per_sample - 1) / a.blocks_per_sample;    \
     const int p_begin = blockIdx.x * per_blk;                                      \
     const int p_end = min(a.HW, p_begin + per_blk);                                \
     const int gs = a.C / GN_GROUPS;
 
-template <typename T>
+template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
     GN_THREAD_MAP();
     __shared__ float s_acc[GN_GROUPS * 2];
@@ -88,17 +112,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
 #pragma unroll
     for (int i = 0; i < P; ++i) { s[i] = 0.f; q[i] = 0.f; }
     float sc[P];
-    load_scale2<T>(a, b, ch0, sc);
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
     for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
-        RawRow<T> raw[GN_U];
+        RawRow<HAS2> raw[GN_U];
 #pragma unroll
         for (int u = 0; u < GN_U; ++u)
-            if (p + u * rstep < p_end) load_raw<T>(a, (long)b * a.HW + p + u * rstep, ch0, raw[u]);
+            if (p + u * rstep < p_end) load_raw<T, HAS2>(a, (long)b * a.HW + p + u * rstep, ch0, raw[u]);
 #pragma unroll
         for (int u = 0; u < GN_U; ++u) {
             if (p + u * rstep >= p_end) break;
             float v[P];
-            finish_v<T>(a, raw[u], sc, v);
+            finish_v<T, HAS2>(raw[u], sc, v);
 #pragma unroll
             for (int i = 0; i < P; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
         }
@@ -143,7 +167,7 @@ __device__ __forceinline__ void block_group_stats(const GnArgs& a, int b, int gs
     __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void gn_elu_fwd_kernel(GnArgs a) {
     GN_THREAD_MAP();
     __shared__ float s_mr[GN_GROUPS * 2];
@@ -158,17 +182,17 @@ __global__ __launch_bounds__(256) void gn_elu_fwd_kernel(GnArgs a) {
         kb[i] = a.beta[ch0 + i] - mean * rstd * gm;
     }
     float sc[P];
-    load_scale2<T>(a, b, ch0, sc);
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
     for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
-        RawRow<T> raw[GN_U];
+        RawRow<HAS2> raw[GN_U];
 #pragma unroll
         for (int u = 0; u < GN_U; ++u)
-            if (p + u * rstep < p_end) load_raw<T>(a, (long)b * a.HW + p + u * rstep, ch0, raw[u]);
+            if (p + u * rstep < p_end) load_raw<T, HAS2>(a, (long)b * a.HW + p + u * rstep, ch0, raw[u]);
 #pragma unroll
         for (int u = 0; u < GN_U; ++u) {
             if (p + u * rstep >= p_end) break;
             float v[P];
-            finish_v<T>(a, raw[u], sc, v);
+            finish_v<T, HAS2>(raw[u], sc, v);
 #pragma unroll
             for (int i = 0; i < P; ++i) v[i] = elu1(fmaf(v[i], ka[i], kb[i]));
             *(u32x4_t*)((T*)a.z + ((long)b * a.HW + p + u * rstep) * a.ldz + ch0) = pack16<T>(v);
@@ -176,45 +200,46 @@ __global__ __launch_bounds__(256) void gn_elu_fwd_kernel(GnArgs a) {
     }
 }
 
-// pass 1 of the backward: red[b][c] = (sum_px dyhat, sum_px dyhat * xhat), dyhat = dz * elu'(u)
-template <typename T>
+// pass 1 of the backward: red[b][c] = (sum_px dyhat, sum_px dyhat * xhat), dyhat = dz * elu'(u), u = v*ka + kb,
+// xhat = v*xa + xb (xa = rstd, xb = -mean*rstd of the channel's group)
+template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
     GN_THREAD_MAP();
     extern __shared__ float s_red[];                      // [C][2]
     __shared__ float s_mr[GN_GROUPS * 2];
     for (int i = threadIdx.x; i < a.C * 2; i += 256) s_red[i] = 0.f;
     block_group_stats(a, b, gs, s_mr);
-    float mean[P], rstd[P], gm[P], bt[P], r1[P], r2[P];
+    float ka[P], kb[P], xa[P], xb[P], r1[P], r2[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        mean[i] = s_mr[2 * ((ch0 + i) / gs)]; rstd[i] = s_mr[2 * ((ch0 + i) / gs) + 1];
-        gm[i] = a.gamma[ch0 + i]; bt[i] = a.beta[ch0 + i];
+        const float mean = s_mr[2 * ((ch0 + i) / gs)], rstd = s_mr[2 * ((ch0 + i) / gs) + 1];
+        const float gm = a.gamma[ch0 + i];
+        xa[i] = rstd; xb[i] = -mean * rstd;
+        ka[i] = rstd * gm; kb[i] = a.beta[ch0 + i] - mean * rstd * gm;
         r1[i] = 0.f; r2[i] = 0.f;
     }
     float sc[P];
-    load_scale2<T>(a, b, ch0, sc);
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
     for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
-        RawRow<T> raw[GN_U];
+        RawRow<HAS2> raw[GN_U];
         u32x4_t gr[GN_U];
 #pragma unroll
         for (int u = 0; u < GN_U; ++u)
             if (p + u * rstep < p_end) {
                 const long pix = (long)b * a.HW + p + u * rstep;
-                load_raw<T>(a, pix, ch0, raw[u]);
+                load_raw<T, HAS2>(a, pix, ch0, raw[u]);
                 gr[u] = *(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0);
             }
 #pragma unroll
         for (int u = 0; u < GN_U; ++u) {
             if (p + u * rstep >= p_end) break;
             float v[P], g[P];
-            finish_v<T>(a, raw[u], sc, v);
+            finish_v<T, HAS2>(raw[u], sc, v);
             unpack16<T>(gr[u], g);
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                const float xh = (v[i] - mean[i]) * rstd[i];
-                const float uu = fmaf(xh, gm[i], bt[i]);
-                const float dyh = g[i] * (uu > 0.f ? 1.f : __expf(uu));
-                r1[i] += dyh; r2[i] = fmaf(dyh, xh, r2[i]);
+                const float dyh = g[i] * elu_grad(fmaf(v[i], ka[i], kb[i]));
+                r1[i] += dyh; r2[i] = fmaf(dyh, fmaf(v[i], xa[i], xb[i]), r2[i]);
             }
         }
     }
@@ -224,13 +249,14 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
     for (int i = threadIdx.x; i < a.C * 2; i += 256) atomicAdd(&a.red[(long)b * a.C * 2 + i], s_red[i]);
 }
 
-// pass 2: dv = rstd * (dyhat*gamma - (S1 + xhat*S2)/n), S1 = sum_{c in g} gamma_c r1, S2 = sum gamma_c r2
-template <typename T>
+// pass 2: dv = rstd * (dyhat*gamma - (S1 + xhat*S2)/n) = dyhat*ka - (c0 + v*c1),
+//         S1 = sum_{c in g} gamma_c r1, S2 = sum gamma_c r2, c1 = rstd^2 S2/n, c0 = rstd S1/n - mean c1
+template <typename T, bool HAS2, bool HASDB>
 __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
     GN_THREAD_MAP();
-    extern __shared__ float s_db[];                       // [C] when a.dbias
+    extern __shared__ float s_db[];                       // [C] when HASDB
     __shared__ float s_mr[GN_GROUPS * 2], s_S[GN_GROUPS * 2];
-    if (a.dbias)
+    if constexpr (HASDB)
         for (int i = threadIdx.x; i < a.C; i += 256) s_db[i] = 0.f;
     if (threadIdx.x < GN_GROUPS * 2) s_S[threadIdx.x] = 0.f;
     block_group_stats(a, b, gs, s_mr);
@@ -251,27 +277,27 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
             a.dgamma[c] = g; a.dbeta[c] = bsum;
         }
     }
-    float db[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) db[i] = 0.f;
-    float mean[P], rstd[P], gm[P], bt[P], s1[P], s2[P], sc[P];
+    float ka[P], kb[P], c0[P], c1[P], sc[P], db[P];
     const float inv_n = 1.f / ((float)a.HW * gs);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int g = (ch0 + i) / gs;
-        mean[i] = s_mr[2 * g]; rstd[i] = s_mr[2 * g + 1];
-        gm[i] = a.gamma[ch0 + i]; bt[i] = a.beta[ch0 + i];
-        sc[i] = (a.y2 && a.scale2) ? a.scale2[(long)b * a.C + ch0 + i] : 1.f;
-        s1[i] = s_S[2 * g] * inv_n; s2[i] = s_S[2 * g + 1] * inv_n;
+        const float mean = s_mr[2 * g], rstd = s_mr[2 * g + 1];
+        const float gm = a.gamma[ch0 + i];
+        ka[i] = rstd * gm; kb[i] = a.beta[ch0 + i] - mean * rstd * gm;
+        c1[i] = rstd * rstd * (s_S[2 * g + 1] * inv_n);
+        c0[i] = rstd * (s_S[2 * g] * inv_n) - mean * c1[i];
+        if constexpr (HASDB) db[i] = 0.f;
     }
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
     for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
-        RawRow<T> raw[GN_U];
+        RawRow<HAS2> raw[GN_U];
         u32x4_t gr[GN_U];
 #pragma unroll
         for (int u = 0; u < GN_U; ++u)
             if (p + u * rstep < p_end) {
                 const long pix = (long)b * a.HW + p + u * rstep;
-                load_raw<T>(a, pix, ch0, raw[u]);
+                load_raw<T, HAS2>(a, pix, ch0, raw[u]);
                 gr[u] = *(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0);
             }
 #pragma unroll
@@ -279,25 +305,25 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
             if (p + u * rstep >= p_end) break;
             const long pix = (long)b * a.HW + p + u * rstep;
             float v[P], g[P];
-            finish_v<T>(a, raw[u], sc, v);
+            finish_v<T, HAS2>(raw[u], sc, v);
             unpack16<T>(gr[u], g);
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                const float xh = (v[i] - mean[i]) * rstd[i];
-                const float uu = fmaf(xh, gm[i], bt[i]);
-                const float dyh = g[i] * (uu > 0.f ? 1.f : __expf(uu));
-                v[i] = rstd[i] * (dyh * gm[i] - (s1[i] + xh * s2[i]));
-                db[i] += v[i];
+                const float dyh = g[i] * elu_grad(fmaf(v[i], ka[i], kb[i]));
+                v[i] = dyh * ka[i] - fmaf(v[i], c1[i], c0[i]);
+                if constexpr (HASDB) db[i] += v[i];
             }
             *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
-            if (a.d2) {
+            if constexpr (HAS2) {
+                if (a.d2) {
 #pragma unroll
-                for (int i = 0; i < P; ++i) v[i] *= sc[i];
-                *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
+                    for (int i = 0; i < P; ++i) v[i] *= sc[i];
+                    *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
+                }
             }
         }
     }
-    if (a.dbias) {
+    if constexpr (HASDB) {
 #pragma unroll
         for (int i = 0; i < P; ++i) atomicAdd(&s_db[ch0 + i], db[i]);
         __syncthreads();
@@ -305,12 +331,247 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
     }
 }
 
-int g_gn_min_rows = 32, g_gn_target = 2048;         // development knobs (mte_debug_set(2 / 3, v))
+// =====================================================================================================================
+// SLAB kernels: workgroup = one (sample b, group g) slab held in registers
+// =====================================================================================================================
+// block id -> (b, g) with the 16 groups of a sample on one XCD (blocks L and L+8 share an XCD): neighbouring groups share
+// 128-byte lines (a group is 16-64 bytes of a pixel), so their fetches meet in one L2 instead of eight.
+#define GN_SLAB_MAP()                                                                                  \
+    constexpr int P = Elem<T>::PER16;                                                                  \
+    const int L_ = blockIdx.x, k_ = L_ >> 3;                                                           \
+    const int b = (L_ & 7) + 8 * (k_ / GN_GROUPS), g = k_ % GN_GROUPS;                                 \
+    if (b >= a.B) return;                                                                              \
+    const int gs = a.C / GN_GROUPS;                                                                    \
+    const int cps = 1 << a.cps_shift;                      /* 16-byte chunks per pixel in this group */ \
+    const int nchunks = a.HW << a.cps_shift;                                                           \
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;                                           \
+    const int ch0 = g * gs + (t & (cps - 1)) * P;          /* NT % cps == 0: a thread keeps its column */
 
-int gn_blocks(int B, int HW, int rstep) {
-    // ~8 workgroups per CU across the batch, at least g_gn_min_rows pixels per thread row
+// sum over the block of one float per thread -> double, broadcast to all threads (s_w: NT/64 floats of LDS)
+template <int NT>
+__device__ __forceinline__ double block_sum(float v, float* s_w, int lane, int wave) {
+    v = wave_sum(v);
+    __syncthreads();                                       // s_w free again
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tot += (double)s_w[w];
+    return tot;
+}
+
+template <typename T, bool HAS2, int NCH, int NT>
+__global__ __launch_bounds__(NT) void gn_fwd_slab_kernel(GnArgs a) {
+    GN_SLAB_MAP();
+    __shared__ float s_w[NT / 64];
+    RawRow<HAS2> raw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) load_raw<T, HAS2>(a, (long)b * a.HW + (id >> a.cps_shift), ch0, raw[i]);
+    }
+    float sc[P];
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (t + i * NT < nchunks) {
+            float v[P];
+            finish_v<T, HAS2>(raw[i], sc, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) s += v[k];
+        }
+    }
+    const double n = (double)a.HW * gs;
+    const double S = block_sum<NT>(s, s_w, lane, wave);
+    const float mean = (float)(S / n);
+    float q = 0.f;                                         // centred second moment: the slab is on chip, a second sweep is free
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (t + i * NT < nchunks) {
+            float v[P];
+            keep_packed<HAS2>(raw[i]);
+            finish_v<T, HAS2>(raw[i], sc, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+        }
+    }
+    const double Q = block_sum<NT>(q, s_w, lane, wave);
+    // statistics in the stream kernels' format (sum, sum of squares; copy 0 carries them, the other partial copies are zero):
+    // sum (v - m)^2 = sum v^2 - 2 m S + n m^2 for ANY m, so sum v^2 = Q + 2 m S - n m^2 exactly
+    const double sumsq = Q + 2.0 * (double)mean * S - n * (double)mean * (double)mean;
+    if (t < 2 * MTE_GN_REP) {
+        const int r = t >> 1, which = t & 1;
+        a.stats[((long)r * a.B + b) * GN_GROUPS * 2 + 2 * g + which] = r == 0 ? (which ? sumsq : S) : 0.0;
+    }
+    const double md = S / n;
+    double var = sumsq / n - md * md;                      // what the consumers of `stats` will compute
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)md;
+    float ka[P], kb[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float gm = a.gamma[ch0 + k];
+        ka[k] = rstd * gm;
+        kb[k] = a.beta[ch0 + k] - meanf * rstd * gm;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) {
+            float v[P];
+            keep_packed<HAS2>(raw[i]);
+            finish_v<T, HAS2>(raw[i], sc, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) v[k] = elu1(fmaf(v[k], ka[k], kb[k]));
+            *(u32x4_t*)((T*)a.z + ((long)b * a.HW + (id >> a.cps_shift)) * a.ldz + ch0) = pack16<T>(v);
+        }
+    }
+}
+
+// per-channel sums over the block: x[k] of threads that share a chunk column (t % cps) -> s_ch[(t % cps) * P + k]
+// (one shuffle tree over the lanes of equal column, one LDS slot per wave, then the first gs threads add the waves up)
+template <int NT, int P>
+__device__ __forceinline__ void block_channel_sums(float* x, int cps, int lane, int wave, float* s_part, float* s_ch, int gs) {
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        for (int off = cps; off < 64; off <<= 1) x[k] += __shfl_xor(x[k], off, 64);
+    __syncthreads();                                       // s_part / s_ch free again
+    if (lane < cps) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) s_part[wave * 32 + lane * P + k] = x[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < gs) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += s_part[w * 32 + threadIdx.x];
+        s_ch[threadIdx.x] = tot;
+    }
+    __syncthreads();
+}
+
+template <typename T, bool HAS2, bool HASDB, int NCH, int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
+    GN_SLAB_MAP();
+    __shared__ float s_part[(NT / 64) * 32];               // per-wave channel partials (a group has <= 32 channels)
+    __shared__ float s_r1[32], s_r2[32], s_db[32], s_S[2];
+    __shared__ double s_st[2];
+    if (t < 2) {                                           // this group's (sum, sum of squares): add the partial copies
+        const double* sp = a.stats + (long)b * GN_GROUPS * 2 + 2 * g + t;
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < MTE_GN_REP; ++r) acc += sp[(long)r * a.B * GN_GROUPS * 2];
+        s_st[t] = acc;
+    }
+    RawRow<HAS2> raw[NCH];
+    u32x4_t gr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) {
+            const long pix = (long)b * a.HW + (id >> a.cps_shift);
+            load_raw<T, HAS2>(a, pix, ch0, raw[i]);
+            gr[i] = *(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0);
+        }
+    }
+    __syncthreads();
+    const double n = (double)a.HW * gs;
+    const double md = s_st[0] / n;
+    double var = s_st[1] / n - md * md;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)md, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float xa = rstd, xb = -mean * rstd;
+    float ka[P], kb[P], sc[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float gm = a.gamma[ch0 + k];
+        ka[k] = rstd * gm; kb[k] = a.beta[ch0 + k] - mean * rstd * gm;
+    }
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    float r1[P], r2[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { r1[k] = 0.f; r2[k] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (t + i * NT < nchunks) {
+            float v[P], gz[P];
+            finish_v<T, HAS2>(raw[i], sc, v);
+            unpack16<T>(gr[i], gz);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float dyh = gz[k] * elu_grad(fmaf(v[k], ka[k], kb[k]));
+                r1[k] += dyh; r2[k] = fmaf(dyh, fmaf(v[k], xa, xb), r2[k]);
+            }
+        }
+    }
+    block_channel_sums<NT, P>(r1, cps, lane, wave, s_part, s_r1, gs);
+    block_channel_sums<NT, P>(r2, cps, lane, wave, s_part, s_r2, gs);
+    if (t < 64) {                                          // S1 = sum_c gamma_c r1_c, S2 = sum_c gamma_c r2_c over the group's channels
+        const float gm = t < gs ? a.gamma[g * gs + t] : 0.f;
+        const float S1 = wave_sum(t < gs ? gm * s_r1[t] : 0.f), S2 = wave_sum(t < gs ? gm * s_r2[t] : 0.f);
+        if (t == 0) { s_S[0] = S1; s_S[1] = S2; }
+        if (t < gs) {                                      // dgamma / dbeta: sums over the batch (zeroed by the launcher)
+            atomicAdd(&a.dgamma[g * gs + t], s_r2[t]);
+            atomicAdd(&a.dbeta[g * gs + t], s_r1[t]);
+        }
+    }
+    __syncthreads();
+    const float inv_n = 1.f / ((float)a.HW * gs);
+    const float c1 = rstd * rstd * (s_S[1] * inv_n);
+    const float c0 = rstd * (s_S[0] * inv_n) - mean * c1;
+    float db[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) db[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) {
+            const long pix = (long)b * a.HW + (id >> a.cps_shift);
+            float v[P], gz[P];
+            keep_packed<HAS2>(raw[i]);
+            asm volatile("" : "+v"(gr[i]));
+            finish_v<T, HAS2>(raw[i], sc, v);
+            unpack16<T>(gr[i], gz);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float dyh = gz[k] * elu_grad(fmaf(v[k], ka[k], kb[k]));
+                v[k] = dyh * ka[k] - fmaf(v[k], c1, c0);
+                if constexpr (HASDB) db[k] += v[k];
+            }
+            *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
+            if constexpr (HAS2) {
+                if (a.d2) {
+#pragma unroll
+                    for (int k = 0; k < P; ++k) v[k] *= sc[k];
+                    *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
+                }
+            }
+        }
+    }
+    if constexpr (HASDB) {
+        block_channel_sums<NT, P>(db, cps, lane, wave, s_part, s_db, gs);
+        if (t < gs) atomicAdd(&a.dbias[g * gs + t], s_db[t]);
+    }
+}
+
+int g_gn_min_rows = 32, g_gn_target = 2048;         // development knobs (mte_debug_set(2 / 3, v))
+int g_gn_slab = 1;                                  // development knob (mte_debug_set(13, v)): 0 = stream kernels only
+
+int g_gn_zigzag = 1;                                // development knob (mte_debug_set(14, v))
+
+// Two-pass kernels read the same tensors twice.  Blocks are dispatched in blockIdx order, i.e. sample after sample: when the
+// second pass walks the samples in the OPPOSITE order it starts on the bytes the first pass touched last, which are still in
+// the 256 MB Infinity Cache (a full-resolution 32-channel activation is 252 MB per tensor at T8: in the same order nothing
+// of the first pass survives to the second).
+int gn_blocks(int B, int HW, int rstep, bool forward = false) {
+    // ~8 workgroups per CU across the batch, at least min_rows pixels per thread row: a thread's rows are consumed in serial
+    // batches of GN_U loads, so long runs leave the short low-resolution launches latency-bound; the backward kernels pay a
+    // per-workgroup flush of 2-3 C atomics and prefer fewer, longer workgroups
+    const int min_rows = forward ? (g_gn_min_rows < 16 ? g_gn_min_rows : 16) : g_gn_min_rows;
     long want = (g_gn_target + B - 1) / B;
-    long maxb = ((long)HW + (long)g_gn_min_rows * rstep - 1) / ((long)g_gn_min_rows * rstep);
+    long maxb = ((long)HW + (long)min_rows * rstep - 1) / ((long)min_rows * rstep);
     if (want > maxb) want = maxb;
     return (int)(want < 1 ? 1 : want);
 }
@@ -322,15 +583,109 @@ bool gn_shape_ok(int C, int dtype) {
     return cpr <= 256 && 256 % cpr == 0;
 }
 
+// slab geometry: a group must be whole 16-byte chunks (1, 2, 4 or 8 per pixel); -> chunks of one slab, or 0 if not a slab shape
+long slab_chunks(int HW, int C, int dtype, int* cps_shift) {
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    const int gs = C / GN_GROUPS;
+    if (!g_gn_slab || gs % per16 != 0 || gs > 32) return 0;
+    const int cps = gs / per16;
+    if (cps != 1 && cps != 2 && cps != 4 && cps != 8) return 0;
+    int sh = 0;
+    while ((1 << sh) < cps) ++sh;
+    *cps_shift = sh;
+    return (long)HW * cps;
+}
+unsigned slab_grid(int B) { return 8u * GN_GROUPS * ((B + 7) / 8); }
+// A slab workgroup runs load -> reduce -> apply -> store back to back with the CU to itself (1024 threads), and only B*16
+// of them exist: measured (tools/gn_bench.py, B = 8, bf16) it wins 3x on the 12x40 layers (6.8 vs 19 us forward, 19 vs 37 us
+// backward), ties at 24x80 and loses at 48x160, where the streaming kernels overlap their phases across workgroups.
+constexpr long GN_SLAB_MAX = 1024L * 4;
+
+template <typename T, bool HAS2> bool launch_fwd_slab(const GnArgs& a, long n, hipStream_t st) {
+    const dim3 grid(slab_grid(a.B));
+#define GN_FWD_SLAB(NCH)                                                                                       \
+    if (n <= 1024L * NCH) { hipLaunchKernelGGL((gn_fwd_slab_kernel<T, HAS2, NCH, 1024>), grid, dim3(1024), 0, st, a); return true; }
+    GN_FWD_SLAB(2) GN_FWD_SLAB(4)
+#undef GN_FWD_SLAB
+    return false;
+}
+template <typename T, bool HAS2, bool HASDB> bool launch_bwd_slab(const GnArgs& a, long n, hipStream_t st) {
+    const dim3 grid(slab_grid(a.B));
+#define GN_BWD_SLAB(NCH, NT)                                                                                   \
+    if (n <= (long)NT * NCH) { hipLaunchKernelGGL((gn_bwd_slab_kernel<T, HAS2, HASDB, NCH, NT>), grid, dim3(NT), 0, st, a); return true; }
+    GN_BWD_SLAB(2, 1024) GN_BWD_SLAB(4, 1024)
+#undef GN_BWD_SLAB
+    return false;
+}
+
+template <typename T> int run_stats(GnArgs& a, hipStream_t stream) {
+    a.blocks_per_sample = gn_blocks(a.B, a.HW, 256 / (a.C / Elem<T>::PER16), true);
+    a.reverse = g_gn_zigzag;                               // the producing conv wrote sample 0 first: start on the freshest bytes
+    dim3 grid(a.blocks_per_sample, a.B);
+    if (a.y2) hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, dim3(256), 0, stream, a);
+    return mte_check_launch();
+}
+
+template <typename T> int run_fwd(GnArgs& a, hipStream_t stream) {
+    a.blocks_per_sample = gn_blocks(a.B, a.HW, 256 / (a.C / Elem<T>::PER16), true);
+    a.reverse = 0;                                         // ... and the statistics pass ended on sample 0
+    dim3 grid(a.blocks_per_sample, a.B);
+    if (a.y2) hipLaunchKernelGGL((gn_elu_fwd_kernel<T, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gn_elu_fwd_kernel<T, false>), grid, dim3(256), 0, stream, a);
+    return mte_check_launch();
+}
+
+template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
+    int sh = 0;
+    const long n = slab_chunks(a.HW, a.C, dtype, &sh);
+    if (n > 0 && n <= GN_SLAB_MAX && !(a.y2 && a.dbias)) {
+        a.cps_shift = sh;
+        // the slab kernels ADD this sample's part of dgamma / dbeta (the stream kernels overwrite them): clear them first
+        if (hipMemsetAsync(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (hipMemsetAsync(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        bool done;
+        if (a.y2) done = launch_bwd_slab<T, true, false>(a, n, stream);
+        else if (a.dbias) done = launch_bwd_slab<T, false, true>(a, n, stream);
+        else done = launch_bwd_slab<T, false, false>(a, n, stream);
+        if (done) return mte_check_launch();
+    }
+    a.blocks_per_sample = gn_blocks(a.B, a.HW, 256 / (a.C / Elem<T>::PER16));
+    dim3 grid(a.blocks_per_sample, a.B);
+    const size_t lds = sizeof(float) * a.C * 2;
+    GnArgs a2 = a;
+    a2.reverse = g_gn_zigzag;                              // the apply pass starts where the reduce pass ended
+    if (a.y2) {
+        hipLaunchKernelGGL((gn_elu_bwd_reduce_kernel<T, true>), grid, dim3(256), lds, stream, a);
+        if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, true, true>), grid, dim3(256), sizeof(float) * a.C, stream, a2);
+        else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, true, false>), grid, dim3(256), 0, stream, a2);
+    } else {
+        hipLaunchKernelGGL((gn_elu_bwd_reduce_kernel<T, false>), grid, dim3(256), lds, stream, a);
+        if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, false, true>), grid, dim3(256), sizeof(float) * a.C, stream, a2);
+        else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, false, false>), grid, dim3(256), 0, stream, a2);
+    }
+    return mte_check_launch();
+}
+
 }  // namespace
 
 extern "C" int mtei_set_gn(int which, int value) {
+    if (which == 2) { g_gn_slab = value; return MTE_OK; }
+    if (which == 3) { g_gn_zigzag = value; return MTE_OK; }
     if (value < 1) return MTE_ERR_ARG;
     if (which == 0) g_gn_min_rows = value; else g_gn_target = value;
     return MTE_OK;
 }
 
 extern "C" {
+
+// 1 if mte_gn_elu_fwd computes the statistics of this shape itself (single-pass slab kernel): the caller then skips mte_gn_stats.
+int mte_gn_fwd_is_single_pass(int HW, int C, int has_y2, int dtype) {
+    int sh = 0;
+    if (!gn_shape_ok(C, dtype)) return 0;
+    const long n = slab_chunks(HW, C, dtype, &sh);
+    return (n > 0 && n <= GN_SLAB_MAX) ? 1 : 0;
+}
 
 // stats[MTE_GN_REP][B][16][2] (double; zeroed here; partial copies) <- per-(sample, group) sum and sum of squares of v = y1 + scale2*y2
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
@@ -339,31 +694,34 @@ int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float
     if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     if (!g_mte_gn_prezeroed && hipMemsetAsync(stats, 0, sizeof(double) * MTE_GN_REP * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
-    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
-    a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));
-    dim3 grid(a.blocks_per_sample, B);
-    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, stream, a);
-    return mte_check_launch();
+    return dtype == MTE_DT_BF16 ? run_stats<bf16_t>(a, stream) : run_stats<float>(a, stream);
 }
 
-int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, const double* stats,
+// z = ELU(GN(y1 + scale2*y2)).  stats: the sums mte_gn_stats (or a conv epilogue) accumulated -- or, where
+// mte_gn_fwd_is_single_pass(HW, C, y2 != null, dtype) is 1 and stats_ready == 0, an OUTPUT: the kernel computes the
+// statistics of the slab it holds on chip and stores them in the same format for the backward pass.
+int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats, int stats_ready,
                    const float* gamma, const float* beta, void* z, long ldz,
                    int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y1 || !stats || !gamma || !beta || !z || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
-    GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
+    GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats;
     a.gamma = gamma; a.beta = beta; a.z = z; a.ldz = ldz; a.B = B; a.HW = HW; a.C = C; a.eps = eps;
-    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
-    a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));
-    dim3 grid(a.blocks_per_sample, B);
-    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(gn_elu_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(gn_elu_fwd_kernel<float>, grid, dim3(256), 0, stream, a);
-    return mte_check_launch();
+    if (!stats_ready) {
+        if (!mte_gn_fwd_is_single_pass(HW, C, y2 != nullptr, dtype)) return MTE_ERR_ARG;
+        int sh = 0;
+        const long n = slab_chunks(HW, C, dtype, &sh);
+        a.cps_shift = sh;
+        bool ok;
+        if (dtype == MTE_DT_BF16) ok = y2 ? launch_fwd_slab<bf16_t, true>(a, n, stream) : launch_fwd_slab<bf16_t, false>(a, n, stream);
+        else ok = y2 ? launch_fwd_slab<float, true>(a, n, stream) : launch_fwd_slab<float, false>(a, n, stream);
+        return ok ? mte_check_launch() : MTE_ERR_ARG;
+    }
+    return dtype == MTE_DT_BF16 ? run_fwd<bf16_t>(a, stream) : run_fwd<float>(a, stream);
 }
 
 // Backward of z = ELU(GN(y1 + scale2*y2)).  red[B][C][2] is scratch (zeroed here).  Writes d1 (grad of y1),
-// optionally d2 (grad of y2 = scale2 * d1), dgamma/dbeta [C] (overwritten) and, if non-null, dbias [C] = column sums of d1.
+// optionally d2 (grad of y2 = scale2 * d1), dgamma/dbeta [C] (overwritten) and, if non-null, dbias [C] += column sums of d1.
 int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
                    const double* stats, const float* gamma, const float* beta, float* red,
                    void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,
@@ -377,18 +735,7 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
     GnArgs a{}; a.dbias = dbias; a.dgamma = dgamma; a.dbeta = dbeta; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
     a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;
     a.B = B; a.HW = HW; a.C = C; a.eps = eps;
-    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
-    a.blocks_per_sample = gn_blocks(B, HW, 256 / (C / per16));
-    dim3 grid(a.blocks_per_sample, B);
-    const size_t lds = sizeof(float) * C * 2;
-    if (dtype == MTE_DT_BF16) {
-        hipLaunchKernelGGL(gn_elu_bwd_reduce_kernel<bf16_t>, grid, dim3(256), lds, stream, a);
-        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<bf16_t>, grid, dim3(256), dbias ? sizeof(float) * C : 0, stream, a);
-    } else {
-        hipLaunchKernelGGL(gn_elu_bwd_reduce_kernel<float>, grid, dim3(256), lds, stream, a);
-        hipLaunchKernelGGL(gn_elu_bwd_apply_kernel<float>, grid, dim3(256), dbias ? sizeof(float) * C : 0, stream, a);
-    }
-    return mte_check_launch();
+    return dtype == MTE_DT_BF16 ? run_bwd<bf16_t>(a, dtype, stream) : run_bwd<float>(a, dtype, stream);
 }
 
 int mte_set_option(int option, int value) {

@@ -210,8 +210,16 @@ _arena = _ZeroArena()
 
 
 def begin_graph_capture():
-    """Library-side state a HIP-graph capture must not inherit (see _ZeroArena.zeros)."""
+    """Library-side state a HIP-graph capture must not inherit (see _ZeroArena.zeros): zero-arena chunks and the pooled
+    Dropout2d draws (a pool left over from eager steps would be baked into the graph as constants; a pool drawn INSIDE the
+    capture is a node whose Philox offset torch advances at every replay)."""
     _arena.begin_capture()
+    _dropout_pool.clear()
+
+
+def end_graph_capture():
+    """After a capture: drop the references eager code would otherwise keep into the graph's private memory pool."""
+    _dropout_pool.clear()
 
 
 def _zeros(shape, dtype, device):
@@ -361,6 +369,12 @@ def prefetch_weight_packs():
                 for g in group:
                     g._event = ev
                 group = []
+    if torch.cuda.is_current_stream_capturing():
+        # a HIP-graph capture must end with every forked stream joined; inside a graph the packs are DAG nodes that depend on
+        # the optimizer only, so the replay still overlaps them with whatever else is ready
+        torch.cuda.current_stream().wait_stream(side)
+        for pk in packs:
+            pk._event = None
 
 
 def _splitk_workspace(M, N, device):
@@ -554,14 +568,18 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, stats=None):
     p1, l1 = _pl(y1)
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     st = _stream()
+    ready = 1
     if stats is None:
         stats = _zeros((GN_REP, B, 16, 2), torch.float64, y1.device)
-        lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
+        if lib.mte_gn_fwd_is_single_pass(H * W, C, 1 if y2 is not None else 0, _dt(y1)) == 1:
+            ready = 0                  # low-resolution layer: one kernel holds each (sample, group) slab on chip -- statistics + apply
+        else:
+            lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
     if tuple(z.shape) != (B, C, H, W) or z.dtype != y1.dtype:
         raise MteError("output destination has shape %s / %s, expected %s / %s" % (tuple(z.shape), z.dtype, (B, C, H, W), y1.dtype))
     zp, lz = _pl(z)
-    lib.mte_gn_elu_fwd(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), zp, lz,
+    lib.mte_gn_elu_fwd(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), ready, gamma.data_ptr(), beta.data_ptr(), zp, lz,
                        B, H * W, C, eps, _dt(y1), st)
     return z, stats
 
@@ -1146,6 +1164,65 @@ class EdgeLossFn(torch.autograd.Function):
         lib.mte_edge_loss_bwd(pred.data_ptr(), edge.data_ptr(), _ptr(normal), _ptr(mask), coef.data_ptr(), gl.data_ptr(),
                               dpred.data_ptr(), B, H, W, from_inv, is_grad, is_sigmoid, thresh, _stream())
         return (dpred,) + (None,) * 10
+
+
+class _EdgeScale(ctypes.Structure):       # mte_edge_scale of include/mte_kernels.h
+    _fields_ = [("pred", ctypes.c_void_p), ("edge", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+                ("gmap", ctypes.c_void_p), ("dpred", ctypes.c_void_p), ("H", ctypes.c_int), ("W", ctypes.c_int)]
+
+
+class DepthLossesFn(torch.autograd.Function):
+    """Every loss term of SemiSupEdgeModel.forward (models/SemiSupEdgeModel.py:137-151) in ONE forward and ONE backward launch:
+    the depth-edge loss of all scales (compute_edge_loss_with_all_scales, :164-198; GradLoss 'cross_entropy' fused with
+    inv2depth) and, when `gt_depth` is given, the sparse silog loss of scale 0 -- both read the same inverse-depth maps.
+    -> fp32 [S] (+1): weight * balanced BCE per scale, then the silog loss when gt_depth is given."""
+
+    @staticmethod
+    def forward(ctx, weight, pos_to_neg, thresh, from_inv, mask, gt_depth, edges, normals, *preds):
+        S = len(preds)
+        B = preds[0].shape[0]
+        dev = preds[0].device
+        preds = [p.contiguous().float() for p in preds]
+        edges = [e.contiguous().float() for e in edges]
+        normals = [None if n is None else n.contiguous().float() for n in normals]
+        mask = None if mask is None else mask.contiguous().float()
+        if mask is not None and any(tuple(mask.shape[-2:]) != tuple(p.shape[-2:]) for p in preds):
+            raise MteError("one full-resolution mask for every scale is an upstream bug that only works with mask=None")
+        gt = None if gt_depth is None else gt_depth.contiguous().float()
+        arr = (_EdgeScale * S)()
+        for o, p, e, n in zip(arr, preds, edges, normals):
+            if tuple(p.shape) != tuple(e.shape) or (n is not None and tuple(n.shape) != tuple(e.shape)):
+                raise MteError("prediction / label shapes differ: %s vs %s" % (tuple(p.shape), tuple(e.shape)))
+            o.pred, o.edge, o.normal, o.mask = p.data_ptr(), e.data_ptr(), _ptr(n), _ptr(mask)
+            o.gmap = o.dpred = None
+            o.H, o.W = p.shape[-2], p.shape[-1]
+        work = torch.empty((lib.mte_edge_loss_work_elems(ctypes.addressof(arr), S, B),), dtype=torch.float64, device=dev)
+        losses = torch.empty((S + (1 if gt is not None else 0),), dtype=torch.float32, device=dev)
+        coef = torch.empty((S * (2 * B + 1),), dtype=torch.float32, device=dev)
+        aux = torch.empty((2,), dtype=torch.float32, device=dev) if gt is not None else None
+        lib.mte_edge_loss_multi_fwd(ctypes.addressof(arr), S, B, int(from_inv), 1, 1, float(thresh), float(weight), float(pos_to_neg),
+                                    _ptr(gt), work.data_ptr(), losses.data_ptr(), coef.data_ptr(),
+                                    losses.data_ptr() + 4 * S if gt is not None else 0, _ptr(aux), _stream())
+        ctx.save_for_backward(coef, mask, gt, aux, *preds, *edges, *[n for n in normals if n is not None])
+        ctx.cfg = (S, B, int(from_inv), float(thresh), [n is not None for n in normals])
+        return losses
+
+    @staticmethod
+    def backward(ctx, glosses):
+        S, B, from_inv, thresh, has_n = ctx.cfg
+        coef, mask, gt, aux = ctx.saved_tensors[:4]
+        rest = ctx.saved_tensors[4:]
+        preds, edges, nrm = rest[:S], rest[S:2 * S], list(rest[2 * S:])
+        normals = [nrm.pop(0) if h else None for h in has_n]
+        dpreds = [torch.empty_like(p) for p in preds]
+        arr = (_EdgeScale * S)()
+        for o, p, e, n, d in zip(arr, preds, edges, normals, dpreds):
+            o.pred, o.edge, o.normal, o.mask, o.gmap, o.dpred = p.data_ptr(), e.data_ptr(), _ptr(n), _ptr(mask), None, d.data_ptr()
+            o.H, o.W = p.shape[-2], p.shape[-1]
+        gl = glosses.contiguous().float()
+        lib.mte_edge_loss_multi_bwd(ctypes.addressof(arr), S, B, from_inv, 1, 1, thresh, coef.data_ptr(), gl.data_ptr(), _ptr(gt),
+                                    _ptr(aux), gl.data_ptr() + 4 * S if gt is not None else 0, _stream())
+        return (None,) * 8 + tuple(dpreds)
 
 
 class SilogFn(torch.autograd.Function):

@@ -9,6 +9,8 @@ Differences from the reference, all behaviour-preserving for the shipped configu
   * inv2depth is fused into the edge-loss stencil (from_inv_depth=True), and the detached edge-strength maps the
     reference computes and drops are not written.
   * the caller's inv_depths list is not mutated by the supervised loss.
+  * in the shipped configuration the four per-scale head calls and the silog loss run as ONE fused forward and ONE fused
+    backward launch (``fuse_losses``); `edge_loss(...)` / `supervised_loss(...)` remain and give the same numbers per scale.
 """
 import torch
 
@@ -33,6 +35,7 @@ class SemiSupEdgeModel(SfmModel):
         if self.edges_depth_edge_loss_all_scales:
             self._input_keys += ['edge_1', 'edge_2', 'edge_3', 'normal_1', 'normal_2', 'normal_3']
         self.depth_edges_loss_weight = depth_edges_loss_weight
+        self.fuse_losses = True          # one launch for every loss term (kernels.DepthLossesFn); False = one head call per scale
 
     @property
     def logs(self):
@@ -55,15 +58,39 @@ class SemiSupEdgeModel(SfmModel):
             total = loss if total is None else total + loss
         return total / 4 if self.edges_depth_edge_loss_all_scales else total
 
+    def _fused_losses(self, inv_depths, batch):
+        """Edge loss of all scales + silog in one forward / one backward launch (kernels.DepthLossesFn): the shipped
+        configuration (4 scales, cross-entropy head, sparse-silog on scale 0).  -> (edge_loss, supervised 'loss' [1]) or None when
+        the configuration needs the per-scale path."""
+        from .. import kernels as K
+        head = getattr(self, 'edge_loss_head', None)
+        sup = self._supervised_loss
+        if (not self.edges_depth_edge_loss_all_scales or head is None or type(head).__name__ != 'GradLoss' or getattr(sup, 'n', 0) != 1
+                or not inv_depths[0].is_cuda or tuple(batch['depth'].shape[-2:]) != tuple(inv_depths[0].shape[-2:])):
+            return None
+        sfx = ['', '_1', '_2', '_3']
+        edges = [batch['edge' + s] for s in sfx]
+        normals = [batch.get('normal' + s) for s in sfx]
+        if any(tuple(e.shape[-2:]) != tuple(i.shape[-2:]) for e, i in zip(edges, inv_depths)):
+            return None
+        losses = K.DepthLossesFn.apply(head.weight, head.depth_edges_loss_pos_to_neg_weight, 4.0, True, batch.get('rgb_edge'),
+                                       batch['depth'], edges, normals, *inv_depths[:4])
+        sup.add_metric('supervised_loss', losses[4])
+        return losses[:4].sum() / 4, losses[4:5]
+
     def forward(self, batch, return_logs=False, progress=0.0, **kwargs):
         if not self.training:
             return SfmModel.forward(self, batch, return_logs=return_logs, **kwargs)
         out = SfmModel.forward(self, batch, return_logs=return_logs, **kwargs)
         inv_depths = out['inv_depths']
-        edge_loss = self.compute_edge_loss_with_all_scales(inv_depths, batch, batch.get('rgb_edge'), is_grad=True,
-                                                           is_sigmoid=True, sigmoid_thresh=4)
-        sup = self.supervised_loss(inv_depths, batch['depth'], return_logs=return_logs, progress=progress)
-        supervised_loss = self.supervised_loss_weight * sup['loss']
+        fused = self._fused_losses(inv_depths, batch) if self.fuse_losses else None
+        if fused is not None:
+            edge_loss, sup_loss = fused
+        else:
+            edge_loss = self.compute_edge_loss_with_all_scales(inv_depths, batch, batch.get('rgb_edge'), is_grad=True,
+                                                               is_sigmoid=True, sigmoid_thresh=4)
+            sup_loss = self.supervised_loss(inv_depths, batch['depth'], return_logs=return_logs, progress=progress)['loss']
+        supervised_loss = self.supervised_loss_weight * sup_loss
         edge_loss = self.depth_edges_loss_weight * edge_loss
         loss = supervised_loss + edge_loss
         metrics = {'metrics': {'edge_loss': edge_loss.detach(), 'supervised_loss': supervised_loss.detach()}}

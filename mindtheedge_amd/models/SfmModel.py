@@ -40,8 +40,17 @@ class SfmModel(BaseModel):
             return flip_output(self.depth_net(**flip_batch_input(batch_input)))
         return self.depth_net(**batch_input)
 
+    _pinned_flip = None          # utils.graph.GraphedTrainStep: the host-side flip draw is taken outside the captured step
+
+    def draw_flip(self):
+        """the reference's whole-batch flip draw (SfmModel.py:90): python's RNG, one draw per training step"""
+        return random.random() < self.flip_lr_prob
+
     def compute_depth_net(self, batch, force_flip=False, output_features=False):
-        flag_flip_lr = random.random() < self.flip_lr_prob if self.training else force_flip
+        if self.training:
+            flag_flip_lr = self.draw_flip() if self._pinned_flip is None else self._pinned_flip
+        else:
+            flag_flip_lr = force_flip
         return self.depth_net_flipping(batch, flag_flip_lr, output_features)
 
     def forward(self, batch, return_logs=False, force_flip=False, output_features=False):

@@ -198,6 +198,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.steps = 0
+        self.hyper = torch.zeros(3, dtype=torch.float32, device=flat.flat.device)    # lr, 1 - b1^t, sqrt(1 - b2^t): read by the kernel
 
     def zero_grad(self, set_to_none=False):
         self.flatp.zero_grad()
@@ -209,11 +210,32 @@ class FusedAdam(torch.optim.Optimizer):
             K.join_side_stream()
         gscale = self.reducer.finish() if self.reducer is not None else 1.0
         g = self.param_groups[0]
-        self.steps += 1
-        K.adam_step_flat(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq, self.steps, lr=g['lr'],
-                         betas=g['betas'], eps=g['eps'], gscale=gscale)
+        if self.flatp.grad.is_cuda:
+            # step count and learning rate reach the kernel through device memory, so the launch is identical every step (HIP-graph
+            # replay); under capture the host side of the step (advance) is the replaying caller's job
+            if not torch.cuda.is_current_stream_capturing():
+                self.advance()
+            K.lib.mte_adam_step_dev(self.flatp.flat.data_ptr(), self.flatp.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                    self.exp_avg_sq.data_ptr(), self.flatp.flat.numel(), self.hyper.data_ptr(),
+                                    float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(gscale),
+                                    torch.cuda.current_stream().cuda_stream)
+            K.bump_weights_epoch()
+        else:
+            self.steps += 1
+            K.adam_step_flat(self.flatp.flat, self.flatp.grad, self.exp_avg, self.exp_avg_sq, self.steps, lr=g['lr'],
+                             betas=g['betas'], eps=g['eps'], gscale=gscale)
         if self.flatp.grad.is_cuda:
             K.prefetch_weight_packs()                       # next step's kernel-ready weight packs, off the critical path
+
+    def advance(self):
+        """Host side of one step: count it and hand the kernel its learning rate and bias corrections (same double-precision
+        arithmetic as mte_adam_step) -- called by step(), or by a graph-replaying caller right before each replay."""
+        import math
+        g = self.param_groups[0]
+        self.steps += 1
+        b1, b2 = g['betas']
+        vals = [float(g['lr']), 1.0 - math.pow(float(b1), self.steps), math.sqrt(1.0 - math.pow(float(b2), self.steps))]
+        self.hyper.copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=True)
 
     def set_index_space(self, names, local_names):
         """Number the optimizer state like the reference's ``torch.optim.Adam(depth_net.parameters())`` does.

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Loss-kernel microbenchmark (development aid): the fused 4-scale depth-edge + silog forward / backward at T8 size, replayed
+from a HIP graph (the Python enqueue must not be what is measured) -> us per launch and algorithmic GB/s."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from mindtheedge_amd import kernels as K  # noqa: E402
+from mindtheedge_amd.utils.synthetic import synthetic_batch  # noqa: E402
+
+
+def main():
+    B, H, W = 8, 384, 1280
+    dev = torch.device("cuda")
+    batch = synthetic_batch(B, H, W, 3, dev)
+    sfx = ["", "_1", "_2", "_3"]
+    invs = [(0.05 + 1.9 * torch.rand(B, 1, H >> s, W >> s, device=dev)).requires_grad_(True) for s in range(4)]
+    edges = [batch["edge" + s] for s in sfx]
+    normals = [batch["normal" + s] for s in sfx]
+    px = sum(B * (H >> s) * (W >> s) for s in range(4))
+    import ctypes
+    lib = K.lib
+    S = 4
+    preds = [i.detach() for i in invs]
+    dpreds = [torch.empty_like(p) for p in preds]
+    arr = (K._EdgeScale * S)()
+    for o, p, e, n, d in zip(arr, preds, edges, normals, dpreds):
+        o.pred, o.edge, o.normal, o.mask, o.gmap, o.dpred = p.data_ptr(), e.data_ptr(), n.data_ptr(), None, None, d.data_ptr()
+        o.H, o.W = p.shape[-2], p.shape[-1]
+    work = torch.empty((lib.mte_edge_loss_work_elems(ctypes.addressof(arr), S, B),), dtype=torch.float64, device=dev)
+    losses = torch.empty((S + 1,), dtype=torch.float32, device=dev)
+    coef = torch.empty((S * (2 * B + 1),), dtype=torch.float32, device=dev)
+    aux = torch.empty((2,), dtype=torch.float32, device=dev)
+    gl = torch.ones((S + 1,), dtype=torch.float32, device=dev)
+    for with_silog in (False, True):
+        gt = batch["depth"].data_ptr() if with_silog else 0
+
+        def fwd():
+            lib.mte_edge_loss_multi_fwd(ctypes.addressof(arr), S, B, 1, 1, 1, 4.0, 10.0, 1.0, gt, work.data_ptr(), losses.data_ptr(),
+                                        coef.data_ptr(), losses.data_ptr() + 16 if gt else 0, aux.data_ptr() if gt else 0, K._stream())
+
+        def bwd():
+            lib.mte_edge_loss_multi_bwd(ctypes.addressof(arr), S, B, 1, 1, 1, 4.0, coef.data_ptr(), gl.data_ptr(), gt,
+                                        aux.data_ptr() if gt else 0, gl.data_ptr() + 16 if gt else 0, K._stream())
+        iters = 20
+        res = {}
+        for name, fn in (("fwd", fwd), ("bwd", bwd)):
+            fwd()
+            torch.cuda.synchronize()
+
+            def body():
+                for _ in range(iters):
+                    fn()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()
+            graph.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = e0.elapsed_time(e1) / iters * 1e3
+        extra = B * H * W * 4 if with_silog else 0
+        fb, bb = 12.0 * px + extra, 16.0 * px + extra
+        f, b = res["fwd"], res["bwd"]
+        print("silog fused=%d  fwd %6.1f us (%5.0f GB/s)  bwd %6.1f us (%5.0f GB/s)  both %6.1f us (%5.0f GB/s = %.3f of 8 TB/s)"
+              % (with_silog, f, fb / f / 1e3, b, bb / b / 1e3, f + b, (fb + bb) / (f + b) / 1e3, (fb + bb) / (f + b) / 1e3 / 8000))
+    print("losses", losses.tolist())
+
+
+if __name__ == "__main__":
+    main()
