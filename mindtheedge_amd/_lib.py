@@ -69,12 +69,13 @@ class _Lib:
         if name.startswith("mte_"):
             fn = getattr(self.load(), name)
             if name in QUERIES:
-                return fn
-
-            def call(*args):
-                rc = fn(*args)
-                if rc != 0:
-                    raise MteError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
+                call = fn
+            else:
+                def call(*args):
+                    rc = fn(*args)
+                    if rc != 0:
+                        raise MteError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
+            self.__dict__[name] = call        # ~1000 launches per training step go through here: resolve each entry point once
             return call
         raise AttributeError(name)
 

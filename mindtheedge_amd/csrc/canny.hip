@@ -121,7 +121,7 @@ extern "C" int mte_canny_begin(const float* depth, int B, int H, int W, int n_pa
         pr.low[p] = thresholds[2 * p] < thresholds[2 * p + 1] ? thresholds[2 * p] : thresholds[2 * p + 1];
         pr.high[p] = thresholds[2 * p] < thresholds[2 * p + 1] ? thresholds[2 * p + 1] : thresholds[2 * p];
     }
-    if (hipMemsetAsync(max_ws, 0, sizeof(unsigned) * B, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(max_ws, 0, sizeof(unsigned) * B, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     int bx = cdiv((long)H * W, 256 * 8); if (bx > 256) bx = 256;
     hipLaunchKernelGGL(image_max_kernel, dim3(bx, B), dim3(256), 0, stream, depth, max_ws, H * W);
     hipLaunchKernelGGL(canny_nms_kernel, dim3(cdiv(W, TX), cdiv(H, TY), B), dim3(256), 0, stream, depth, max_ws, vis_u8, state, B, H, W, pr);

@@ -112,7 +112,7 @@ extern "C" int mte_chamfer_distance(const float* im_pred, const float* im_gt, in
     if ((size_t)W * 4 > 60000) return MTE_ERR_UNSUPPORTED;                                  // one row of g^2 lives in LDS
     double* acc = (double*)workspace;                                                       // [B][4], 8-byte aligned first
     unsigned* g2 = (unsigned*)((char*)workspace + (long)B * 4 * 8);
-    if (hipMemsetAsync(acc, 0, (size_t)B * 4 * 8, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(acc, 0, (size_t)B * 4 * 8, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     hipLaunchKernelGGL(edt_columns_kernel, dim3(cdiv(W, EC), B), dim3(EC * ES), 0, stream, im_gt, g2, H, W);
     hipLaunchKernelGGL(edt_rows_chamfer_kernel, dim3(H, B), dim3(256), (size_t)W * 4, stream, im_pred, g2, acc, dist_map, cond_map, H, W,
                        edge_to_edge_thresh);

@@ -101,6 +101,32 @@ extern int g_mte_gn_prezeroed;
 // before they land: statistics fused into the conv epilogues cost more than the stand-alone pass they replaced.
 #define MTE_GN_REP 16
 
+// Zero / byte-pattern fill as a KERNEL.  hipMemsetAsync must not be used on this library's launch paths: captured into a HIP
+// graph (utils/graph.py) its memset node was seen NOT to take effect on replays issued after the device had gone idle
+// (ROCm 7.2, MI355X: split-K workspaces kept the previous frame's sums, GroupNorm variances went negative, NaN downstream),
+// while fill kernels replay correctly.  16-byte stores when the range allows it, words or bytes otherwise.
+static __global__ void mte_fill16_kernel(u32x4_t* __restrict__ p, unsigned v, size_t n16, unsigned* __restrict__ tail, int ntail) {
+    const u32x4_t vv = {v, v, v, v};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = vv;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = v;
+}
+static __global__ void mte_fill1_kernel(unsigned char* __restrict__ p, unsigned char v, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static inline hipError_t mte_memset_async(void* p, int value, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    const unsigned b = (unsigned)value & 0xffu, v = b | (b << 8) | (b << 16) | (b << 24);
+    if (((uintptr_t)p & 15) == 0 && bytes % 4 == 0) {
+        const size_t n16 = bytes / 16;
+        size_t g = (n16 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+        hipLaunchKernelGGL(mte_fill16_kernel, dim3((unsigned)g), dim3(256), 0, st, (u32x4_t*)p, v, n16, (unsigned*)p + n16 * 4, (int)((bytes % 16) / 4));
+    } else {
+        size_t g = (bytes + 255) / 256; if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(mte_fill1_kernel, dim3((unsigned)g), dim3(256), 0, st, (unsigned char*)p, (unsigned char)b, bytes);
+    }
+    return hipGetLastError();
+}
+
 static inline int mte_check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) fprintf(stderr, "[libmte_hip] launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));

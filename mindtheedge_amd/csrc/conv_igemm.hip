@@ -441,8 +441,8 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
                       a.N % 16 == 0;
     if (stats_done) *stats_done = fuse ? 1 : 0;
     if (!fuse) a.gn_stats = nullptr;
-    else { a.gn_gs = a.N / 16; if (!g_mte_gn_prezeroed && hipMemsetAsync(a.gn_stats, 0, sizeof(double) * MTE_GN_REP * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
-    if (a.splits > 1 && hipMemsetAsync(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
+    else { a.gn_gs = a.N / 16; if (!g_mte_gn_prezeroed && mte_memset_async(a.gn_stats, 0, sizeof(double) * MTE_GN_REP * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
+    if (a.splits > 1 && mte_memset_async(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
     if constexpr ((BN * 4) % NTHR == 0) {
         if (g_igemm_dma) {
             const size_t lds4 = 4 * (BM + BN) * 64 + 256;
@@ -1009,7 +1009,7 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st, int parts_cap, int* parts_out)
     } else {
         a.part_stride = 0;
         if (parts_out) *parts_out = 1;
-        if (a.splits > 1 && hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (a.splits > 1 && mte_memset_async(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
     }
     const size_t lds = WG_RING * 32 * (BNO + BC) * 2;
     const dim3 grid((unsigned)(base_wgs * a.splits));
@@ -1039,7 +1039,7 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
     a.blocks_per_split = (int)((nblk + splits - 1) / splits);
     a.splits = (int)((nblk + a.blocks_per_split - 1) / a.blocks_per_split);
     if (a.splits > 1) {
-        hipError_t e = hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st);
+        hipError_t e = mte_memset_async(a.dw, 0, sizeof(float) * (size_t)a.N * taps * a.Cin_p, st);
         if (e != hipSuccess) return MTE_ERR_LAUNCH;
     }
     const size_t lds = 2 * 32 * (RS_Y + RS_X);
@@ -1259,7 +1259,7 @@ int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, hip
     if (!y || !out || N % 8 != 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (N / per16 > 256) return MTE_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(out, 0, sizeof(float) * N, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(out, 0, sizeof(float) * N, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     const int rstep = 256 / (N / per16);
     long want = (M + rstep - 1) / rstep;
     want = (want + 31) / 32;                          // >= 32 rows per thread

@@ -419,7 +419,7 @@ template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream
     } else {
         a.part_stride = 0;
         if (parts_out) *parts_out = 1;
-        if (hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (mte_memset_async(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT, SL>), dim3((unsigned)groups, nslices), dim3(256), lds, st, a);
     return mte_check_launch();
@@ -478,7 +478,7 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
     if (gn_stats && N % 16 != 0) return MTE_ERR_ARG;
-    if (gn_stats && !g_mte_gn_prezeroed && hipMemsetAsync(gn_stats, 0, sizeof(double) * MTE_GN_REP * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (gn_stats && !g_mte_gn_prezeroed && mte_memset_async(gn_stats, 0, sizeof(double) * MTE_GN_REP * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, gn_stats};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
 }

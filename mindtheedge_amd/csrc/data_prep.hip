@@ -59,7 +59,7 @@ int mte_normal_target_from_u8(const unsigned char* src, float* dst, long n, hipS
 int mte_resize_depth_preserve(const float* src, int B, int h, int w, float* dst, int H, int W, int* winner_ws, hipStream_t stream) {
     if (!src || !dst || !winner_ws || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (long)h * w >= (1L << 30) || (long)H * W >= (1L << 30))
         return MTE_ERR_ARG;
-    if (hipMemsetAsync(winner_ws, 0xff, sizeof(int) * (size_t)B * H * W, stream) != hipSuccess) return MTE_ERR_LAUNCH;      // -1
+    if (mte_memset_async(winner_ws, 0xff, sizeof(int) * (size_t)B * H * W, stream) != hipSuccess) return MTE_ERR_LAUNCH;      // -1
     hipLaunchKernelGGL(rdp_scatter_kernel, dim3(grid_for((long)h * w), B), dim3(256), 0, stream, src, winner_ws, h, w, H, W,
                        (double)H / (double)h, (double)W / (double)w);
     hipLaunchKernelGGL(rdp_gather_kernel, dim3(grid_for((long)H * W), B), dim3(256), 0, stream, src, winner_ws, dst, h * w, H * W);

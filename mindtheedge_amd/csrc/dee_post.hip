@@ -195,7 +195,7 @@ extern "C" int mte_dee_sobel_nms(const float* pred, float scale, unsigned char* 
 extern "C" int mte_hysteresis_begin(const float* img, unsigned char* state, int* info, int B, int H, int W, double t_low, double t_high,
                                     hipStream_t stream) {
     if (!img || !state || !info || B <= 0 || H <= 0 || W <= 0 || (long)H * W >= (1L << 30)) return MTE_ERR_ARG;
-    if (hipMemsetAsync(info, 0, (size_t)B * 4 * sizeof(int), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(info, 0, (size_t)B * 4 * sizeof(int), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     const int bx = std::min(cdiv((long)H * W, 256 * 8), 512);
     hipLaunchKernelGGL(hyst_classify_kernel, dim3(bx, B), dim3(256), 0, stream, img, state, (unsigned*)info, H, W, t_low, t_high);
     return mte_check_launch();
@@ -203,8 +203,8 @@ extern "C" int mte_hysteresis_begin(const float* img, unsigned char* state, int*
 
 extern "C" int mte_hysteresis_propagate(unsigned char* state, int* flags, int sweeps, int B, int H, int W, hipStream_t stream) {
     if (!state || !flags || sweeps <= 0 || B <= 0 || H <= 0 || W <= 0) return MTE_ERR_ARG;
-    if (hipMemsetAsync(flags, 0, (size_t)(sweeps + 1) * sizeof(int), stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    if (hipMemsetAsync(flags, 1, 1, stream) != hipSuccess) return MTE_ERR_LAUNCH;             // flags[0] != 0: the first sweep always runs
+    if (mte_memset_async(flags, 0, (size_t)(sweeps + 1) * sizeof(int), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(flags, 1, 1, stream) != hipSuccess) return MTE_ERR_LAUNCH;             // flags[0] != 0: the first sweep always runs
     for (int k = 1; k <= sweeps; ++k)
         hipLaunchKernelGGL(hyst_propagate_kernel, dim3(cdiv(W, HX), cdiv(H, HY), B), dim3(256), 0, stream, state, flags, k, H, W);
     return mte_check_launch();

@@ -46,7 +46,7 @@ struct EdgeMulti {
     int from_inv, is_grad, is_sigmoid, finalize;
     float thresh, weight, pos_to_neg;
     double* results;                    // [nscales][B][NP] accumulators (zeroed by the launcher)
-    unsigned* counter;                  // arrival ticket (zeroed by the launcher)
+    unsigned* counter;                  // [0] launch ticket, [1 + s*B + b] ticket of (scale, sample) (zeroed by the launcher)
     float* losses;                      // forward out: [nscales]
     float* coef;                        // forward out / backward in: [nscales][2B + 1]
     const float* gout;                  // backward: upstream gradient per scale loss (device, nullable = 1)
@@ -95,7 +95,7 @@ template <int R> struct DepthTile {
     static_assert(ROWS * 2 * R <= 256, "one halo pixel per thread");
     f32x4_t v[NI];
     float hv;
-    __device__ __forceinline__ void issue(const EdgeScale& sc, int b, int x0, int y0) {
+    __device__ __forceinline__ void issue(const EdgeScale& sc, int vec, int b, int x0, int y0) {
         const float* img = sc.pred + (long)b * sc.H * sc.W;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -103,7 +103,7 @@ template <int R> struct DepthTile {
             const int ly = i >> 4, c4 = (i & 15) * 4;
             const int gy = y0 + ly - R;
             v[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (i < ROWS * (TW / 4) && (unsigned)gy < (unsigned)sc.H) v[k] = load4(img, gy, x0 + c4, sc.W, sc.vec);
+            if (i < ROWS * (TW / 4) && (unsigned)gy < (unsigned)sc.H) v[k] = load4(img, gy, x0 + c4, sc.W, vec);
         }
         hv = 0.f;
         const int i = threadIdx.x;
@@ -153,7 +153,9 @@ __device__ __forceinline__ void sobel4(const float w[3][6], int k, float& sh, fl
     srl = (n1 - n3) + 2.f * (n2 - n6) + (n5 - n7);
     slr = (n5 - n1) + 2.f * (n8 - n0) + (n7 - n3);
 }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+// 1-ulp reciprocal (v_rcp_f32): enough wherever the result is not differenced against a neighbour (the depth tile keeps IEEE division)
+__device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf(float x) { return rcpf(1.f + __expf(-x)); }
 
 struct BlockId { int s, b, x0, y0; };
 __device__ __forceinline__ BlockId decode_block(const EdgeMulti& a) {
@@ -171,6 +173,10 @@ __device__ __forceinline__ BlockId decode_block(const EdgeMulti& a) {
 // ---------------- forward -----------------------------------------------------------------------------------------
 __device__ void finalize_losses(const EdgeMulti& a);
 
+// FAST = the training configuration on every scale (16-byte accesses legal, inverse depth in, Sobel + normals + sigmoid, no mask):
+// the flags are compile-time there.  The generic instantiation carries every runtime flag -- its body is ~10k instructions
+// (scalar and vector access paths, magnitude / probability / mask branches), several times what the instruction cache likes.
+template <bool FAST>
 __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
     __shared__ __attribute__((aligned(16))) float sd[(TH + 2) * LS];
     __shared__ float sred[4][NP];
@@ -179,28 +185,32 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
     const EdgeScale& sc = a.s[id.s];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = (tid & 15) * 4, r0 = tid >> 4;                   // this thread's 4 pixels: columns c..c+3 of rows r0 and r0 + 16
-    const bool has_mask = sc.mask != nullptr;
+    const bool has_mask = FAST ? false : sc.mask != nullptr;
     const bool silog = a.gt_depth != nullptr && id.s == 0;
+    const int vec = FAST ? 1 : sc.vec;
+    const bool is_grad = FAST ? true : a.is_grad != 0, is_sigmoid = FAST ? true : a.is_sigmoid != 0;
+    const bool has_normal = FAST ? true : sc.normal != nullptr;
+    const int from_inv = FAST ? 1 : a.from_inv;
     const long img = (long)id.b * sc.H;
 
     // every global load of the workgroup first: one memory latency for the tile, the labels and the normals together
     DepthTile<1> tile;
-    if (a.is_grad) tile.issue(sc, id.b, id.x0, id.y0);
+    if (is_grad) tile.issue(sc, vec, id.b, id.x0, id.y0);
     f32x4_t e4[2], n4[2], m4[2], d4[2], i4[2];
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
         const int gy = id.y0 + r0 + 16 * ps;
         const bool ok = gy < sc.H;
-        e4[ps] = ok ? load4(sc.edge, img + gy, id.x0 + c, sc.W, sc.vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (sc.normal && a.is_grad) n4[ps] = ok ? load4(sc.normal, img + gy, id.x0 + c, sc.W, sc.vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (has_mask) m4[ps] = ok ? load4(sc.mask, img + gy, id.x0 + c, sc.W, sc.vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        e4[ps] = ok ? load4(sc.edge, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (has_normal && is_grad) n4[ps] = ok ? load4(sc.normal, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (has_mask) m4[ps] = ok ? load4(sc.mask, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (silog) {
-            d4[ps] = ok ? load4(a.gt_depth, img + gy, id.x0 + c, sc.W, sc.vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            i4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, sc.vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            d4[ps] = ok ? load4(a.gt_depth, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            i4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-        if (!a.is_grad) i4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, sc.vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!is_grad) i4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    if (a.is_grad) tile.commit(sc, a.from_inv, id.x0, id.y0, sd);
+    if (is_grad) tile.commit(sc, from_inv, id.x0, id.y0, sd);
     __syncthreads();
 
     float acc[NP];
@@ -211,16 +221,16 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
         const int ly = r0 + 16 * ps, gy = id.y0 + ly;
         if (gy >= sc.H) continue;
         float w[3][6];
-        if (a.is_grad) window(sd, ly + 1, c, w);
+        if (is_grad) window(sd, ly + 1, c, w);
         f32x4_t g4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (id.x0 + c + k >= sc.W) { g4[k] = 0.f; continue; }
             float g;
-            if (a.is_grad) {
+            if (is_grad) {
                 float sh, sv, srl, slr;
                 sobel4(w, k, sh, sv, srl, slr);
-                if (sc.normal) {
+                if (has_normal) {
                     const int code = direction_code(n4[ps][k]);
                     g = fabsf(code == 0 ? sh : (code == 1 ? sv : (code == 2 ? srl : slr)));
                 } else {
@@ -230,9 +240,13 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
                 g = i4[ps][k];
             }
             g4[k] = g;
-            const float p = a.is_sigmoid ? sigmoidf(g - a.thresh) : g;
+            // p = 1 / (1 + t), 1 - p = t p with t = exp(-(g - thresh)): the reference forms 1 - p by subtraction in float32, which
+            // loses everything once p rounds towards 1 (g - thresh > ~8); t p is exact to an ulp and agrees wherever that is defined
+            float p, omp;
+            if (is_sigmoid) { const float t = __expf(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
+            else { p = g; omp = 1.f - g; }
             const float e = e4[ps][k];
-            const float pos = -e * __logf(p + 0.001f), neg = -(1.f - e) * __logf(1.f - p + 0.001f);
+            const float pos = -e * __logf(p + 0.001f), neg = -(1.f - e) * __logf(omp + 0.001f);
             acc[2] += pos; acc[3] += neg;
             if (has_mask) {
                 const float m = m4[ps][k];
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
                 }
             }
         }
-        if (sc.gmap) store4(sc.gmap, img + gy, id.x0 + c, sc.W, sc.vec, g4);
+        if (!FAST && sc.gmap) store4(sc.gmap, img + gy, id.x0 + c, sc.W, vec, g4);
     }
     // fp32 within the wave, fp64 across the waves and across workgroups
 #pragma unroll
@@ -265,22 +279,31 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
     __syncthreads();
     if (tid < NP) {
         const bool live = !((tid >= 4 && tid < 10 && !has_mask) || (tid >= 10 && !silog));
-        if (live) atomicAdd(&a.results[((long)id.s * a.B + id.b) * NP + tid],
-                            (double)sred[0][tid] + (double)sred[1][tid] + (double)sred[2][tid] + (double)sred[3][tid]);
+        if (live) {
+            // RETURNING atomic: the value comes back only after the add has been performed at the memory side, so once this wave
+            // has its results every add of this workgroup is globally visible (a no-return add is acknowledged earlier: with it
+            // the ticket below was seen to overtake an add about once per few thousand workgroups)
+            const double before = atomicAdd(&a.results[((long)id.s * a.B + id.b) * NP + tid],
+                                            (double)sred[0][tid] + (double)sred[1][tid] + (double)sred[2][tid] + (double)sred[3][tid]);
+            asm volatile("" ::"v"(before));
+        }
     }
-    // ---- the last workgroup to arrive finishes the losses (placement-independent: the adds are device-scope atomics, drained
-    //      by every issuing wave; agent-scope release, relaxed ticket, one agent-scope acquire in the last workgroup)
+    // ---- the last workgroup to arrive finishes the losses.  The payload is the fp64 atomics above: device-scope, performed at
+    //      the memory side (nothing of it sits in this CU's L1 / this XCD's L2), so there is nothing for a write-back fence to
+    //      write back -- the adding wave waits for its returned values (vmcnt), the workgroup meets at a barrier, then one lane
+    //      draws a ticket, and the last workgroup reads the accumulators with agent-scope loads.  Two levels of tickets -- per (scale, sample), then one per
+    //      launch -- because 2,568 workgroups on ONE word serialise at ~88 tickets/us (29 us, longer than the stencil itself).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == (unsigned)(a.nblocks - 1);
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
+        const unsigned per_image = (unsigned)(sc.tiles_x * sc.tiles_y);
+        const unsigned old = __hip_atomic_fetch_add(a.counter + 1 + id.s * a.B + id.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == per_image - 1) {
+            const unsigned old2 = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old2 == (unsigned)(a.nscales * a.B - 1);
         }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -365,6 +388,7 @@ __device__ __forceinline__ float tap_weight(int code, int dy, int dx) {
     return code == 0 ? kh : (code == 1 ? kv : (code == 2 ? krl : klr));
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
     // depth on the tile + 2-pixel halo; G = d loss / d s(p) (and the direction code) on the tile + 1-pixel halo
     __shared__ __attribute__((aligned(16))) float sd[(TH + 4) * LS];
@@ -378,17 +402,20 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
     const float go = a.gout ? a.gout[id.s] : 1.f;
     const float* coef = a.coef + (long)id.s * (2 * a.B + 1);
     const float cpos = coef[2 * id.b] * go, cneg = coef[2 * id.b + 1] * go;
-    const bool use_keep = coef[2 * a.B] != 0.f && sc.mask != nullptr;
+    const bool use_keep = FAST ? false : (coef[2 * a.B] != 0.f && sc.mask != nullptr);
     const bool silog = a.gt_depth != nullptr && id.s == 0;
-    const bool magnitude = sc.normal == nullptr;
+    const bool magnitude = FAST ? false : sc.normal == nullptr;
+    const int vec = FAST ? 1 : sc.vec;
+    const bool is_grad = FAST ? true : a.is_grad != 0, is_sigmoid = FAST ? true : a.is_sigmoid != 0;
+    const int from_inv = FAST ? 1 : a.from_inv;
 
     // ---- every global load of the workgroup is issued here: depth tile, labels / normals of the G region, inputs of the output phase
     constexpr int GITEMS = (TH + 2) * (TW / 4 + 2), NG = (GITEMS + 255) / 256;     // G region: interior groups of 4 + two halo columns per row
     DepthTile<2> tile;
     f32x4_t ge[NG], gn[NG], gm[NG];
     f32x4_t inv4[2], d4[2], oe4[2], om4[2];
-    if (a.is_grad) {
-        tile.issue(sc, id.b, id.x0, id.y0);
+    if (is_grad) {
+        tile.issue(sc, vec, id.b, id.x0, id.y0);
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int i = tid + k * 256;
@@ -399,9 +426,9 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
             ge[k] = f32x4_t{0.f, 0.f, 0.f, 0.f}; gn[k] = ge[k]; gm[k] = f32x4_t{1.f, 1.f, 1.f, 1.f};
             if (i < GITEMS && (unsigned)gy < (unsigned)sc.H) {
                 if (group) {
-                    ge[k] = load4(sc.edge, img + gy, id.x0 + j0, sc.W, sc.vec);
-                    if (!magnitude) gn[k] = load4(sc.normal, img + gy, id.x0 + j0, sc.W, sc.vec);
-                    if (use_keep) gm[k] = load4(sc.mask, img + gy, id.x0 + j0, sc.W, sc.vec);
+                    ge[k] = load4(sc.edge, img + gy, id.x0 + j0, sc.W, vec);
+                    if (!magnitude) gn[k] = load4(sc.normal, img + gy, id.x0 + j0, sc.W, vec);
+                    if (use_keep) gm[k] = load4(sc.mask, img + gy, id.x0 + j0, sc.W, vec);
                 } else if ((unsigned)(id.x0 + j0) < (unsigned)sc.W) {
                     const long idx = (img + gy) * sc.W + id.x0 + j0;
                     ge[k][0] = sc.edge[idx];
@@ -416,15 +443,15 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
         const int gy = id.y0 + r0 + 16 * ps;
         const bool ok = gy < sc.H && id.x0 + c < sc.W;
         const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-        inv4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, sc.vec) : z;
-        if (silog) d4[ps] = ok ? load4(a.gt_depth, img + gy, id.x0 + c, sc.W, sc.vec) : z;
-        if (!a.is_grad) {
-            oe4[ps] = ok ? load4(sc.edge, img + gy, id.x0 + c, sc.W, sc.vec) : z;
-            om4[ps] = (ok && use_keep) ? load4(sc.mask, img + gy, id.x0 + c, sc.W, sc.vec) : f32x4_t{1.f, 1.f, 1.f, 1.f};
+        inv4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, vec) : z;
+        if (silog) d4[ps] = ok ? load4(a.gt_depth, img + gy, id.x0 + c, sc.W, vec) : z;
+        if (!is_grad) {
+            oe4[ps] = ok ? load4(sc.edge, img + gy, id.x0 + c, sc.W, vec) : z;
+            om4[ps] = (ok && use_keep) ? load4(sc.mask, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{1.f, 1.f, 1.f, 1.f};
         }
     }
-    if (a.is_grad) {
-        tile.commit(sc, a.from_inv, id.x0, id.y0, sd);
+    if (is_grad) {
+        tile.commit(sc, from_inv, id.x0, id.y0, sd);
         __syncthreads();
 #pragma unroll
         for (int kq = 0; kq < NG; ++kq) {
@@ -463,11 +490,13 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
                         g = sqrtf(sv * sv + sh * sh + 1e-6f);
                         da = sv / g; db = sh / g;                  // a = v, b = h
                     }
-                    const float p = a.is_sigmoid ? sigmoidf(g - a.thresh) : g;
+                    float p, omp;                  // p and 1 - p without cancellation (see the forward kernel)
+                    if (is_sigmoid) { const float t = __expf(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
+                    else { p = g; omp = 1.f - g; }
                     const float e = e4[k];
                     const float keep = (use_keep && m4[k] == 0.f) ? 0.f : 1.f;
-                    const float dp = a.is_sigmoid ? p * (1.f - p) : 1.f;
-                    const float dg = keep * dp * (-cpos * e / (p + 0.001f) + cneg * (1.f - e) / (1.f - p + 0.001f));
+                    const float dp = is_sigmoid ? p * omp : 1.f;
+                    const float dg = keep * dp * (-cpos * e * rcpf(p + 0.001f) + cneg * (1.f - e) * rcpf(omp + 0.001f));
                     ga = dg * da; gb = dg * db;
                 }
                 const int o = ly * LS + 4 + j0 + k;
@@ -483,7 +512,7 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
         const int ly = r0 + 16 * ps, gy = id.y0 + ly;
         if (gy >= sc.H || id.x0 + c >= sc.W) continue;
         f32x4_t out = {0.f, 0.f, 0.f, 0.f};
-        if (a.is_grad) {
+        if (is_grad) {
             // d loss / d depth(q) = sum_p G(p) K_code(p)[q - p]: the 3 x 6 windows of G and code around the 4 pixels
             float wa[3][6], wb[3][6]; int wc[3][6];
             window(sga, ly + 1, c, wa);
@@ -506,9 +535,9 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
                         if (magnitude) dd += tap_weight(1, dy, dx) * wa[r][k + cc] + tap_weight(0, dy, dx) * wb[r][k + cc];
                         else dd += tap_weight(wc[r][k + cc], dy, dx) * wa[r][k + cc];
                     }
-                if (a.from_inv) {
+                if (from_inv) {
                     const float inv = inv4[ps][k];
-                    const float d = 1.f / fmaxf(inv, 1e-6f);
+                    const float d = rcpf(fmaxf(inv, 1e-6f));
                     dd = inv >= 1e-6f ? -dd * d * d : 0.f;
                 }
                 out[k] = dd;
@@ -518,10 +547,12 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float g = inv4[ps][k];
-                const float p = a.is_sigmoid ? sigmoidf(g - a.thresh) : g;
+                float p, omp;
+                if (is_sigmoid) { const float t = __expf(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
+                else { p = g; omp = 1.f - g; }
                 const float keep = (use_keep && m4[k] == 0.f) ? 0.f : 1.f;
-                const float dp = a.is_sigmoid ? p * (1.f - p) : 1.f;
-                out[k] = keep * dp * (-cpos * e4[k] / (p + 0.001f) + cneg * (1.f - e4[k]) / (1.f - p + 0.001f));
+                const float dp = is_sigmoid ? p * omp : 1.f;
+                out[k] = keep * dp * (-cpos * e4[k] * rcpf(p + 0.001f) + cneg * (1.f - e4[k]) * rcpf(omp + 0.001f));
             }
         }
         if (silog) {
@@ -536,7 +567,7 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
                 }
             }
         }
-        store4(sc.dpred, img + gy, id.x0 + c, sc.W, sc.vec, out);
+        store4(sc.dpred, img + gy, id.x0 + c, sc.W, vec, out);
     }
 }
 
@@ -592,6 +623,14 @@ struct mte_edge_scale_t { const float* pred; const float* edge; const float* nor
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // fills the grid geometry; returns the number of workgroups or -1
+// every scale in the training configuration (see FAST)?
+bool fast_config(const EdgeMulti& a) {
+    if (!a.from_inv || !a.is_grad || !a.is_sigmoid) return false;
+    for (int s = 0; s < a.nscales; ++s)
+        if (!a.s[s].vec || !a.s[s].normal || a.s[s].mask || a.s[s].gmap) return false;
+    return true;
+}
+
 int setup_scales(EdgeMulti& a, const mte_edge_scale_t* scales, int nscales, int B, bool backward) {
     if (!scales || nscales < 1 || nscales > MAXS || B < 1) return -1;
     int blocks = 0;
@@ -611,6 +650,7 @@ int setup_scales(EdgeMulti& a, const mte_edge_scale_t* scales, int nscales, int 
     return blocks;
 }
 long results_elems(int nscales, int B) { return ((long)nscales * B * NP + 1) & ~1L; }
+long counter_elems(int nscales, int B) { return (((long)nscales * B + 1) * 4 + 15) / 16 * 2; }      // doubles holding the tickets (16-byte multiple)
 
 }  // namespace
 
@@ -621,7 +661,7 @@ long mte_edge_loss_work_elems(const void* scales, int nscales, int B) {
     EdgeMulti a{};
     const int blocks = setup_scales(a, (const mte_edge_scale_t*)scales, nscales, B, false);
     if (blocks < 0) return -1;
-    return results_elems(nscales, B) + 2;
+    return results_elems(nscales, B) + counter_elems(nscales, B);
 }
 
 // Forward of `nscales` (<= 4) depth-edge losses in ONE launch, the silog loss of scale 0 fused in when gt_depth != NULL.
@@ -639,8 +679,9 @@ int mte_edge_loss_multi_fwd(const void* scales, int nscales, int B, int from_inv
     a.silog_loss = silog_loss; a.silog_aux = silog_aux;
     const long r = results_elems(nscales, B);
     a.results = work; a.counter = (unsigned*)(work + r);
-    if (hipMemsetAsync(work, 0, sizeof(double) * (r + 2), stream) != hipSuccess) return MTE_ERR_LAUNCH;     // accumulators + ticket
-    hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    if (mte_memset_async(work, 0, sizeof(double) * (r + counter_elems(nscales, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;     // accumulators + tickets
+    if (fast_config(a)) hipLaunchKernelGGL(edge_loss_fwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(edge_loss_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
 
@@ -655,7 +696,8 @@ int mte_edge_loss_multi_bwd(const void* scales, int nscales, int B, int from_inv
     if (gt_depth && !aligned16(gt_depth)) a.s[0].vec = 0;
     a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.thresh = thresh;
     a.coef = (float*)coef; a.gout = gout; a.gt_depth = gt_depth; a.silog_aux = (float*)silog_aux; a.silog_gout = silog_gout;
-    hipLaunchKernelGGL(edge_loss_bwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    if (fast_config(a)) hipLaunchKernelGGL(edge_loss_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(edge_loss_bwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
 
@@ -663,7 +705,7 @@ int mte_edge_loss_multi_bwd(const void* scales, int nscales, int B, int from_inv
 // doubles the caller must provide as `sums`: [B][13] accumulators (6 class-balance / BCE sums, 4 mask statistics, 3 unused) + the ticket
 long mte_edge_loss_sums_elems(int B, int H, int W) {
     (void)H; (void)W;
-    return results_elems(1, B) + 2;
+    return results_elems(1, B) + counter_elems(1, B);
 }
 
 // Forward pass of one scale.  sums: mte_edge_loss_sums_elems(B, H, W) doubles (content on entry ignored).  gmap nullable.
@@ -678,8 +720,8 @@ int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal,
     a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.finalize = 0; a.thresh = thresh;
     const long r = results_elems(1, B);
     a.results = sums; a.counter = (unsigned*)(sums + r);
-    if (hipMemsetAsync(sums, 0, sizeof(double) * (r + 2), stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    if (mte_memset_async(sums, 0, sizeof(double) * (r + counter_elems(1, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    hipLaunchKernelGGL(edge_loss_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
 // loss_this (nullable) <- weight * balanced BCE;  *loss_acc (nullable) += out_scale * loss;  coef: [2B + 1] floats
@@ -703,7 +745,7 @@ int mte_edge_loss_bwd(const float* pred, const float* edge, const float* normal,
 int mte_silog_fwd(const float* inv, const float* depth, long n, double* sums, float out_scale, float* loss_acc, float* loss_this, float* aux, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!inv || !depth || !sums || !aux) return MTE_ERR_ARG;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 3, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(sums, 0, sizeof(double) * 3, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     long g = (n + 255) / 256; if (g > 1024) g = 1024; if (g < 1) g = 1;
     hipLaunchKernelGGL(silog_fwd_kernel, dim3((unsigned)g), dim3(256), 0, stream, inv, depth, n, sums);
     hipLaunchKernelGGL(silog_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, out_scale, loss_acc, loss_this, aux);

@@ -243,7 +243,7 @@ extern "C" int mte_depth_metrics(const float* gt, const float* pred, int B, int 
     a.sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     a.top = H - h; a.left = (W - w) / 2;
     a.use_gt_scale = use_gt_scale;
-    if (hipMemsetAsync(workspace, 0, (size_t)mte_depth_metrics_workspace_bytes(B), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(workspace, 0, (size_t)mte_depth_metrics_workspace_bytes(B), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     const long total = (long)(a.y2 - a.y1) * (a.x2 - a.x1);
     if (total > 0) {
         const int bx = (int)std::min<long>(std::max<long>(cdiv(total, 256 * 8), 1), 1024);

@@ -354,7 +354,7 @@ int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float*
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dlogit || !dwb || !head_ok(C)) return MTE_ERR_ARG;
     const long npix = (long)B * H * W;
-    if (hipMemsetAsync(dwb, 0, sizeof(float) * (C * 9 + 1), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(dwb, 0, sizeof(float) * (C * 9 + 1), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     HeadArgs a{}; a.x = x; a.ldx = ldx; a.dlogit = dlogit; a.dw = dwb; a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
     const int ppb = 256 / (C / 8);
     // few, long-running blocks: every block ends with C*9+1 same-address global atomics (contended adds are ~14x slower);

@@ -642,8 +642,8 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
     if (n > 0 && n <= GN_SLAB_MAX && !(a.y2 && a.dbias)) {
         a.cps_shift = sh;
         // the slab kernels ADD this sample's part of dgamma / dbeta (the stream kernels overwrite them): clear them first
-        if (hipMemsetAsync(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-        if (hipMemsetAsync(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
         bool done;
         if (a.y2) done = launch_bwd_slab<T, true, false>(a, n, stream);
         else if (a.dbias) done = launch_bwd_slab<T, false, true>(a, n, stream);
@@ -692,7 +692,7 @@ int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float
                  int B, int HW, int C, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
-    if (!g_mte_gn_prezeroed && hipMemsetAsync(stats, 0, sizeof(double) * MTE_GN_REP * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (!g_mte_gn_prezeroed && mte_memset_async(stats, 0, sizeof(double) * MTE_GN_REP * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
     return dtype == MTE_DT_BF16 ? run_stats<bf16_t>(a, stream) : run_stats<float>(a, stream);
 }
@@ -729,8 +729,8 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dz || !y1 || !stats || !gamma || !beta || !red || !d1 || !dgamma || !dbeta || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     if (!g_mte_gn_prezeroed) {
-        if (hipMemsetAsync(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-        if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (mte_memset_async(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (dbias && mte_memset_async(dbias, 0, sizeof(float) * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
     }
     GnArgs a{}; a.dbias = dbias; a.dgamma = dgamma; a.dbeta = dbeta; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
     a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;

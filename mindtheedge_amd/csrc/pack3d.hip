@@ -978,7 +978,7 @@ int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, f
                           int B, int H, int W, int C, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dout || !dwb || !p3_ok(C)) return MTE_ERR_ARG;
-    if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
@@ -1023,7 +1023,7 @@ int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo,
                             int B, int H, int W, int C, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !dout || !dwb || !p3_ok(C)) return MTE_ERR_ARG;
-    if (hipMemsetAsync(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (mte_memset_async(dwb, 0, 112 * sizeof(float), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     P3Args a{}; a.x = x; a.ldx = ldx; a.o = dout; a.ldo = ldo; a.dw3 = dwb; a.B = B; a.H = H; a.W = W; a.C = C;
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 32 == 0 && C <= 512) {
         P3LArgs l = upl_args(B, H, W, C, g_p3_small_tiles != 0); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;

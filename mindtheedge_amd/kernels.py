@@ -172,7 +172,8 @@ class _ZeroArena:
     CHUNK = 8 << 20
 
     def __init__(self):
-        self.chunks = {}                 # (device, stream) -> [uint8 chunk, offset]
+        self.chunks = {}                 # (device, stream) -> [uint8 chunk, offset, capture id or None]
+        self.captured = []               # chunks created under HIP-graph capture (kept alive for the graphs that fill them)
         self.enabled = False
 
     def zeros(self, shape, dtype, device):
@@ -193,6 +194,8 @@ class _ZeroArena:
         # earlier capture (same capture stream, other graph) has no fill node here: buffers carved from it would accumulate
         # on stale statistics from the second replay on.
         if c is None or c[1] + nbytes > self.CHUNK or (capturing and c[2] != self.capture_id) or (not capturing and c[2] is not None):
+            if c is not None and c[2] is not None:
+                self.captured.append(c[0])                   # a captured graph keeps replaying into this chunk: never hand it back
             c = self.chunks[key] = [torch.zeros((self.CHUNK,), dtype=torch.uint8, device=device), 0,
                                     self.capture_id if capturing else None]
         out = c[0][c[1]:c[1] + nbytes].view(dtype)[:n].view(shape)

@@ -30,3 +30,11 @@ def test_bench_json_contract():
         assert o["bound"] == bound and o["unit"] == unit and o["peak"] > 0
         assert abs(o["frac"] - o["achieved"] / o["peak"]) < 1e-9 and 0 < o["frac"] < 1
         assert o["traffic"] is None or o["traffic"] > 0
+    # round 2: how the step was launched, the loss stencils as ONE forward + ONE backward launch, the all-reduce layout
+    assert d["step_launch"].split(" ")[0] in ("hip_graph", "eager")
+    loss = d["roofline_hbm"]["edge_loss_stencils"]
+    assert loss["launches_per_step"] <= 4 and loss["achieved"] > 0
+    ar = d["allreduce"]
+    assert ar["rccl_ranks"] == 1 and ar["allreduce_exposed_ms"] == 0.0
+    assert max(ar["buckets_mb"]) > 150 and ar["message_mb"] == 32.0            # the 151 MB pack5.conv weight rides in one bucket ...
+    assert max(ar["messages_per_bucket"]) >= 5                                   # ... which goes out as <= 32 MB messages
