@@ -184,6 +184,11 @@ int mte_edge_loss_finalize(const double* sums, int B, long numel, float weight, 
 int mte_edge_loss_bwd(const float* pred, const float* edge, const float* normal, const float* mask, const float* coef, const float* gout,
                       float* dpred, int B, int H, int W, int from_inv, int is_grad, int is_sigmoid, float thresh, mte_stream_t stream);
 
+/* F.interpolate(pred, size = label size, mode = 'bilinear') of GradLoss.forward (grad_loss.py:127; identity on the multi-scale
+ * training path, where every scale is compared at its own resolution) and its adjoint; fp32 [B,h,w] -> [B,H,W] */
+int mte_resize_bilinear_fwd(const float* x, float* y, int B, int h, int w, int H, int W, mte_stream_t stream);
+int mte_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, mte_stream_t stream);
+
 /* ---- silog supervised loss: depth2inv + sparse mask + SilogLoss (utils/depth.py:124-144; losses/supervised_loss.py:57-69,155-216) */
 int mte_silog_fwd(const float* inv, const float* depth, long n, double* sums, float out_scale, float* loss_acc, float* loss_this, float* aux, mte_stream_t stream);
 int mte_silog_bwd(const float* inv, const float* depth, const float* aux, const float* gout, float* dinv, long n, int accumulate, mte_stream_t stream);

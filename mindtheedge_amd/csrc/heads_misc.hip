@@ -314,6 +314,36 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
     }
 }
 
+// F.interpolate(x, size, mode='bilinear', align_corners=False) on fp32 [B,h,w] maps and its adjoint (GradLoss.forward's resize of
+// the prediction to the label size, grad_loss.py:127).  Source index as ATen's area_pixel_compute_source_index: scale * (dst + 0.5)
+// - 0.5, clamped at 0; weights in float.
+__device__ __forceinline__ void bilin_src(int dst, int in, float scale, int& i0, int& i1, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src; if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 < in - 1 ? i0 + 1 : i0;
+    l1 = src - (float)i0;
+}
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ dx, const float* __restrict__ dy,
+                                       int B, int h, int w, int H, int W) {
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const long n = (long)B * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W), Y = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+        int y0, y1, x0, x1; float ly, lx;
+        bilin_src(Y, h, sh, y0, y1, ly); bilin_src(X, w, sw, x0, x1, lx);
+        const long base = (long)b * h * w;
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+        if (y) {
+            y[i] = w00 * x[base + (long)y0 * w + x0] + w01 * x[base + (long)y0 * w + x1] + w10 * x[base + (long)y1 * w + x0] + w11 * x[base + (long)y1 * w + x1];
+        } else {
+            const float g = dy[i];
+            atomicAdd(dx + base + (long)y0 * w + x0, w00 * g); atomicAdd(dx + base + (long)y0 * w + x1, w01 * g);
+            atomicAdd(dx + base + (long)y1 * w + x0, w10 * g); atomicAdd(dx + base + (long)y1 * w + x1, w11 * g);
+        }
+    }
+}
+
 inline int stream_grid(long n, int per = 256) { long g = (n + per - 1) / per; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 inline bool head_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <= 64 && (cb & (cb - 1)) == 0; }
 
@@ -422,6 +452,22 @@ int mte_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        (float)bc1, (float)sqrt(bc2), gscale);
+    return mte_check_launch();
+}
+
+// y[B,H,W] = bilinear resize (align_corners = False, as F.interpolate) of x[B,h,w]
+int mte_resize_bilinear_fwd(const float* x, float* y, int B, int h, int w, int H, int W, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !y || B < 1 || h < 1 || w < 1 || H < 1 || W < 1) return MTE_ERR_ARG;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(stream_grid((long)B * H * W)), dim3(256), 0, stream, x, y, (float*)nullptr, (const float*)nullptr, B, h, w, H, W);
+    return mte_check_launch();
+}
+// dx[B,h,w] (overwritten) = adjoint of the resize applied to dy[B,H,W]
+int mte_resize_bilinear_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!dy || !dx || B < 1 || h < 1 || w < 1 || H < 1 || W < 1) return MTE_ERR_ARG;
+    if (mte_memset_async(dx, 0, sizeof(float) * (size_t)B * h * w, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(stream_grid((long)B * H * W)), dim3(256), 0, stream, (const float*)nullptr, (float*)nullptr, dx, dy, B, h, w, H, W);
     return mte_check_launch();
 }
 

@@ -1169,6 +1169,28 @@ class EdgeLossFn(torch.autograd.Function):
         return (dpred,) + (None,) * 10
 
 
+class BilinearResizeFn(torch.autograd.Function):
+    """F.interpolate(x, size=(H, W), mode='bilinear') for fp32 [B,1,h,w] maps -- the resize GradLoss.forward applies when the
+    prediction and the label differ in size (grad_loss.py:127)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W):
+        x = x.contiguous().float()
+        B, C, h, w = x.shape
+        y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        lib.mte_resize_bilinear_fwd(x.data_ptr(), y.data_ptr(), B * C, h, w, H, W, _stream())
+        ctx.geom = (B, C, h, w, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, h, w, H, W = ctx.geom
+        dy = dy.contiguous().float()
+        dx = torch.empty((B, C, h, w), dtype=torch.float32, device=dy.device)
+        lib.mte_resize_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), B * C, h, w, H, W, _stream())
+        return dx, None, None
+
+
 class _EdgeScale(ctypes.Structure):       # mte_edge_scale of include/mte_kernels.h
     _fields_ = [("pred", ctypes.c_void_p), ("edge", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("mask", ctypes.c_void_p),
                 ("gmap", ctypes.c_void_p), ("dpred", ctypes.c_void_p), ("H", ctypes.c_int), ("W", ctypes.c_int)]

@@ -44,8 +44,12 @@ class GradLoss(nn.Module):
         inverse depth.  `return_grad_map=False` skips writing the detached edge-strength map."""
         K._require_gpu(output)
         if tuple(output.shape[-2:]) != tuple(gt_edge.shape[-2:]):
-            raise NotImplementedError("prediction/label size mismatch (bilinear resize branch, grad_loss.py:127) is not on "
-                                      "the multi-scale training path: every scale is compared at its own resolution")
+            # reference :127: F.interpolate(output, size=label size, mode='bilinear').  The reference resizes the DEPTH (its
+            # caller applied inv2depth already); with the fused inv2depth the reciprocal is therefore taken first here too.
+            if from_inv_depth:
+                output = 1.0 / output.clamp(min=1e-6)
+                from_inv_depth = False
+            output = K.BilinearResizeFn.apply(output, gt_edge.shape[-2], gt_edge.shape[-1])
         loss, g = K.EdgeLossFn.apply(output, gt_edge, gt_normals if is_grad else None, gt_mask, self.weight,
                                      self.depth_edges_loss_pos_to_neg_weight, from_inv_depth, is_grad, is_sigmoid,
                                      float(sigmoid_thresh), return_grad_map)

@@ -57,8 +57,8 @@ def _enter(x, channels):
     """plain NCHW fp32 -> NHWC activation (zero channel padding to a multiple of 8); activations pass through."""
     if x.dtype == K.compute_dtype() and K.is_act(x) and x.shape[1] == K.round8(channels):
         return x
-    if x.shape[1] == channels and x.dtype == torch.float32 and x.is_contiguous():
-        return K.image_to_act(x)
+    if x.shape[1] == channels and x.dtype == torch.float32:
+        return K.image_to_act(x)                     # (makes a strided image contiguous first)
     if x.shape[1] == K.round8(channels):
         return K.as_act(x, K.compute_dtype())
     raise K.MteError("expected %d (or %d padded) input channels, got %s" % (channels, K.round8(channels), tuple(x.shape)))

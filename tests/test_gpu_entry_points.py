@@ -95,7 +95,25 @@ def test_infer_depth_function_matches_wrapper_depth(tmp_path):
         assert not w.training and tuple(depth.shape) == (2, 1, 64, 128)
         with torch.no_grad():
             want = inv2depth(w.depth(img, rgb_edge=None)["inv_depths"][0][0])
-        assert torch.equal(depth, want)
+        # two launches of the same bf16 forward differ by the order of the statistics / split-K atomics only
+        assert float((depth - want).abs().max() / want.abs().max()) < 2e-2
     finally:
         K.set_grad_sink(None)
         K.set_compute_dtype("bf16")
+
+
+def test_infer_edges_png_input_is_resized_and_written_as_npy_and_png(tmp_path, capsys):
+    """config #1's plumbing end to end: an image FILE of another size -> LANCZOS resize to the configured shape -> depth files."""
+    from PIL import Image
+    cfg = _yaml(tmp_path, 96, 160)
+    rng = np.random.default_rng(4)
+    src = os.path.join(tmp_path, "frame.png")
+    Image.fromarray(rng.integers(0, 256, size=(120, 200, 3), dtype=np.uint8)).save(src)
+    outdir = os.path.join(tmp_path, "out")
+    _run_main("infer_edges", ["infer_edges.py", "--config", cfg, "--input", src, "--output", outdir])
+    assert "wrote 1 depth maps" in capsys.readouterr().out
+    d = np.load(os.path.join(outdir, "00000000_regular.npy"))
+    assert d.shape == (96, 160) and np.isfinite(d).all()
+    png = np.asarray(Image.open(os.path.join(outdir, "00000000_regular.png")))
+    assert png.shape == (96, 160) and png.dtype == np.uint8 and png.max() == 255
+    assert np.abs(png.astype(np.float64) - np.rint(d / d.max() * 255.0)).max() <= 1

