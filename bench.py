@@ -359,6 +359,7 @@ def main():
     # an event pair around each of the ~280 conv launches per step costs ~50 us of GPU idle each (14 ms/step), which
     # would distort `value`; the kernel durations themselves are unaffected by the gaps.
     ksteps = 0
+    overlapped_records = []
     if timer:
         # the weight-gradient side stream is switched off for these steps: with kernels of two streams sharing the CUs an
         # event pair measures contention, not the kernel
@@ -372,6 +373,16 @@ def main():
             sync()
         timer.enabled = False
         K.use_wgrad_side_stream(not os.environ.get("MTE_NO_SIDE_STREAM"))
+        # the same event pairs with the two-stream schedule ON: what the conv kernels cost while they share the CUs with the other
+        # queue (the schedule `value` is measured on) -> roofline.frac_overlapped
+        serial_records = timer.records
+        timer.records = []
+        timer.enabled = "conv"
+        for _ in range(ksteps):
+            kstep()
+        sync()
+        timer.enabled = False
+        overlapped_records, timer.records = timer.records, serial_records
     if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -415,6 +426,10 @@ def main():
                                    "traffic": pmc_traffic_per_launch(args, B, H, W),
                                    "launches_per_step": n / ksteps, "avg_launch_ms": tot_t / n * 1e3,
                                    "conv_ms_per_step": tot_t / ksteps * 1e3, "timed_steps": ksteps,
+                                   "frac_overlapped": (alg / (sum(e0.elapsed_time(e1) for _, e0, e1, _, _ in overlapped_records) * 1e-3) / 1e12 / peak)
+                                   if overlapped_records else None,
+                                   "conv_ms_per_step_overlapped": (sum(e0.elapsed_time(e1) for _, e0, e1, _, _ in overlapped_records) / ksteps)
+                                   if overlapped_records else None,
                                    "algorithmic_flops_per_step": alg / ksteps, "executed_flops_per_step": tot_f / ksteps,
                                    "by_kernel": {k: {"launches_per_step": v[0] / ksteps, "ms_per_step": v[1] / ksteps * 1e3,
                                                      "executed_tflops": v[2] / v[1] / 1e12 if v[1] > 0 else None} for k, v in s.items()}}

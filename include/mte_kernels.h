@@ -70,8 +70,9 @@ int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout,
                           int Cin_p, int Cout_p, int dtype, mte_stream_t stream);
 /* dgrad pack derived from an existing forward pack */
 int mte_pack_conv_weights_bwd(const void* wfwd, void* wbwd, int Cout, int KH, int KW, int Cin_p, int dtype, mte_stream_t stream);
-/* sum of the `parts` partial stages -> OIHW fp32 gradient (drops channel padding) */
-int mte_unpack_conv_wgrad(const float* dw_stage, int parts, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, mte_stream_t stream);
+/* sum of the `parts` partial stages -> OIHW fp32 gradient (drops channel padding).  The stage is scratch: with more than 32 parts
+ * (LDS-patch weight gradient: one slab per workgroup) a parallel first level adds parts 1.. into part 0 before the transpose. */
+int mte_unpack_conv_wgrad(float* dw_stage, int parts, float* dw_oihw, int Cout, int Cin, int KH, int KW, int Cin_p, mte_stream_t stream);
 /* out[N] = column sums of y[M][N] (conv bias gradient) */
 int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, mte_stream_t stream);
 

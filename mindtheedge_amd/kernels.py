@@ -394,7 +394,8 @@ def _splitk_workspace(M, N, device):
 # atomics, one more barrier and a tail of fp64 atomics that must land before the kernel retires).
 _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30,
         "conv_epilogue_stats": bool(os.environ.get("MTE_STATS_FUSION")),
-        "no_fork_accumulate": bool(os.environ.get("MTE_NO_FORK_ACCUM"))}
+        "no_fork_accumulate": bool(os.environ.get("MTE_NO_FORK_ACCUM")),
+        "patch_wgrad_slabs": not os.environ.get("MTE_PATCH_WGRAD_ATOMICS")}
 
 
 def use_pack_folding(flag):
@@ -516,10 +517,13 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     # generic kernel's <= 32 splits -- the patch kernel's 128..512 workgroup groups stay on atomics: summing that many parts
     # in the unpack pass measured 7 % slower)
     per = cout * kh * kw * Cp
-    cap = max(1, min(32, (96 << 20) // (4 * per)))
+    patch = _patch_ok(W, Cp, cout, kh, kw, x.dtype)
+    # the LDS-patch kernel runs 128..512 workgroups per layer: one slab each (plain stores), combined by a two-level reduction
+    # (mte_unpack_conv_wgrad) -- its slabs are 70-210 KB, so even 512 of them stay near 100 MB
+    cap = max(1, min(512, (192 << 20) // (4 * per))) if patch and _cfg["patch_wgrad_slabs"] else max(1, min(32, (96 << 20) // (4 * per)))
     stage = torch.empty((cap, cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
     parts = ctypes.c_int(1)
-    if _patch_ok(W, Cp, cout, kh, kw, x.dtype):
+    if patch:
         lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, Cp, cout, kh, kw, st)
     else:
         lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, Cp, cout, kh, kw, _dt(x), st)
