@@ -40,7 +40,12 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
  * GroupNorm(16) sum / sum-of-squares of the stored outputs are accumulated in the epilogue and *gn_stats_done = 1;
  * otherwise *gn_stats_done = 0 and the caller runs mte_gn_stats.
  * accumulate = 1: y += conv(x) (sum formed in fp32, rounded once): the second data gradient of an activation with two consumers
- * lands in the first one's buffer instead of going through a separate add. */
+ * lands in the first one's buffer instead of going through a separate add.  `accumulate` is a bit set: MTE_CONV_ACCUMULATE (1) and
+ * MTE_CONV_SOLO (2) = no kernel of another stream is expected to run beside this launch (forward pass, inference), so the 256 x 128
+ * tile may use its 3-slot-ring variant that puts two workgroups on a CU and claims 148 of the 160 KB of LDS: measured 15-20 % faster
+ * on the short-reduction layers when alone, but slower for the step when the weight-gradient stream needs LDS on the same CUs. */
+#define MTE_CONV_ACCUMULATE 1
+#define MTE_CONV_SOLO 2
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
                      float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, int accumulate, mte_stream_t stream);
@@ -57,7 +62,10 @@ int mte_set_option(int option, int value);
  *   7 min tiles for the big igemm tiles (224)   8 wgrad 8/16-wave tiles (1)   9 wgrad workgroup target (512)
  *   11 patch conv: 0/1 tall 16x32 tiles, >= 100 = workgroup target of the patch wgrad (512)
  *   13 GroupNorm single-pass slab kernels (1 [default], 0 = streaming kernels only)
- *   14 GroupNorm second passes walk the samples in reverse order (Infinity-Cache reuse; 1 [default]) */
+ *   14 GroupNorm second passes walk the samples in reverse order (Infinity-Cache reuse; 1 [default])
+ *   15 implicit GEMM, 8-wave 256x128 tile: 0 [default] 4-slot LDS ring, 3-slot / two workgroups per CU for MTE_CONV_SOLO launches;
+ *      1 = 6 slots, 3 = always 3 slots x 2 workgroups, 4 = always 4 slots
+ *   17 implicit GEMM main-loop ablation (tools/igemm_ablate.py): leave out 1 MFMAs | 2 in-loop LDS-DMA | 4 fragment reads; results are garbage */
 int mte_debug_set(int key, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
  * pixels is split over workgroups; when their number fits stage_parts each one stores its PARTIAL gradient in its own part

@@ -34,6 +34,7 @@ struct ConvArgs {
     int splits; float* ws;          // split-K: partial sums are atomically added into ws[M][N] (fp32), finished separately
     int accum;                      // 1: y += conv (sum formed in fp32, rounded once) -- second gradient of a two-consumer activation
     double* gn_stats; int gn_gs;    // optional fused GroupNorm statistics: stats[MTE_GN_REP][B][16][2] += (sum, sumsq) of the stored outputs
+    int solo;                       // host-side hint (MTE_CONV_SOLO): nothing runs beside this launch on another stream
 };
 
 template <typename T> struct Mma;
@@ -61,8 +62,19 @@ __device__ u32x4_t g_zero16 = {0u, 0u, 0u, 0u};      // source of zero chunks fo
 // filter tap and the K advance is a wave-uniform SGPR offset, so a K-step costs ~4 VALU instead of ~130 -- the loader's
 // address arithmetic, not HBM or LDS, was what held the MFMA pipe at ~25 %.  Out-of-image taps use an out-of-range offset
 // (the buffer bounds check returns zeros).
-template <typename T, int WM, int WN, int TM, int TN, int LD>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
+// RING = LDS ring slots of the DMA loaders (RING - 1 K-steps in flight); MINW = waves per SIMD the register allocation must allow.
+// Measured on the 8-wave 256 x 128 tile (round-2 A/B, profiles/README.md): six slots instead of four change nothing (7.56 vs
+// 7.52 ms / step over all launches) -- the loop is not short of bytes in flight; three slots with two workgroups per CU (74 KB
+// each, MINW = 4) are 15-20 % faster on the short-reduction layers because one workgroup's prologue / epilogue overlaps the
+// other's main loop, but the pair claims 148 of the 160 KB of LDS and slows the step down when the weight-gradient stream wants
+// the same CUs, so it is used for MTE_CONV_SOLO launches only (forward pass, inference).  Two wave groups half a K-step apart
+// and fragment reads one K-step ahead of the MFMAs were also tried: no gain, removed.  tools/igemm_ablate.py (ABL below) shows
+// why: LDS-DMA alone takes as long as the MFMAs alone (~ 50 of the CU's 64 B / clk L1 -> LDS path), so the tile's bytes per
+// flop, not the schedule, bound the loop.
+// ABL (development, tools/igemm_ablate.py): bit set of main-loop pieces to LEAVE OUT (1 MFMAs, 2 in-loop LDS-DMA, 4 fragment ds_reads) --
+// the time that remains when a piece is removed says which pipe the loop is waiting on.  Results are garbage when ABL != 0.
+template <typename T, int WM, int WN, int TM, int TN, int LD, int RING = 4, int MINW = 1, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool DMA = LD != 0;
     constexpr int NTHR = WM * WN * 64;                 // one wave per (TM*32) x (TN*32) sub-tile
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr int A_CH = BM * 4 / NTHR;                 // 16-B chunks of the A tile per thread
     static_assert(BM * 4 % NTHR == 0, "the A tile must split evenly over the threads");
     constexpr int B_CH = (BN * 4 + NTHR - 1) / NTHR;         // (BN = 32: only threads < 128 load)
-    constexpr int ST = DMA ? 4 : 2;                    // LDS ring depth
+    constexpr int ST = DMA ? RING : 2;                 // LDS ring depth
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                                   // [ST][BM*64]
     char* sB = smem + ST * BM * 64;                    // [ST][BN*64]
@@ -248,34 +260,62 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             u32x4_t fa[TM], fb[TN];
+            if constexpr (ABL & 4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { fa[i] = u32x4_t{(unsigned)lane, (unsigned)i, 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(fa[i])); }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { fb[j] = u32x4_t{(unsigned)lane, (unsigned)j, 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(fb[j])); }
+            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(pA + lds_chunk_off((wm * TM + i) * 32 + r, 2 * kk + h));
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(pB + lds_chunk_off((wn * TN + j) * 32 + r, 2 * kk + h));
+            }
+            if constexpr (ABL & 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
+            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+            }
         }
     };
     if constexpr (DMA) {
-        // 4-slot LDS ring filled by LDS-DMA three K-steps ahead.  vmcnt is COUNTED (two younger stages stay in
+        // ST-slot LDS ring filled by LDS-DMA ST-1 K-steps ahead.  vmcnt is COUNTED (the younger stages stay in
         // flight across the barrier): the only wait per K-step is for the stage about to be consumed, so HBM/L2
-        // latency (1-2k cycles under load) is covered by three K-steps of MFMA work instead of one.
+        // latency (1-2k cycles under load) is covered by ST-1 K-steps of MFMA work instead of one.
         static_assert((BN * 4) % NTHR == 0, "every wave must issue the same number of DMA instructions per stage");
+        static_assert(ST == 3 || ST == 4 || ST == 6, "wait ladder below is written for 3, 4 or 6 slots");
         constexpr int LPS = A_CH + B_CH;
+        constexpr int AHEAD = ST - 1;
         const int nst = s_end - s_begin;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < AHEAD; ++p)
             if (p < nst) { if constexpr (LD == 2) dma_fast(s_begin + p, p); else dma_step(s_begin + p, p); }
         for (int i = 0; i < nst; ++i) {
-            const int rem = nst - 1 - i;
-            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int rem = nst - 1 - i;                   // stages issued after stage i and possibly still in flight: min(rem, AHEAD - 1)
+            if constexpr (ST == 6) {
+                if (rem >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPS) : "memory");
+                else if (rem == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+                else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if constexpr (ST == 4) {
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
-            if (i + 3 < nst) { if constexpr (LD == 2) dma_fast(s_begin + i + 3, (i + 3) & 3); else dma_step(s_begin + i + 3, (i + 3) & 3); }
-            compute(i & 3);
+            if constexpr (!(ABL & 2))
+            if (i + AHEAD < nst) { if constexpr (LD == 2) dma_fast(s_begin + i + AHEAD, (i + AHEAD) % ST); else dma_step(s_begin + i + AHEAD, (i + AHEAD) % ST); }
+            compute(i % ST);
         }
     } else {
         if (s_begin < s_end) {
@@ -430,6 +470,9 @@ inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems, i
     return (int)(s < 1 ? 1 : s);
 }
 
+int g_igemm_ablate = 0;                              // development knob (mte_debug_set(17, v)): main-loop ablation, see ABL
+int g_igemm_ring6 = 0;                               // development knob (mte_debug_set(15, v)) for the 8-wave 256 x 128 tile: 1 = 6-slot ring, 3 = 3-slot ring with two workgroups per CU
+
 template <typename T, int WM, int WN, int TM, int TN>
 int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
@@ -449,6 +492,43 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
             const long es = (long)sizeof(T);
             const bool fast = g_igemm_dma == 1 && a.Cin_p % (4 * Elem<T>::PER16) == 0 &&
                               ((a.M - 1) * a.ldx + a.Cin_p) * es < 0x7ff00000L && (long)a.N * a.KH * a.KW * a.Cin_p * es < 0x7ff00000L;
+            if constexpr (sizeof(T) == 2 && ((BM == 256 && BN == 128) || (BM == 128 && BN == 128) || (BM == 256 && BN == 256))) {
+                if (fast && g_igemm_ablate) {
+                    const dim3 g((unsigned)(tiles * a.splits)), b(NTHR);
+                    switch (g_igemm_ablate) {
+                    case 1: hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 4, 1, 1>), g, b, lds4, st, a); break;
+                    case 2: hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 4, 1, 2>), g, b, lds4, st, a); break;
+                    case 3: hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 4, 1, 3>), g, b, lds4, st, a); break;
+                    case 4: hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 4, 1, 4>), g, b, lds4, st, a); break;
+                    case 5: hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 4, 1, 5>), g, b, lds4, st, a); break;
+                    case 6: hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 4, 1, 6>), g, b, lds4, st, a); break;
+                    default: hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 4, 1, 7>), g, b, lds4, st, a); break;
+                    }
+                    goto launched;
+                }
+            }
+            if constexpr (sizeof(T) == 2 && BM == 256 && BN == 128) {
+                if (fast && (g_igemm_ring6 == 3 || (g_igemm_ring6 == 0 && a.solo))) {
+                    constexpr size_t lds3 = 3 * (BM + BN) * 64 + 256;
+                    static bool attr3 = false;
+                    if (!attr3) {
+                        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WM, WN, TM, TN, 2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return MTE_ERR_LAUNCH;
+                        attr3 = true;
+                    }
+                    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 3, 4>), dim3((unsigned)(tiles * a.splits)), dim3(NTHR), lds3, st, a);
+                    goto launched;
+                }
+                if (fast && g_igemm_ring6 == 1) {
+                    constexpr size_t lds6 = 6 * (BM + BN) * 64 + 256;
+                    static bool attr = false;
+                    if (!attr) {
+                        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WM, WN, TM, TN, 2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6) != hipSuccess) return MTE_ERR_LAUNCH;
+                        attr = true;
+                    }
+                    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2, 6>), dim3((unsigned)(tiles * a.splits)), dim3(NTHR), lds6, st, a);
+                    goto launched;
+                }
+            }
             if (fast) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 2>), dim3((unsigned)(tiles * a.splits)), dim3(NTHR), lds4, st, a);
             else hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, 1>), dim3((unsigned)(tiles * a.splits)), dim3(NTHR), lds4, st, a);
             goto launched;
@@ -1200,6 +1280,8 @@ int mte_debug_set(int key, int value) {
     if (key == 1) return mtei_set_pack3d_lds(value);
     if (key == 2 || key == 3) return mtei_set_gn(key - 2, value);
     if (key == 13) return mtei_set_gn(2, value);
+    if (key == 15) { g_igemm_ring6 = value; return MTE_OK; }
+    if (key == 17) { g_igemm_ablate = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
@@ -1219,7 +1301,7 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
     if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
-    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, accumulate ? 1 : 0, gn_stats, 1};
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, accumulate & 1, gn_stats, 1, (accumulate >> 1) & 1};
     if (gn_stats_done) *gn_stats_done = 0;
     if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream, gn_stats_done);
     if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream, gn_stats_done);

@@ -497,23 +497,40 @@ struct P3LArgs {
     float* dwb;                        // [112]
     int B, H, W, C, TH, TW;
     int tiles_h, tiles_w, ntiles;
+    int dshift, tshift;                // matrix-core weight gradient: log2(depth pairs per pixel) or -1 when not a power of two; log2(TW)
 };
 
-// stage packed P tile: tile[(ph)][(pw)][d], d = 4c + s, origin (h0-1, w0-1), zero outside the image
+// stage packed P tile: tile[(ph)][(pw)][d], d = 4c + s, origin (h0-1, w0-1), zero outside the image.
+// One work item = (packed pixel, 8 channels): the four sub-pixel chunks are loaded as 16 bytes each, interleaved in registers
+// (depth d = 4c + s: word k of the 32 consecutive depths pairs sub-pixels 2(k&1), 2(k&1)+1 of channel k>>1) and stored as four
+// ds_write_b128 -- the element-wise version issued 32 two-byte LDS stores per item.
 __device__ __forceinline__ void stage_packed_tile(const P3LArgs& a, bf16_t* tile, int b, int h0, int w0) {
-    const int PHu = 2 * (a.TH + 2), PWu = 2 * (a.TW + 2), cpp = a.C >> 3, D = 4 * a.C;
+    const int PH = a.TH + 2, PW = a.TW + 2, cpp = a.C >> 3, D = 4 * a.C;
     const int H2 = a.H >> 1, W2 = a.W >> 1;
-    const int total = PHu * PWu * cpp;
+    const int total = PH * PW * cpp;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int cc = idx % cpp; int t = idx / cpp;
-        const int px = t % PWu, py = t / PWu;
-        const int hh = h0 - 1 + (py >> 1), ww = w0 - 1 + (px >> 1);
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if ((unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2)
-            v = *(const u32x4_t*)(a.x + (((long)b * a.H + 2 * hh + (py & 1)) * a.W + 2 * ww + (px & 1)) * a.ldx + cc * 8);
-        bf16_t* dstp = tile + ((py >> 1) * (a.TW + 2) + (px >> 1)) * LDP(D) + 32 * cc + ((py & 1) * 2 + (px & 1));
+        const int cc = idx % cpp; const int t = idx / cpp;
+        const int px = t % PW, py = t / PW;
+        const int hh = h0 - 1 + py, ww = w0 - 1 + px;
+        u32x4_t v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dstp[8 * i] = (bf16_t)(v[i] & 0xffffu); dstp[8 * i + 4] = (bf16_t)(v[i] >> 16); }
+        for (int sp = 0; sp < 4; ++sp) v[sp] = u32x4_t{0u, 0u, 0u, 0u};
+        if ((unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2) {
+            const bf16_t* src = a.x + (((long)b * a.H + 2 * hh) * a.W + 2 * ww) * a.ldx + cc * 8;
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) v[sp] = *(const u32x4_t*)(src + ((long)(sp >> 1) * a.W + (sp & 1)) * a.ldx);
+        }
+        bf16_t* dstp = tile + (py * PW + px) * LDP(D) + 32 * cc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                       // output chunk q: depths 8q .. 8q+7 = channels 2q, 2q+1
+            u32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                   // word k of the chunk: channel 2q + (k >> 1), sub-pixels 2(k&1), 2(k&1)+1
+                const unsigned lo = v[2 * (k & 1)][q], hi = v[2 * (k & 1) + 1][q];
+                o[k] = (k >> 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            }
+            *(u32x4_t*)(dstp + 8 * q) = o;
+        }
     }
 }
 
@@ -908,6 +925,137 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a)
         atomicAdd(a.dwb + threadIdx.x, sred[threadIdx.x] + sred[112 + threadIdx.x] + sred[224 + threadIdx.x] + sred[336 + threadIdx.x]);
 }
 
+// ---- dw3 / db3 on the matrix cores (pack and unpack).  dW3[f][tap] = sum over positions of G[f][pos] * V[pos + off(tap)] is a GEMM
+// with M = 4 features, N = 27 taps (+ one all-ones column that yields db3) and K = every (pixel, depth) position of the volume:
+// one v_mfma_f32_32x32x16_bf16 takes 16 positions (2 x 8 consecutive depths of one pixel) for all 4 x 28 outputs at once.  Only 4
+// of the 32 rows carry data -- a tenth of the MFMA rate is still 4x what the fp32-VALU version above reached (it spent 864 FMAs +
+// 36 window reads per 8 depths and ran 6x over its HBM time).
+//   A operand: lane (row f = lane & 31 < 4, half = lane >> 5) holds G[f][pixel][d0 + 8 half .. +8) -- a 16-byte global load (pack)
+//              or four 4-byte loads from the pixel-shuffled gradient + a 16-bit interleave (unpack); rows >= 4 are zero.
+//   B operand: lane (column = tap = (kd*3 + kh)*3 + kw) holds V[pixel + (kh-1, kw-1)][d0 + 8 half + kd - 1 .. +8) from the LDS tile:
+//              the aligned 16-byte chunk plus the 4-byte words either side of it, shifted by one element with v_alignbyte
+//              according to the lane's kd.  The 8 pad elements after every pixel's depths (and 16 bytes in front of the tile)
+//              are kept zero, so depths -1 and D read as zero without a branch.
+//   Accumulators: lane (column = tap) of half 0 holds rows 0..3 = the four features in registers 0..3.
+template <bool UNPACK>
+__global__ __launch_bounds__(512) void conv3d_bwd_weight_mfma_kernel(P3LArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)(smem_ + 16);
+    __shared__ float sred[8 * 112];
+    __shared__ __attribute__((aligned(16))) char scratch[8 * 2 * 1024];        // per wave: two 1 KB gradient blocks (see the round loop)
+    const int D = UNPACK ? a.C : 4 * a.C;
+    const int H2 = UNPACK ? a.H : a.H >> 1, W2 = UNPACK ? a.W : a.W >> 1;     // volume extent in pixels
+    const int PW = a.TW + 2, npix = (a.TH + 2) * PW, dbs = D >> 3, dpairs = D >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the item index arithmetic stays on the SALU)
+    const int r = lane & 31, half = lane >> 5, nwaves = blockDim.x >> 6;
+    const int tap = r < 27 ? r : 0;
+    const int kd = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+    const int tapoff = (kh * PW + kw) * LDP(D) + 8 * half;                      // elements, relative to the item's pixel / depth pair
+    const bool up1 = kd >= 1;
+    const unsigned sh = kd == 1 ? 0u : 2u;
+    if (threadIdx.x == 0) *(u32x4_t*)smem_ = u32x4_t{0u, 0u, 0u, 0u};
+    for (int p = threadIdx.x; p < npix; p += blockDim.x) *(u32x4_t*)(tile + p * LDP(D) + D) = u32x4_t{0u, 0u, 0u, 0u};
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+        int b, h0, w0;
+        if constexpr (UNPACK) up_tile_coords(a, tl, b, h0, w0); else tile_coords(a, tl, b, h0, w0);
+        __syncthreads();
+        if constexpr (UNPACK) {
+            for (int idx = threadIdx.x; idx < npix * dbs; idx += blockDim.x) {
+                const int dc = idx % dbs; const int p = idx / dbs;
+                const int hh = h0 - 1 + p / PW, ww = w0 - 1 + p % PW;
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W)
+                    v = *(const u32x4_t*)(a.x + (((long)b * a.H + hh) * a.W + ww) * a.ldx + dc * 8);
+                *(u32x4_t*)(tile + p * LDP(D) + dc * 8) = v;
+            }
+        } else {
+            stage_packed_tile(a, tile, b, h0, w0);
+        }
+        __syncthreads();
+        // A wave owns the tile pixels p = wave, wave + nwaves, ...; one ROUND = one pixel x U depth pairs (128 depths).  The round's
+        // gradient block (4 features x 128 depths = 1 KB) is fetched by ONE 16-byte load per lane, a round ahead, parked in the wave's
+        // LDS scratch, and the 8 lanes of an item's A fragment pick their chunks out of it: fetching fragments straight from global
+        // memory used 8 of 64 lanes per load instruction (unpack: 4 instructions per item) and the kernel ran at the texture
+        // addresser's instruction rate, 180-370 cycles per MFMA.
+        constexpr int U = 8;
+        const int rpp = (dpairs + U - 1) / U;                    // rounds per pixel
+        const int npx = (a.TH * a.TW - wave + nwaves - 1) / nwaves;
+        const int nrounds = npx * rpp;
+        auto fetch = [&](int k) -> u32x4_t {                     // this lane's 16 bytes of round k (zeros outside the image / depth range)
+            const int j = k / rpp, dp0 = (k - j * rpp) * U;
+            const int p = wave + j * nwaves;
+            const int pw = p & (a.TW - 1), ph = p >> a.tshift;   // (TW is a power of two in every tile table)
+            const int h = h0 + ph, w = w0 + pw;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (h < H2 && w < W2) {
+                const int f = lane >> 4;
+                if constexpr (UNPACK) {
+                    const int sp = (lane >> 2) & 3, q = lane & 3;                       // sub-pixel, 8-channel part
+                    if (dp0 * 4 + 8 * q < (a.C >> 2))
+                        v = *(const u32x4_t*)(a.o + (((long)b * 2 * a.H + 2 * h + (sp >> 1)) * (2 * a.W) + 2 * w + (sp & 1)) * a.ldo + f * (a.C >> 2) + dp0 * 4 + 8 * q);
+                } else {
+                    const int c = lane & 15;
+                    if (dp0 * 16 + c * 8 < D) v = *(const u32x4_t*)(a.o + (((long)b * H2 + h) * W2 + w) * a.ldo + f * D + dp0 * 16 + c * 8);
+                }
+            }
+            return v;
+        };
+        u32x4_t cur = nrounds > 0 ? fetch(0) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (int k = 0; k < nrounds; ++k) {
+            u32x4_t nxt = {0u, 0u, 0u, 0u};
+            if (k + 1 < nrounds) nxt = fetch(k + 1);
+            const int j = k / rpp, dp0 = (k - j * rpp) * U;
+            const int p = wave + j * nwaves;
+            const int pw = p & (a.TW - 1), ph = p >> a.tshift;
+            if (h0 + ph < H2 && w0 + pw < W2) {                  // wave-uniform
+                char* sc = scratch + (wave * 2 + (k & 1)) * 1024;
+                *(u32x4_t*)(sc + lane * 16) = cur;
+                const bf16_t* pb0 = tile + (ph * PW + pw) * LDP(D) + tapoff + dp0 * 16;
+                const int nd = min(U, dpairs - dp0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u >= nd) break;                          // wave-uniform
+                    u32x4_t fa = {0u, 0u, 0u, 0u};
+                    if (r < 4) {
+                        if constexpr (UNPACK) {
+                            // depths d0 .. d0+7 of feature r: channels (d0 >> 2, + 1) at the four sub-pixel positions = word 2(u&1) + half of part u >> 1
+                            const char* g = sc + (r * 16 + (u >> 1)) * 16 + (2 * (u & 1) + half) * 4;
+                            const unsigned u0 = *(const unsigned*)g, u1 = *(const unsigned*)(g + 64), u2 = *(const unsigned*)(g + 128), u3 = *(const unsigned*)(g + 192);
+                            fa = u32x4_t{(u0 & 0xffffu) | (u1 << 16), (u2 & 0xffffu) | (u3 << 16), (u0 >> 16) | (u1 & 0xffff0000u), (u2 >> 16) | (u3 & 0xffff0000u)};
+                        } else {
+                            fa = *(const u32x4_t*)(sc + (r * 16 + 2 * u + half) * 16);
+                        }
+                    }
+                    const bf16_t* pb = pb0 + u * 16;
+                    const u32x4_t c = *(const u32x4_t*)pb;
+                    const unsigned x0 = *(const unsigned*)(pb - 2), x5 = *(const unsigned*)(pb + 8);
+                    const unsigned y0 = up1 ? c[0] : x0, y1 = up1 ? c[1] : c[0], y2 = up1 ? c[2] : c[1], y3 = up1 ? c[3] : c[2], y4 = up1 ? x5 : c[3];
+                    u32x4_t fb = {__builtin_amdgcn_alignbyte(y1, y0, sh), __builtin_amdgcn_alignbyte(y2, y1, sh),
+                                  __builtin_amdgcn_alignbyte(y3, y2, sh), __builtin_amdgcn_alignbyte(y4, y3, sh)};
+                    if (r >= 27) fb = r == 27 ? u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : u32x4_t{0u, 0u, 0u, 0u};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb), acc, 0, 0, 0);
+                }
+            }
+            cur = nxt;
+        }
+    }
+    // D[row][col]: lane holds column lane & 31, rows (e & 3) + 8 (e >> 2) + 4 half: features 0..3 = registers 0..3 of half 0
+    if (half == 0 && r < 28) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) sred[wave * 112 + (r < 27 ? f * 27 + r : 108 + f)] = acc[f];
+    }
+    __syncthreads();
+    if (threadIdx.x < 112) {
+        float t = 0.f;
+        for (int wv = 0; wv < nwaves; ++wv) t += sred[wv * 112 + threadIdx.x];
+        atomicAdd(a.dwb + threadIdx.x, t);
+    }
+}
+
 inline P3LArgs upl_args(int B, int H, int W, int C, bool half_tile = false) {
     P3LArgs a{}; a.B = B; a.H = H; a.W = W; a.C = C;
     P3Tile t = up_tile(C);
@@ -917,7 +1065,7 @@ inline P3LArgs upl_args(int B, int H, int W, int C, bool half_tile = false) {
     return a;
 }
 
-template <typename KF> int launch_p3l(KF kf, P3LArgs a, int grid, hipStream_t st, size_t lds_override = 0) {
+template <typename KF> int launch_p3l(KF kf, P3LArgs a, int grid, hipStream_t st, size_t lds_override = 0, int threads = 256) {
     const size_t lds = lds_override ? lds_override : p3_lds_bytes(a.C);
     static const void* done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool seen = false;
@@ -926,7 +1074,7 @@ template <typename KF> int launch_p3l(KF kf, P3LArgs a, int grid, hipStream_t st
         if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess) return MTE_ERR_LAUNCH;
         for (int i = 0; i < 8; ++i) if (!done[i]) { done[i] = (const void*)kf; break; }
     }
-    hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kf, dim3(grid), dim3(threads), lds, st, a);
     return mte_check_launch();
 }
 
@@ -938,10 +1086,12 @@ inline P3LArgs p3l_args(int B, int H, int W, int C) {
 }
 
 int g_p3_lds = 2;                                   // development knob (mte_debug_set(1, v))
+int g_p3_mfma_threads = 512;
+int g_p3_mfma = 1;                                  // development knob (mte_debug_set(1, 200 + v)): conv3d weight gradients on the matrix cores
 
 }  // namespace
 
-extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
+extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
 
 
 extern "C" {
@@ -983,6 +1133,8 @@ int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, f
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
         P3LArgs l = p3l_args(B, H, W, C); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;
+        { const int dpairs = 4 * C / 16; l.dshift = (dpairs & (dpairs - 1)) == 0 ? __builtin_ctz(dpairs) : -1; l.tshift = __builtin_ctz(l.TW); }
+        if (g_p3_mfma) return launch_p3l(conv3d_bwd_weight_mfma_kernel<false>, l, l.ntiles < 768 ? l.ntiles : 768, stream, p3_lds_bytes(C) + 16, g_p3_mfma_threads);
         return launch_p3l(pack3d_bwd_weight_lds_kernel, l, l.ntiles < 512 ? l.ntiles : 512, stream);
     }
     if (C <= 256) a.total *= 2;
@@ -1029,6 +1181,8 @@ int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo,
         P3LArgs l = upl_args(B, H, W, C, g_p3_small_tiles != 0); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;
         const size_t lds = (size_t)(l.TH + 2) * (l.TW + 2) * LDP(C) * 2;
         const int cap = g_p3_small_tiles ? 1024 : 512;
+        { const int dpairs = C / 16; l.dshift = (dpairs & (dpairs - 1)) == 0 ? __builtin_ctz(dpairs) : -1; l.tshift = __builtin_ctz(l.TW); }
+        if (g_p3_mfma) return launch_p3l(conv3d_bwd_weight_mfma_kernel<true>, l, l.ntiles < 768 ? l.ntiles : 768, stream, lds + 16, g_p3_mfma_threads);
         return launch_p3l(unpack3d_bwd_weight_lds_kernel, l, l.ntiles < cap ? l.ntiles : cap, stream, lds);
     }
     a.total = (long)B * H * W * (C / 8);

@@ -437,8 +437,11 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stat
     ws, ws_n = _splitk_workspace(B * H * W, cout, x.device)
     done = ctypes.c_int(0)
     lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _ptr(ws), ws_n,
-                         gn_stats.data_ptr() if want else 0, ctypes.byref(done), 1 if accumulate else 0, _stream())
+                         gn_stats.data_ptr() if want else 0, ctypes.byref(done), (1 if accumulate else 0) | _CONV_SOLO, _stream())
     return (out, bool(done.value)) if gn_stats is not None else out
+
+
+_CONV_SOLO = 2      # MTE_CONV_SOLO: the forward pass has no weight-gradient kernels running beside it (see include/mte_kernels.h)
 
 
 # ---- weight-gradient side stream --------------------------------------------------------------------------------
