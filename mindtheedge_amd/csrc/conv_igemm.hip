@@ -568,7 +568,7 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         const long reach256 = t256 * (can_split ? (ksteps / 16 < 8 ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : 8) : 1);
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
             (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160)))   // (96: below it choose_splits does split)
-            return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st, stats_done);   // 256 x 256, 16 waves
+            return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st, stats_done);   // 256 x 256, 16 waves (8 waves of 128 x 64: 7.82 vs 7.65 ms / step, not kept)
         // 65..96 columns (the 72-channel decoder concat as data-gradient N): a 192 x 96 tile of 6 waves wastes a quarter of
         // the MFMA work instead of the 44 % a 128-wide tile does
         if (g_igemm_big >= 3 && dma_ok && !a.out_f32 && a.N > 64 && a.N <= 96 && ((a.M + 191) / 192) >= g_igemm_big_min_tiles)
