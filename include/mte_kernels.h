@@ -267,7 +267,7 @@ int mte_resize_linear(const float* src, int B, int h, int w, float* dst, int H, 
 int mte_canny_propagate(unsigned char* state, int* flags, int sweeps, int maps, int H, int W, mte_stream_t stream);
 int mte_canny_finish(const unsigned char* state, float* edges, int maps, int H, int W, mte_stream_t stream);
 
-/* ---- sparse auxiliary (SAN) branch, inference only.  PARITY UNPINNED: dense-equivalent of the
+/* ---- sparse auxiliary (SAN) branch.  PARITY UNPINNED: dense-equivalent of the
  * MinkowskiEngine operators the reference uses (networks/layers/minkowski_encoder.py:11-132, minkowski.py:33-79); see
  * oracle/san_oracle.py.  Features are zero-filled NHWC activations (bf16 / fp32), the active set is a byte mask [B,H,W].
  * mte_sparsify_depth: mask = depth > 0, feat channel 0 = depth on the mask, channels 1..7 = 0 (feat has >= 8 channels/pixel)
@@ -283,6 +283,28 @@ int mte_sparse_bn_relu(const void* a, long lda, const void* b, long ldb, const v
                        void* out, long ldo, long npix, int C, int dtype, mte_stream_t stream);
 int mte_san_fuse(const void* skip, long ld_skip, const void* sparse, long ld_sparse, const float* w, const float* bias,
                  void* out, long ldo, long npix, int C, int dtype, mte_stream_t stream);
+/* Training path of the branch (two-pass RGB / RGB+LiDAR step, networks/depth/PackNetSAN01.py:324-342; minkowski_encoder.py:27-84):
+ * mte_sparse_bn_stats: MinkowskiBatchNorm in training mode = BatchNorm1d over the active points of the whole batch:
+ *   sums[0..C) = sum x, sums[C..2C) = sum x^2 over the active pixels (x = a [+ b] [+ c]), sums[2C] = number of active pixels
+ *   (fp64, zeroed here).  The caller forms mean / biased variance and runs mte_sparse_bn_relu with them.
+ * mte_sparse_bn_relu_bwd: dy = dout * [out > 0];  dx = mask ? gamma * invstd * (dy - mean_active(dy) - xhat * mean_active(dy xhat)) : 0
+ *   (the gradient of a, b and c alike; n_active: device pointer to the number of active pixels, i.e. mte_sparse_bn_stats' sums + 2C); sums[0..C) = sum dy (= dbeta), sums[C..2C) = sum dy * xhat (= dgamma); scratch zeroed here.
+ * mte_sparse_maxpool3s2_bwd: a fine cell receives the gradient of every coarse cell whose window maximum it is (first maximum in
+ *   row-major window order among the active cells).
+ * mte_san_fuse_bwd: dskip = dout * w[0]; sums[0] = sum dout * skip (dw), sums[1] = sum dout (db); the sparse operand's gradient is dout.
+ * mte_feat_l2: sum (nullable) = sum (a - b)^2;  db (nullable) = -2 (a - b) * inv_n * gscale[0]  -- the feature-matching loss between
+ *   the RGB+LiDAR pass (a, detached) and the RGB pass (b) and its gradient (PackNetSAN01.py:340-342). */
+int mte_sparse_bn_stats(const void* a, long lda, const void* b, long ldb, const void* c, long ldc, const unsigned char* mask,
+                        double* sums, long npix, int C, int dtype, mte_stream_t stream);
+int mte_sparse_bn_relu_bwd(const void* a, long lda, const void* b, long ldb, const void* c, long ldc, const void* out, long ldo,
+                           const void* dout, long ldd, const unsigned char* mask, const float* gamma, const float* mean, const float* invstd,
+                           const double* n_active, double* sums, void* dx, long ldx, long npix, int C, int dtype, mte_stream_t stream);
+int mte_sparse_maxpool3s2_bwd(const void* in, long ldi, const unsigned char* mask_in, const void* dout, long ldd, void* din, long ldn,
+                              int B, int H, int W, int C, int dtype, mte_stream_t stream);
+int mte_san_fuse_bwd(const void* skip, long ld_skip, const void* dout, long ldd, const float* w, void* dskip, long ldk, double* sums,
+                     long npix, int C, int dtype, mte_stream_t stream);
+int mte_feat_l2(const void* a, long lda, const void* b, long ldb, double* sum, void* db, long ldg, const float* gscale, float inv_n,
+                long npix, int C, int dtype, mte_stream_t stream);
 
 /* ---- training-target preparation (data half)
  * mte_edge_target_from_u8:   dst = src / 255                      (datasets/augmentations.py:186-188,199-201)

@@ -1,4 +1,4 @@
-// Sparse auxiliary (SAN) branch of PackNet-SAN for gfx950, inference only.  PARITY UNPINNED: the
+// Sparse auxiliary (SAN) branch of PackNet-SAN for gfx950, inference and training.  PARITY UNPINNED: the
 // reference runs this branch on MinkowskiEngine (third-party CUDA, not available here); what is implemented is the
 // dense-equivalent of its published semantics (see oracle/san_oracle.py for the statement being followed):
 //   sparsify_depth   active set = pixels with depth > 0, one feature = the depth       (networks/layers/minkowski.py:33-57)
@@ -114,6 +114,211 @@ __global__ __launch_bounds__(256) void san_fuse_kernel(const T* __restrict__ ski
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Training path of the branch (round 2).  MinkowskiBatchNorm in training mode = BatchNorm1d over the ACTIVE points of the
+// whole batch (biased variance for the normalisation); the kernels below are the masked statistics / backward passes around
+// the dense MFMA convolutions, plus the backward of the pooling and of the fusion.
+// Work item = (pixel, 16-byte channel chunk); a thread keeps ONE chunk for its whole pixel loop (256 % chunks-per-pixel == 0),
+// so per-channel sums live in registers and are folded per workgroup in LDS, then added to the fp64 global sums.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int P> __device__ __forceinline__ void fold_channel_sums(float (&s0)[P], float (&s1)[P], int chunk, int cpr, double* __restrict__ gsum, int C) {
+    extern __shared__ float s_red[];                       // [2][cpr * P]
+    for (int i = threadIdx.x; i < 2 * cpr * P; i += 256) s_red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P; ++k) { atomicAdd(&s_red[chunk * P + k], s0[k]); atomicAdd(&s_red[cpr * P + chunk * P + k], s1[k]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * cpr * P; i += 256) {
+        const float v = s_red[i];
+        if (v != 0.f) atomicAdd(gsum + (i < cpr * P ? i : C + (i - cpr * P)), (double)v);
+    }
+}
+
+template <typename T> __device__ __forceinline__ void load_sum3(const T* a, long lda, const T* b, long ldb, const T* c, long ldc, long p, int ch0, float* v) {
+    constexpr int P = Elem<T>::PER16;
+    unpack16<T>(*(const u32x4_t*)(a + p * lda + ch0), v);
+    if (b) { float t[P]; unpack16<T>(*(const u32x4_t*)(b + p * ldb + ch0), t); for (int k = 0; k < P; ++k) v[k] += t[k]; }
+    if (c) { float t[P]; unpack16<T>(*(const u32x4_t*)(c + p * ldc + ch0), t); for (int k = 0; k < P; ++k) v[k] += t[k]; }
+}
+
+// sums[0..C) += sum x, sums[C..2C) += sum x^2 over the active pixels (x = a + b + c), sums[2C] += number of active pixels
+template <typename T>
+__global__ __launch_bounds__(256) void sparse_bn_stats_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, const T* __restrict__ c, long ldc,
+                                                              const unsigned char* __restrict__ mask, double* __restrict__ sums, long npix, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P, chunk = threadIdx.x % cpr, ppb = 256 / cpr;
+    float s0[P], s1[P]; float cnt = 0.f;
+#pragma unroll
+    for (int k = 0; k < P; ++k) s0[k] = s1[k] = 0.f;
+    for (long p = (long)blockIdx.x * ppb + threadIdx.x / cpr; p < npix; p += (long)gridDim.x * ppb) {
+        if (!mask[p]) continue;
+        float v[P];
+        load_sum3<T>(a, lda, b, ldb, c, ldc, p, chunk * P, v);
+#pragma unroll
+        for (int k = 0; k < P; ++k) { s0[k] += v[k]; s1[k] = fmaf(v[k], v[k], s1[k]); }
+        if (chunk == 0) cnt += 1.f;
+    }
+    fold_channel_sums<P>(s0, s1, chunk, cpr, sums, C);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt != 0.f) atomicAdd(sums + 2 * C, (double)cnt);
+}
+
+// dy = dout * [out > 0] (out is zero off the active set): sums[0..C) += sum dy, sums[C..2C) += sum dy * xhat, xhat = (x - mean) * invstd
+template <typename T>
+__global__ __launch_bounds__(256) void sparse_bn_bwd_reduce_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, const T* __restrict__ c, long ldc,
+                                                                   const T* __restrict__ out, long ldo, const T* __restrict__ dout, long ldd,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   double* __restrict__ sums, long npix, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P, chunk = threadIdx.x % cpr, ppb = 256 / cpr, ch0 = chunk * P;
+    float s0[P], s1[P], mu[P], is[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { s0[k] = s1[k] = 0.f; mu[k] = mean[ch0 + k]; is[k] = invstd[ch0 + k]; }
+    for (long p = (long)blockIdx.x * ppb + threadIdx.x / cpr; p < npix; p += (long)gridDim.x * ppb) {
+        float o[P], g[P], v[P];
+        unpack16<T>(*(const u32x4_t*)(out + p * ldo + ch0), o);
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < P; ++k) any = any || o[k] > 0.f;
+        if (!any) continue;
+        unpack16<T>(*(const u32x4_t*)(dout + p * ldd + ch0), g);
+        load_sum3<T>(a, lda, b, ldb, c, ldc, p, ch0, v);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float dy = o[k] > 0.f ? g[k] : 0.f;
+            s0[k] += dy; s1[k] = fmaf(dy, (v[k] - mu[k]) * is[k], s1[k]);
+        }
+    }
+    fold_channel_sums<P>(s0, s1, chunk, cpr, sums, C);
+}
+
+// dx = mask ? gamma * invstd * (dy - m1 - xhat * m2) : 0, m1 = sum dy / N, m2 = sum dy xhat / N (N = active pixels)
+template <typename T>
+__global__ __launch_bounds__(256) void sparse_bn_bwd_apply_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, const T* __restrict__ c, long ldc,
+                                                                  const T* __restrict__ out, long ldo, const T* __restrict__ dout, long ldd,
+                                                                  const unsigned char* __restrict__ mask, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const double* __restrict__ sums, const double* __restrict__ n_active, T* __restrict__ dx, long ldx, long npix, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P;
+    const long total = npix * cpr;
+    const double inv_n = n_active[0] > 0.0 ? 1.0 / n_active[0] : 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / cpr;
+        const int ch0 = (int)(i - p * cpr) * P;
+        float r[P];
+        if (mask[p]) {
+            float o[P], g[P], v[P];
+            unpack16<T>(*(const u32x4_t*)(out + p * ldo + ch0), o);
+            unpack16<T>(*(const u32x4_t*)(dout + p * ldd + ch0), g);
+            load_sum3<T>(a, lda, b, ldb, c, ldc, p, ch0, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float is = invstd[ch0 + k], xh = (v[k] - mean[ch0 + k]) * is;
+                const float dy = o[k] > 0.f ? g[k] : 0.f;
+                r[k] = gamma[ch0 + k] * is * (dy - (float)(sums[ch0 + k] * inv_n) - xh * (float)(sums[C + ch0 + k] * inv_n));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < P; ++k) r[k] = 0.f;
+        }
+        *(u32x4_t*)(dx + p * ldx + ch0) = pack16<T>(r);
+    }
+}
+
+// backward of sparse_maxpool_kernel: a fine cell receives the gradient of every coarse cell whose window maximum it is
+// (first maximum in row-major window order among the active cells); gathered per fine cell, no atomics
+template <typename T>
+__global__ __launch_bounds__(256) void sparse_maxpool_bwd_kernel(const T* __restrict__ in, long ldi, const unsigned char* __restrict__ mask_in,
+                                                                 const T* __restrict__ dout, long ldd, T* __restrict__ din, long ldn, int B, int H, int W, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int Ho = H / 2, Wo = W / 2, cpr = C / P;
+    const long total = (long)B * H * W * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / cpr;
+        const int ch0 = (int)(i - p * cpr) * P;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+        const unsigned char* m = mask_in + (long)b * H * W;
+        float r[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) r[k] = 0.f;
+        if (m[(long)y * W + x]) {
+            float mine[P];
+            unpack16<T>(*(const u32x4_t*)(in + p * ldi + ch0), mine);
+            // coarse cells (yo, xo) whose window rows 2yo-1..2yo+1 / columns 2xo-1..2xo+1 contain (y, x)
+            for (int yo = y >> 1; yo <= (y + 1) >> 1; ++yo)
+                for (int xo = x >> 1; xo <= (x + 1) >> 1; ++xo) {
+                    if (yo >= Ho || xo >= Wo) continue;
+                    const int y0 = 2 * yo, x0 = 2 * xo;
+                    if (!(m[(long)y0 * W + x0] | m[(long)y0 * W + x0 + 1] | m[(long)(y0 + 1) * W + x0] | m[(long)(y0 + 1) * W + x0 + 1])) continue;
+                    bool win[P];
+#pragma unroll
+                    for (int k = 0; k < P; ++k) win[k] = true;
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int yy = y0 + dy, xx = x0 + dx;
+                            if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W || !m[(long)yy * W + xx] || (yy == y && xx == x)) continue;
+                            float t[P];
+                            unpack16<T>(*(const u32x4_t*)(in + (((long)b * H + yy) * W + xx) * ldi + ch0), t);
+                            const bool before = yy < y || (yy == y && xx < x);      // earlier in window order: wins ties
+#pragma unroll
+                            for (int k = 0; k < P; ++k) win[k] = win[k] && (before ? t[k] < mine[k] : t[k] <= mine[k]);
+                        }
+                    float g[P];
+                    unpack16<T>(*(const u32x4_t*)(dout + (((long)b * Ho + yo) * Wo + xo) * ldd + ch0), g);
+#pragma unroll
+                    for (int k = 0; k < P; ++k) r[k] += win[k] ? g[k] : 0.f;
+                }
+        }
+        *(u32x4_t*)(din + p * ldn + ch0) = pack16<T>(r);
+    }
+}
+
+// backward of san_fuse: dskip = dout * w; sums[0] += sum dout * skip (dw), sums[1] += sum dout (db)
+template <typename T>
+__global__ __launch_bounds__(256) void san_fuse_bwd_kernel(const T* __restrict__ skip, long lds_, const T* __restrict__ dout, long ldd, const float* __restrict__ w,
+                                                           T* __restrict__ dskip, long ldk, double* __restrict__ sums, long npix, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P;
+    const long total = npix * cpr;
+    const float ww = *w;
+    float s0 = 0.f, s1 = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / cpr;
+        const int ch0 = (int)(i - p * cpr) * P;
+        float s[P], g[P];
+        unpack16<T>(*(const u32x4_t*)(skip + p * lds_ + ch0), s);
+        unpack16<T>(*(const u32x4_t*)(dout + p * ldd + ch0), g);
+#pragma unroll
+        for (int k = 0; k < P; ++k) { s0 = fmaf(g[k], s[k], s0); s1 += g[k]; s[k] = g[k] * ww; }
+        *(u32x4_t*)(dskip + p * ldk + ch0) = pack16<T>(s);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(sums, (double)s0); atomicAdd(sums + 1, (double)s1); }
+}
+
+// feature-matching loss of the two passes (PackNetSAN01.py:340-342): sum (a - b)^2; backward: db = -2 (a - b) * scale
+template <typename T>
+__global__ __launch_bounds__(256) void feat_l2_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, double* __restrict__ sum,
+                                                      T* __restrict__ db, long ldg, const float* __restrict__ gscale, float inv_n, long npix, int C) {
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = C / P;
+    const long total = npix * cpr;
+    const float gs = db ? -2.f * inv_n * (gscale ? *gscale : 1.f) : 0.f;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / cpr;
+        const int ch0 = (int)(i - p * cpr) * P;
+        float x[P], y[P];
+        unpack16<T>(*(const u32x4_t*)(a + p * lda + ch0), x);
+        unpack16<T>(*(const u32x4_t*)(b + p * ldb + ch0), y);
+#pragma unroll
+        for (int k = 0; k < P; ++k) { const float d = x[k] - y[k]; s = fmaf(d, d, s); x[k] = d * gs; }
+        if (db) *(u32x4_t*)(db + p * ldg + ch0) = pack16<T>(x);
+    }
+    if (sum) { s = wave_sum(s); if ((threadIdx.x & 63) == 0) atomicAdd(sum, (double)s); }
+}
+
 inline unsigned grid_for(long total) { long g = (total + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g; }
 
 }  // namespace
@@ -164,6 +369,86 @@ int mte_san_fuse(const void* skip, long ld_skip, const void* sparse, long ld_spa
         hipLaunchKernelGGL(san_fuse_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, (const bf16_t*)skip, ld_skip, (const bf16_t*)sparse, ld_sparse, w, bias, (bf16_t*)out, ldo, npix, C);
     else
         hipLaunchKernelGGL(san_fuse_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)skip, ld_skip, (const float*)sparse, ld_sparse, w, bias, (float*)out, ldo, npix, C);
+    return mte_check_launch();
+}
+
+// ---- training path (see the kernel comments above)
+static inline bool chunks_ok(int C, int per16) { const int cpr = C / per16; return C % per16 == 0 && cpr >= 1 && cpr <= 256 && 256 % cpr == 0; }
+
+int mte_sparse_bn_stats(const void* a, long lda, const void* b, long ldb, const void* c, long ldc, const unsigned char* mask,
+                        double* sums, long npix, int C, int dtype, hipStream_t stream) {
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (!a || !mask || !sums || npix <= 0 || !chunks_ok(C, per16)) return MTE_ERR_ARG;
+    if (mte_memset_async(sums, 0, sizeof(double) * (2 * C + 1), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    const int ppb = 256 / (C / per16);
+    long g = (npix + ppb - 1) / ppb; if (g > 1024) g = 1024;
+    const size_t lds = sizeof(float) * 2 * C;
+    if (dtype == MTE_DT_BF16)
+        hipLaunchKernelGGL(sparse_bn_stats_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (const bf16_t*)c, ldc, mask, sums, npix, C);
+    else
+        hipLaunchKernelGGL(sparse_bn_stats_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, (const float*)a, lda, (const float*)b, ldb, (const float*)c, ldc, mask, sums, npix, C);
+    return mte_check_launch();
+}
+
+int mte_sparse_bn_relu_bwd(const void* a, long lda, const void* b, long ldb, const void* c, long ldc, const void* out, long ldo,
+                           const void* dout, long ldd, const unsigned char* mask, const float* gamma, const float* mean, const float* invstd,
+                           const double* n_active, double* sums, void* dx, long ldx, long npix, int C, int dtype, hipStream_t stream) {
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (!a || !out || !dout || !mask || !gamma || !mean || !invstd || !n_active || !sums || !dx || npix <= 0 || !chunks_ok(C, per16)) return MTE_ERR_ARG;
+    if (mte_memset_async(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    const int ppb = 256 / (C / per16);
+    long g = (npix + ppb - 1) / ppb; if (g > 1024) g = 1024;
+    const size_t lds = sizeof(float) * 2 * C;
+    const unsigned ga = grid_for(npix * (C / per16));
+    if (dtype == MTE_DT_BF16) {
+        hipLaunchKernelGGL(sparse_bn_bwd_reduce_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (const bf16_t*)c, ldc,
+                           (const bf16_t*)out, ldo, (const bf16_t*)dout, ldd, mean, invstd, sums, npix, C);
+        hipLaunchKernelGGL(sparse_bn_bwd_apply_kernel<bf16_t>, dim3(ga), dim3(256), 0, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (const bf16_t*)c, ldc,
+                           (const bf16_t*)out, ldo, (const bf16_t*)dout, ldd, mask, gamma, mean, invstd, sums, n_active, (bf16_t*)dx, ldx, npix, C);
+    } else {
+        hipLaunchKernelGGL(sparse_bn_bwd_reduce_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, (const float*)a, lda, (const float*)b, ldb, (const float*)c, ldc,
+                           (const float*)out, ldo, (const float*)dout, ldd, mean, invstd, sums, npix, C);
+        hipLaunchKernelGGL(sparse_bn_bwd_apply_kernel<float>, dim3(ga), dim3(256), 0, stream, (const float*)a, lda, (const float*)b, ldb, (const float*)c, ldc,
+                           (const float*)out, ldo, (const float*)dout, ldd, mask, gamma, mean, invstd, sums, n_active, (float*)dx, ldx, npix, C);
+    }
+    return mte_check_launch();
+}
+
+int mte_sparse_maxpool3s2_bwd(const void* in, long ldi, const unsigned char* mask_in, const void* dout, long ldd, void* din, long ldn,
+                              int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (!in || !mask_in || !dout || !din || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C % per16 != 0) return MTE_ERR_ARG;
+    const unsigned g = grid_for((long)B * H * W * (C / per16));
+    if (dtype == MTE_DT_BF16)
+        hipLaunchKernelGGL(sparse_maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, (const bf16_t*)in, ldi, mask_in, (const bf16_t*)dout, ldd, (bf16_t*)din, ldn, B, H, W, C);
+    else
+        hipLaunchKernelGGL(sparse_maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)in, ldi, mask_in, (const float*)dout, ldd, (float*)din, ldn, B, H, W, C);
+    return mte_check_launch();
+}
+
+int mte_san_fuse_bwd(const void* skip, long ld_skip, const void* dout, long ldd, const float* w, void* dskip, long ldk, double* sums,
+                     long npix, int C, int dtype, hipStream_t stream) {
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (!skip || !dout || !w || !dskip || !sums || npix <= 0 || C % per16 != 0) return MTE_ERR_ARG;
+    if (mte_memset_async(sums, 0, sizeof(double) * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    long g = (npix * (C / per16) + 255) / 256; if (g > 1024) g = 1024;
+    if (dtype == MTE_DT_BF16)
+        hipLaunchKernelGGL(san_fuse_bwd_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)skip, ld_skip, (const bf16_t*)dout, ldd, w, (bf16_t*)dskip, ldk, sums, npix, C);
+    else
+        hipLaunchKernelGGL(san_fuse_bwd_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)skip, ld_skip, (const float*)dout, ldd, w, (float*)dskip, ldk, sums, npix, C);
+    return mte_check_launch();
+}
+
+int mte_feat_l2(const void* a, long lda, const void* b, long ldb, double* sum, void* db, long ldg, const float* gscale, float inv_n,
+                long npix, int C, int dtype, hipStream_t stream) {
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (!a || !b || (!sum && !db) || npix <= 0 || C % per16 != 0) return MTE_ERR_ARG;
+    if (sum && mte_memset_async(sum, 0, sizeof(double), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    long g = (npix * (C / per16) + 255) / 256; if (g > 1024) g = 1024;
+    if (dtype == MTE_DT_BF16)
+        hipLaunchKernelGGL(feat_l2_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, sum, (bf16_t*)db, ldg, gscale, inv_n, npix, C);
+    else
+        hipLaunchKernelGGL(feat_l2_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)a, lda, (const float*)b, ldb, sum, (float*)db, ldg, gscale, inv_n, npix, C);
     return mte_check_launch();
 }
 

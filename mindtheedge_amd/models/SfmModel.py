@@ -33,12 +33,15 @@ class SfmModel(BaseModel):
         # the reference also forwards 'input_depth' (SemiSupEdgeModel.py:44).  While training, the RGB+LiDAR pass it triggers
         # never reaches the loss and is skipped here; in eval mode it IS the prediction the reference validates, and it is
         # taken when the network owns the sparse branch (PackNetSAN01(with_san=True), parity unpinned)
-        if not self.training and 'input_depth' in batch and getattr(self.depth_net, 'with_san', False):
+        batch_input.pop('input_depth', None)
+        if 'input_depth' in batch and getattr(self.depth_net, 'with_san', False) and (not self.training or self._train_with_lidar):
             batch_input['input_depth'] = batch['input_depth']
         batch_input['output_features'] = output_features
         if flip:
             return flip_output(self.depth_net(**flip_batch_input(batch_input)))
         return self.depth_net(**batch_input)
+
+    _train_with_lidar = False    # EdgeEstimationLIDARModel sets it: its loss consumes the RGB+LiDAR pass (SemiSupEdgeModel's does not)
 
     _pinned_flip = None          # utils.graph.GraphedTrainStep: the host-side flip draw is taken outside the captured step
 

@@ -129,7 +129,7 @@ class PackNetSAN01(nn.Module):
         if freeze_decoder:
             self.freeze_weights(self.decoder.parameters())
         # The reference always owns the sparse branch (34 M parameters) although SemiSupEdgeModel never runs it; here it is
-        # materialised on request (with_san=True, inference with a LiDAR input) so that the training path's parameter set,
+        # materialised on request (with_san=True: inference or training with a LiDAR input) so that the training path's parameter set,
         # flat optimizer buffers and fixtures stay those of the 218 dense tensors.  PARITY UNPINNED, see minkowski_encoder.py.
         if with_san:
             from ..layers.minkowski_encoder import MinkowskiEncoder
@@ -188,11 +188,22 @@ class PackNetSAN01(nn.Module):
             if self.in_channels == 4:
                 out[0] = out[0] * rgb_edge            # as the reference: list * tensor is an upstream bug; kept failing loudly
             return {'inv_depths': out}
-        if input_depth is not None:
-            raise NotImplementedError("training with input_depth needs a backward pass through the SAN branch, which is built "
-                                      "for inference only (SURVEY.md 8 f-1); SemiSupEdgeModel never uses its outputs, so drop the key")
         inv_depths, feats = self.run_network(rgb)
         output = {'inv_depths': inv_depths}
         if output_features:
             output['skip_feat_rgb'] = feats
+        if input_depth is None:
+            return output
+        # reference :324-342: second pass with the LiDAR input through the sparse branch, and the feature-matching loss that
+        # pulls the RGB-only pyramid towards the (detached) RGB+LiDAR one
+        from ..layers.minkowski_encoder import feature_l2
+        inv_depths_rgbd, feats_rgbd = self.run_network(rgb, input_depth)
+        output['inv_depths_rgbd'] = inv_depths_rgbd
+        loss = None
+        for srgbd, srgb in zip(feats_rgbd, feats):
+            term = feature_l2(srgbd, srgb)
+            loss = term if loss is None else loss + term
+        output['depth_loss'] = loss / len(feats_rgbd)
+        if output_features:
+            output['skip_feat_rgbd'] = feats_rgbd
         return output

@@ -1,4 +1,4 @@
-"""Sparse auxiliary (SAN) branch of PackNet-SAN, inference only -- SURVEY.md 8 row f-1.  **Parity unpinned.**
+"""Sparse auxiliary (SAN) branch of PackNet-SAN, inference and training -- SURVEY.md 8 row f-1.  **Parity unpinned.**
 
 Mirror of packnet_sfm/networks/layers/minkowski_encoder.py (``MinkConv2D`` :11-86, ``MinkowskiEncoder`` :89-132) and of
 ``sparsify_depth`` / ``densify_features`` (networks/layers/minkowski.py:33-79) WITHOUT MinkowskiEngine: the sparse
@@ -13,15 +13,43 @@ documentation as restated in oracle/san_oracle.py and cannot be checked against 
     checkpoint trained with MinkowskiEngine and must be confirmed against one before trusting such weights;
   * MinkowskiMaxPooling(3, stride=2): output cell (i, j) exists iff one of the fine cells (2i..2i+1, 2j..2j+1) does and
     takes the maximum over the active fine cells in rows 2i-1..2i+1, columns 2j-1..2j+1;
-  * MinkowskiBatchNorm: BatchNorm1d over the active points (``bn.*`` keys); only eval mode (running statistics) is built.
+  * MinkowskiBatchNorm: BatchNorm1d over the active points of the whole batch (``bn.*`` keys): training mode normalises with
+    the batch mean / biased variance of the active points and updates the running statistics (momentum 0.1, unbiased variance),
+    eval mode uses the running statistics.
 
-Parameter names match the reference's state dict (``mconvs.<level>.layer3.0.kernel``, ``...layer3.1.bn.weight`` ...), all
-parameters are created with requires_grad=False (no backward pass exists for this branch).
+Parameter names match the reference's state dict (``mconvs.<level>.layer3.0.kernel``, ``...layer3.1.bn.weight`` ...).  Every
+operator has a backward pass (round 2): the convolutions through the dense data- / weight-gradient kernels, the rest through
+the masked kernels of csrc/san.hip (mte_sparse_bn_stats / _bn_relu_bwd / _maxpool3s2_bwd / mte_san_fuse_bwd), checked against
+autograd through oracle/san_oracle.py.
 """
 import torch
 import torch.nn as nn
 
 from ... import kernels as K
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """dense convolution of the zero-filled map with the [k*k, C_in, C_out] kernel parameter (the caller masks the result)"""
+
+    @staticmethod
+    def forward(ctx, feat, kernel, k, pack):
+        cin, cout = kernel.shape[1], kernel.shape[2]
+        w = kernel.detach().view(k, k, cin, cout).permute(3, 2, 0, 1).contiguous()
+        pack.key = None
+        wf, _ = pack.get(w, feat.dtype, bool(ctx.needs_input_grad[0]))
+        y = K.conv_forward(feat, wf, None, cout, k, k, pack=pack, w=w)
+        ctx.save_for_backward(feat, w)
+        ctx.pack, ctx.k = pack, k
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feat, w = ctx.saved_tensors
+        dy = K.as_act(dy, feat.dtype)
+        dx, dw, _ = K.conv_backward(feat, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False)
+        k = ctx.k
+        dkernel = None if dw is None else dw.permute(2, 3, 1, 0).reshape(k * k, w.shape[1], w.shape[0])
+        return dx, dkernel, None, None
 
 
 class _SparseConv(nn.Module):
@@ -30,22 +58,11 @@ class _SparseConv(nn.Module):
         self.cin, self.cout, self.k = cin, cout, k
         kernel = torch.empty(k * k, cin, cout)
         nn.init.kaiming_uniform_(kernel.view(k * k * cin, cout).t(), a=5 ** 0.5)
-        self.kernel = nn.Parameter(kernel, requires_grad=False)
-        self._pack, self._oihw, self._key = K.WeightPack(), None, None
-
-    def oihw(self):
-        key = (self.kernel.data_ptr(), self.kernel._version)
-        if key != self._key:
-            k = self.k
-            self._oihw = self.kernel.detach().view(k, k, self.cin, self.cout).permute(3, 2, 0, 1).contiguous()
-            self._key = key
-        return self._oihw
+        self.kernel = nn.Parameter(kernel)
+        self._pack = K.WeightPack()
 
     def forward(self, feat):
-        """dense convolution of the zero-filled map (the caller masks the result)"""
-        w = self.oihw()
-        wf, _ = self._pack.get(w, feat.dtype, False)
-        return K.conv_forward(feat, wf, None, self.cout, self.k, self.k, pack=self._pack, w=w)
+        return _SparseConvFn.apply(feat, self.kernel, self.k, self._pack)
 
 
 class _SparseBatchNorm(nn.Module):
@@ -54,25 +71,87 @@ class _SparseBatchNorm(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.bn = nn.BatchNorm1d(c)
-        for p in self.bn.parameters():
-            p.requires_grad = False
+
+
+def _ptrs(*ts):
+    out = []
+    for t in ts:
+        out += list(K._pl(t)) if t is not None else [None, 0]
+    return out
+
+
+class _SparseBnReluFn(torch.autograd.Function):
+    """out = mask ? relu(bn(a [+ b] [+ c])) : 0 with the statistics handed in (batch statistics while training)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, mask, gamma, beta, mean, var, eps, n_active):
+        B, C, H, W = a.shape
+        out = K.new_act(B, C, H, W, a.dtype, a.device)
+        po, lo = K._pl(out)
+        K.lib.mte_sparse_bn_relu(*_ptrs(a, b, c), mask.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                 float(eps), po, lo, B * H * W, C, K._dt(a), K._stream())
+        ctx.save_for_backward(a, b, c, mask, gamma, mean, var, out, n_active)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, c, mask, gamma, mean, var, out, n_active = ctx.saved_tensors
+        if n_active is None:
+            raise K.MteError("the sparse BatchNorm backward needs batch statistics: put the module in train() mode")
+        B, C, H, W = a.shape
+        dout = K.as_act(dout, a.dtype)
+        invstd = torch.rsqrt(var + ctx.eps)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=a.device)
+        dx = K.new_act(B, C, H, W, a.dtype, a.device)
+        px, lx = K._pl(dx)
+        K.lib.mte_sparse_bn_relu_bwd(*_ptrs(a, b, c, out, dout), mask.data_ptr(), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                     n_active.data_ptr(), sums.data_ptr(), px, lx, B * H * W, C, K._dt(a), K._stream())
+        dbeta, dgamma = sums[:C].float(), sums[C:].float()
+        return dx, (dx if b is not None else None), (dx if c is not None else None), None, dgamma, dbeta, None, None, None, None
 
 
 def _bn_relu(a, mask, norm, b=None, c=None):
-    if norm.training:
-        raise NotImplementedError("the sparse branch is built for inference (eval mode) only: batch statistics over the active "
-                                  "points and the backward pass are not implemented (SURVEY.md 8 f-1)")
-    B, C, H, W = a.shape
-    out = K.new_act(B, C, H, W, a.dtype, a.device)
-    pa, la = K._pl(a)
-    pb, lb = K._pl(b) if b is not None else (None, 0)
-    pc, lc = K._pl(c) if c is not None else (None, 0)
-    po, lo = K._pl(out)
     bn = norm.bn
-    K.lib.mte_sparse_bn_relu(pa, la, pb, lb, pc, lc, mask.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps), po, lo, B * H * W, C,
-                             K._dt(a), K._stream())
-    return out
+    if not norm.training:
+        return _SparseBnReluFn.apply(a, b, c, mask, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, None)
+    # MinkowskiBatchNorm in training mode: statistics over the active points of the whole batch
+    B, C, H, W = a.shape
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=a.device)
+    K.lib.mte_sparse_bn_stats(*_ptrs(a, b, c), mask.data_ptr(), sums.data_ptr(), B * H * W, C, K._dt(a), K._stream())
+    n = sums[2 * C:].clamp(min=1.0)
+    mean64 = sums[:C] / n
+    var64 = (sums[C:2 * C] / n - mean64 * mean64).clamp(min=0.0)          # biased, as BatchNorm normalises
+    mean, var = mean64.float(), var64.float()
+    with torch.no_grad():
+        m = bn.momentum if bn.momentum is not None else 0.1
+        bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+        bn.running_var.mul_(1 - m).add_((var64 * (n / (n - 1).clamp(min=1.0))).float(), alpha=m)
+        bn.num_batches_tracked += 1
+    return _SparseBnReluFn.apply(a, b, c, mask, bn.weight, bn.bias, mean, var, bn.eps, sums[2 * C:])
+
+
+class _SparseMaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, mask):
+        B, C, H, W = feat.shape
+        pooled = K.new_act(B, C, H // 2, W // 2, feat.dtype, feat.device)
+        mask2 = torch.empty((B, H // 2, W // 2), dtype=torch.uint8, device=feat.device)
+        pi, li = K._pl(feat)
+        po, lo = K._pl(pooled)
+        K.lib.mte_sparse_maxpool3s2(pi, li, mask.data_ptr(), po, lo, mask2.data_ptr(), B, H, W, C, K._dt(feat), K._stream())
+        ctx.save_for_backward(feat, mask)
+        ctx.mark_non_differentiable(mask2)
+        return pooled, mask2
+
+    @staticmethod
+    def backward(ctx, dpooled, _dmask):
+        feat, mask = ctx.saved_tensors
+        B, C, H, W = feat.shape
+        dpooled = K.as_act(dpooled, feat.dtype)
+        din = K.new_act(B, C, H, W, feat.dtype, feat.device)
+        K.lib.mte_sparse_maxpool3s2_bwd(*_ptrs(feat), mask.data_ptr(), *_ptrs(dpooled, din), B, H, W, C, K._dt(feat), K._stream())
+        return din, None
 
 
 class MinkConv2D(nn.Module):
@@ -96,13 +175,7 @@ class MinkConv2D(nn.Module):
     def forward(self, x):
         feat, mask = x
         if self.stride != 1:
-            B, C, H, W = feat.shape
-            pooled = K.new_act(B, C, H // 2, W // 2, feat.dtype, feat.device)
-            mask2 = torch.empty((B, H // 2, W // 2), dtype=torch.uint8, device=feat.device)
-            pi, li = K._pl(feat)
-            po, lo = K._pl(pooled)
-            K.lib.mte_sparse_maxpool3s2(pi, li, mask.data_ptr(), po, lo, mask2.data_ptr(), B, H, W, C, K._dt(feat), K._stream())
-            feat, mask = pooled, mask2
+            feat, mask = _SparseMaxPoolFn.apply(feat, mask)
         l3, l2 = self.layer3, self.layer2
         x1 = self.layer1[0](feat)
         x2 = l2[3](_bn_relu(l2[0](feat), mask, l2[1]))
@@ -142,13 +215,66 @@ class MinkowskiEncoder(nn.Module):
         return self.d[0]
 
 
+class _SanFuseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, sparse, weight, bias, index):
+        B, C, H, W = skip.shape
+        out = K.new_act(B, C, H, W, skip.dtype, skip.device)
+        po, lo = K._pl(out)
+        w1 = weight.detach()[index:index + 1].contiguous()
+        b1 = bias.detach()[index:index + 1].contiguous()
+        K.lib.mte_san_fuse(*_ptrs(skip, sparse), w1.data_ptr(), b1.data_ptr(), po, lo, B * H * W, C, K._dt(skip), K._stream())
+        ctx.save_for_backward(skip, w1)
+        ctx.index, ctx.n = index, weight.numel()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        skip, w1 = ctx.saved_tensors
+        B, C, H, W = skip.shape
+        dout = K.as_act(dout, skip.dtype)
+        dskip = K.new_act(B, C, H, W, skip.dtype, skip.device)
+        sums = torch.empty(2, dtype=torch.float64, device=skip.device)
+        K.lib.mte_san_fuse_bwd(*_ptrs(skip, dout), w1.data_ptr(), *K._pl(dskip), sums.data_ptr(), B * H * W, C, K._dt(skip), K._stream())
+        dw = torch.zeros(ctx.n, dtype=torch.float32, device=skip.device)
+        db = torch.zeros(ctx.n, dtype=torch.float32, device=skip.device)
+        dw[ctx.index] = sums[0].float()
+        db[ctx.index] = sums[1].float()
+        return dskip, dout, dw, db, None
+
+
 def san_fuse(skip, sparse, weight, bias, index):
     """skip * weight[index] + sparse + bias[index] (PackNetSAN01.py:254-258) in one pass."""
-    B, C, H, W = skip.shape
-    out = K.new_act(B, C, H, W, skip.dtype, skip.device)
-    ps, ls = K._pl(skip)
-    pq, lq = K._pl(sparse)
-    po, lo = K._pl(out)
-    K.lib.mte_san_fuse(ps, ls, pq, lq, weight.detach()[index:index + 1].data_ptr(), bias.detach()[index:index + 1].data_ptr(),
-                       po, lo, B * H * W, C, K._dt(skip), K._stream())
-    return out
+    return _SanFuseFn.apply(skip, sparse, weight, bias, index)
+
+
+class _FeatL2Fn(torch.autograd.Function):
+    """mean((a.detach() - b)^2) over the logical elements (PackNetSAN01.py:340-342: a = RGB+LiDAR feature, b = RGB feature)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        B, C, H, W = b.shape
+        s = torch.empty(1, dtype=torch.float64, device=b.device)
+        K.lib.mte_feat_l2(*_ptrs(a, b), s.data_ptr(), None, 0, None, 0.0, B * H * W, C, K._dt(b), K._stream())
+        ctx.save_for_backward(a, b)
+        ctx.inv_n = 1.0 / (B * H * W * C)
+        return (s * ctx.inv_n).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        B, C, H, W = b.shape
+        db = K.new_act(B, C, H, W, b.dtype, b.device)
+        gs = g.detach().float().contiguous()
+        K.lib.mte_feat_l2(*_ptrs(a, b), None, *K._pl(db), gs.data_ptr(), ctx.inv_n, B * H * W, C, K._dt(b), K._stream())
+        return None, db
+
+
+def feature_l2(a, b):
+    """mean squared difference between two NHWC activations of equal logical shape; gradient flows into ``b`` only"""
+    a, b = K.as_act(a.detach(), K.compute_dtype()), K.as_act(b, K.compute_dtype())
+    if tuple(a.shape) != tuple(b.shape):
+        raise ValueError("feature shapes differ: {} vs {}".format(tuple(a.shape), tuple(b.shape)))
+    if b.shape[1] % 8:
+        raise K.MteError("feature_l2 expects channel counts that are multiples of 8 (no channel padding inside the mean)")
+    return _FeatL2Fn.apply(a, b)

@@ -117,3 +117,28 @@ def test_infer_edges_png_input_is_resized_and_written_as_npy_and_png(tmp_path, c
     png = np.asarray(Image.open(os.path.join(outdir, "00000000_regular.png")))
     assert png.shape == (96, 160) and png.dtype == np.uint8 and png.max() == 255
     assert np.abs(png.astype(np.float64) - np.rint(d / d.max() * 255.0)).max() <= 1
+
+
+def test_train_edges_dee_with_lidar_two_steps(tmp_path, capsys):
+    """the depth-edge estimator trained WITH a LiDAR input through the same entry point (reference EdgeEstimationLIDARModel.py:87-160,
+    PackNetSAN01.py:324-342): two optimizer steps move the sparse-branch parameters and the checkpoint carries them"""
+    from mindtheedge_amd.models.model_checkpoint import load_checkpoint
+    cfgp = _yaml(tmp_path)
+    with open(cfgp) as f:
+        cfg = yaml.safe_load(f)
+    cfg["model"]["name"] = "EdgeEstimationLIDARModel"
+    cfg["model"].setdefault("loss", {})["edges_depth_edge_loss_all_scales"] = True
+    with open(cfgp, "w") as f:
+        yaml.safe_dump(cfg, f)
+    save = os.path.join(tmp_path, "dee")
+    _run_main("train_edges", ["train_edges.py", cfgp, "--synthetic", "--synthetic-lidar", "--steps", "2", "--epochs", "1", "--save", save])
+    out = capsys.readouterr().out
+    hist = eval(out.strip().splitlines()[-1])
+    assert len(hist) == 1 and np.isfinite(hist[0]["avg_loss"]) and hist[0]["avg_loss"] > 0
+    ckpt = load_checkpoint(os.path.join(save, "epoch=0.ckpt"))
+    keys = [k for k in ckpt["state_dict"] if ".mconvs." in k]
+    assert len(keys) >= 70 and any(k.endswith("layer3.0.kernel") for k in keys) and any(k.endswith("running_mean") for k in keys)
+    steps = {int(float(st["step"])) for st in ckpt["optimizer"]["state"].values()}
+    assert steps == {2} and len(ckpt["optimizer"]["state"]) == 288          # the reference's depth_net.parameters() index space
+    tracked = [v for k, v in ckpt["state_dict"].items() if k.endswith("num_batches_tracked")]
+    assert tracked and all(int(v) == 2 for v in tracked)

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the sparse auxiliary (SAN) branch, inference only against oracle/san_oracle.py.
+"""GPU (-m gpu): the sparse auxiliary (SAN) branch, inference and training against oracle/san_oracle.py.
 PARITY UNPINNED -- both sides state MinkowskiEngine's published semantics in dense form; MinkowskiEngine itself is not
 available (see the oracle header).  These tests establish that the HIP path and the independent torch statement agree."""
 import numpy as np
@@ -66,10 +66,10 @@ def test_encoder_levels_match_dense_statement(dtype, tol):
     want = so.san_features(P, d)
     enc.prep(d.cuda())
     for level in range(5):
-        got = enc().float().cpu()
+        got = enc().detach().float().cpu()
         assert got.shape == want[level].shape
         assert rel_err(got, want[level]) < tol, (level, rel_err(got, want[level]))
-        assert float(got.abs().sum()) > 0
+        assert float(got.detach().abs().sum()) > 0
         off = want[level] == 0
         assert float(got[off & (want[level].abs().sum(1, keepdim=True) == 0).expand_as(off)].abs().sum()) == 0.0    # zero off the active set
 
@@ -84,8 +84,7 @@ def test_packnetsan_with_lidar_input_matches_composition():
     _randomise(net.mconvs, seed=9)
     net.weight.data.copy_(torch.tensor([0.9, 1.1, 0.8, 1.2, 1.0]))
     net.bias.data.copy_(torch.tensor([0.01, -0.02, 0.03, 0.0, -0.01]))
-    assert not any(p.requires_grad for p in net.mconvs.parameters())
-    assert sum(p.numel() for p in net.parameters() if p.requires_grad) == 76997806          # the training parameter set is unchanged
+    assert sum(p.numel() for p in PackNetSAN01(dropout=None, version="1A").parameters() if p.requires_grad) == 76997806   # default build: dense set only
     rgb = torch.rand(1, 3, 64, 128, generator=torch.Generator().manual_seed(1)).cuda()
     d = _lidar(1, 64, 128, seed=6).cuda()
     with torch.no_grad():
@@ -102,9 +101,6 @@ def test_packnetsan_with_lidar_input_matches_composition():
     assert rel_err(feats1[0].float().cpu(), feats0[0].float().cpu()) < 1e-5                  # full-resolution skip untouched
     with pytest.raises(NotImplementedError):
         PackNetSAN01(dropout=None, version="1A").cuda().eval()(rgb, input_depth=d)
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(rgb, input_depth=d)
 
 
 def test_validation_uses_the_lidar_pass_when_the_branch_exists():
@@ -155,6 +151,169 @@ def test_edge_estimation_lidar_model_eval():
         ref = wrap.depth_net(rgb, input_depth=lidar / 200.0)["inv_depths"][0]
     assert rel_err(out[0].float().cpu(), ref[0].float().cpu() / 2) < 1e-4
     assert rel_err(out[1].float().cpu(), ref[1].float().cpu()) < 1e-4          # only the full-resolution scale is halved in eval
-    wrap.train()
-    with pytest.raises(NotImplementedError):
-        wrap.model({"rgb": rgb, "input_depth": lidar})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training path (round 2): backward kernels of the branch against torch autograd through the dense statement
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_params(enc):
+    P = {}
+    for k, v in enc.state_dict().items():
+        t = v.detach().cpu().clone()
+        if t.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            t.requires_grad_(True)
+        P["mconvs." + k] = t
+    return P
+
+
+def test_training_features_gradients_and_running_statistics_match_autograd():
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.layers.minkowski_encoder import MinkowskiEncoder
+    K.set_compute_dtype("fp32")
+    enc = MinkowskiEncoder([32, 64, 128, 256, 512])
+    _randomise(enc, seed=11)
+    P = _oracle_params(enc)
+    enc = enc.cuda().train()
+    d = _lidar(2, 64, 128, seed=12, density=0.12)
+    g = torch.Generator().manual_seed(13)
+    want = so.san_features(P, d, train=True)
+    R = [torch.rand(w.shape, generator=g) - 0.5 for w in want]
+    sum((w * r).sum() for w, r in zip(want, R)).backward()
+    enc.prep(d.cuda())
+    got = [enc() for _ in range(5)]
+    for level in range(5):
+        assert rel_err(got[level].float().cpu(), want[level].detach()) < 3e-4, level
+    sum((K_.float() * r.cuda()).sum() for K_, r in zip(got, R)).backward()
+    torch.cuda.synchronize()
+    checked = 0
+    for name, p in enc.named_parameters():
+        ref = P["mconvs." + name].grad
+        assert p.grad is not None and ref is not None, name
+        assert rel_err(p.grad.cpu(), ref) < 2e-3, (name, rel_err(p.grad.cpu(), ref))
+        assert float(ref.abs().max()) > 0
+        checked += 1
+    assert checked == 70                                              # the reference's 70 mconvs parameter tensors
+    for name, b in enc.named_buffers():                               # running statistics: momentum 0.1, unbiased variance
+        if name.endswith(("running_mean", "running_var")):
+            assert rel_err(b.cpu(), P["mconvs." + name]) < 1e-4, name
+        elif name.endswith("num_batches_tracked"):
+            assert int(b) == 1
+
+
+def test_pooling_and_fusion_backward_kernels():
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.layers.minkowski_encoder import _SparseMaxPoolFn, san_fuse, feature_l2
+    K.set_compute_dtype("fp32")
+    g = torch.Generator().manual_seed(21)
+    d = _lidar(2, 32, 64, seed=22, density=0.3)
+    mask = (d > 0)
+    f = ((torch.rand(2, 8, 32, 64, generator=g) - 0.6) * mask).requires_grad_(True)
+    # ties on purpose: a quarter of the active values are set to one common value
+    with torch.no_grad():
+        f[(torch.rand(f.shape, generator=g) < 0.25) & mask.expand_as(f)] = 0.125
+    want, _ = so.max_pool(f, mask)
+    Rp = torch.rand(want.shape, generator=g) - 0.5
+    (want * Rp).sum().backward()
+    fa = K.as_act(f.detach().cuda(), torch.float32).requires_grad_(True)
+    m8 = mask[:, 0].to(torch.uint8).cuda().contiguous()
+    got, m2 = _SparseMaxPoolFn.apply(fa, m8)
+    assert torch.equal(got.float().cpu(), want.detach())
+    (got.float() * Rp.cuda()).sum().backward()
+    assert torch.equal(fa.grad.float().cpu(), f.grad), float((fa.grad.float().cpu() - f.grad).abs().max())
+    # fusion: skip * w[i] + sparse + b[i]
+    skip = (torch.rand(2, 32, 16, 32, generator=g) - 0.5).requires_grad_(True)
+    sp = (torch.rand(2, 32, 16, 32, generator=g) - 0.5).requires_grad_(True)
+    w = torch.tensor([0.9, 1.1, 0.8, 1.2, 1.0], requires_grad=True)
+    b = torch.tensor([0.01, -0.02, 0.03, 0.0, -0.01], requires_grad=True)
+    Rf = torch.rand(2, 32, 16, 32, generator=g) - 0.5
+    ((skip * w[2] + sp + b[2]) * Rf).sum().backward()
+    sk = K.as_act(skip.detach().cuda(), torch.float32).requires_grad_(True)
+    sq = K.as_act(sp.detach().cuda(), torch.float32).requires_grad_(True)
+    wg, bg = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    out = san_fuse(sk, sq, wg, bg, 2)
+    (out.float() * Rf.cuda()).sum().backward()
+    assert rel_err(sk.grad.float().cpu(), skip.grad) < 1e-6 and rel_err(sq.grad.float().cpu(), sp.grad) < 1e-6
+    assert rel_err(wg.grad.cpu(), w.grad) < 1e-5 and rel_err(bg.grad.cpu(), b.grad) < 1e-5
+    assert float(wg.grad[0]) == 0.0 and float(wg.grad[2]) != 0.0
+    # feature-matching loss: mean((a.detach() - b)^2), gradient into b only
+    a_ = torch.rand(2, 32, 16, 32, generator=g)
+    b_ = torch.rand(2, 32, 16, 32, generator=g).requires_grad_(True)
+    (3.0 * ((a_ - b_) ** 2).mean()).backward()
+    ag = K.as_act(a_.cuda(), torch.float32).requires_grad_(True)
+    bg_ = K.as_act(b_.detach().cuda(), torch.float32).requires_grad_(True)
+    loss = feature_l2(ag, bg_)
+    assert abs(float(loss) - float(((a_ - b_) ** 2).mean())) < 1e-6
+    (3.0 * loss).backward()
+    assert ag.grad is None and rel_err(bg_.grad.float().cpu(), b_.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_packnetsan_two_pass_training_step(dtype):
+    """train-mode forward with input_depth (reference PackNetSAN01.py:324-342): RGB pass, RGB+LiDAR pass, feature-matching loss;
+    one backward reaches the dense network, the sparse branch and the fusion scalars"""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
+    K.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    net = PackNetSAN01(dropout=None, version="1A", with_san=True).cuda().train()
+    _randomise(net.mconvs, seed=9)
+    assert sum(1 for _ in net.mconvs.parameters()) == 70 and all(p.requires_grad for p in net.mconvs.parameters())
+    rgb = torch.rand(2, 3, 64, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    d = _lidar(2, 64, 128, seed=6, density=0.1).cuda()
+    out = net(rgb, input_depth=d, output_features=True)
+    assert set(out) == {"inv_depths", "inv_depths_rgbd", "depth_loss", "skip_feat_rgb", "skip_feat_rgbd"}
+    assert len(out["inv_depths"]) == 4 and len(out["inv_depths_rgbd"]) == 4 and len(out["skip_feat_rgbd"]) == 6
+    want = sum(((a.detach().float() - b.detach().float()) ** 2).mean() for a, b in zip(out["skip_feat_rgbd"], out["skip_feat_rgb"])) / 6
+    assert abs(float(out["depth_loss"]) - float(want)) <= 2e-3 * float(want) + 1e-7
+    assert float(out["depth_loss"]) > 0
+    assert rel_err(out["inv_depths_rgbd"][0].float(), out["inv_depths"][0].float()) > 1e-4
+    loss = out["depth_loss"] + sum(i.float().mean() for i in out["inv_depths"]) + sum(i.float().mean() for i in out["inv_depths_rgbd"])
+    loss.backward()
+    torch.cuda.synchronize()
+    for name, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert all(float(p.grad.abs().max()) > 0 for p in net.mconvs.parameters())
+    assert float(net.weight.grad.abs().min()) > 0 and float(net.bias.grad.abs().min()) > 0
+    assert float(net.encoder.conv1.conv_base.weight.grad.abs().max()) > 0
+
+
+def test_edge_estimation_lidar_model_training_step():
+    """DEE training WITH a LiDAR input (reference EdgeEstimationLIDARModel.py:135-160):
+    loss = depth_loss + (edge_rgb + weight_rgbd * edge_lidar) / 2, both edge terms BCE on the halved network output."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.utils.config import load_config
+    from mindtheedge_amd.utils.synthetic import synthetic_batch
+    K.set_compute_dtype("fp32")
+    cfg = load_config(None, {"model": {"name": "EdgeEstimationLIDARModel", "loss": {"edges_depth_edge_loss_all_scales": True}},
+                             "edges": {"train_depth_edges": True}})
+    torch.manual_seed(7)
+    wrap = ModelWrapper(cfg).cuda().train()
+    assert wrap.depth_net.with_san
+    _randomise(wrap.depth_net.mconvs, seed=3)
+    batch = synthetic_batch(2, 64, 128, seed=4, device=torch.device("cuda", 0))
+    batch["input_depth"] = _lidar(2, 64, 128, seed=5, density=0.1).cuda() * 2.0
+    wrap.model._pinned_flip = False
+    out = wrap.model(dict(batch))
+    assert {"edge_loss", "edge_lidar_loss"} <= set(out["metrics"]) and "depth_loss" in out and "inv_depths_rgbd" in out
+    head = wrap.model.edge_loss_head
+    def edge_term(probs):
+        tot = 0.0
+        for s in range(4):
+            l, _ = head(probs[s].detach(), batch["edge" if s == 0 else "edge_%d" % s], None, False, False, 0)
+            tot = tot + float(l)
+        return tot / 4
+    e_rgb, e_lidar = edge_term(out["inv_depths"]), edge_term(out["inv_depths_rgbd"])
+    assert abs(float(out["metrics"]["edge_loss"]) - e_rgb) < 1e-5 * max(1.0, abs(e_rgb))
+    assert abs(float(out["metrics"]["edge_lidar_loss"]) - e_lidar) < 1e-5 * max(1.0, abs(e_lidar))
+    want = float(out["depth_loss"]) + (e_rgb + wrap.model.weight_rgbd * e_lidar) / 2
+    assert abs(float(out["loss"]) - want) < 1e-5 * max(1.0, abs(want))
+    # the network saw input_depth / 200 (reference :108-110)
+    with torch.no_grad():
+        again = wrap.depth_net(batch["rgb"], input_depth=batch["input_depth"] / 200.0)
+    assert rel_err(again["inv_depths_rgbd"][0].float() / 2, out["inv_depths_rgbd"][0].float()) < 1e-4
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    grads = [p.grad for p in wrap.depth_net.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+    assert all(float(p.grad.abs().max()) > 0 for p in wrap.depth_net.mconvs.parameters())

@@ -18,6 +18,7 @@ def main():
     ap.add_argument('file', type=str, help='Input file (.yaml)')
     ap.add_argument('--synthetic', action='store_true')
     ap.add_argument('--steps', type=int, default=20, help='steps per epoch for --synthetic')
+    ap.add_argument('--synthetic-lidar', action='store_true', help="add a sparse 'input_depth' to the synthetic batches (DEE training with LiDAR)")
     ap.add_argument('--epochs', type=int, default=1)
     ap.add_argument('--data', type=str, default=None)
     ap.add_argument('--resume', type=str, default=None, help='.ckpt in the reference layout (model_checkpoint.py:71-81) to resume from')
@@ -46,7 +47,8 @@ def main():
         loader = getattr(importlib.import_module(mod), fn)(config, trainer.proc_rank, trainer.world_size)
     else:
         assert args.synthetic, 'no dataset: pass --synthetic or --data module:callable'
-        loader = SyntheticLoader(config.datasets.train.batch_size, H, W, args.steps, trainer.device, trainer.proc_rank)
+        loader = SyntheticLoader(config.datasets.train.batch_size, H, W, args.steps, trainer.device, trainer.proc_rank,
+                                 lidar=args.synthetic_lidar)
     wrapper.set_dataloaders(train=loader)
     trainer.max_epochs = wrapper.current_epoch + args.epochs
     hist = trainer.fit(wrapper)
