@@ -5,8 +5,10 @@ packnet_sfm/networks/depth/PackNetSAN01.py: same constructor signature, module t
   train: {'inv_depths': [4 x fp32 [B,1,H/2^s,W/2^s]]}                         (reference :319-322)
   eval : {'inv_depths': [[4 maps], [skip0..skip4, x5p]]}                       (reference :282-293)
 
-The sparse LiDAR (SAN / MinkowskiEngine) branch is outside this build's scope: passing
-``input_depth`` raises NotImplementedError instead of silently ignoring it.
+  train with input_depth (with_san=True): + 'inv_depths_rgbd', 'depth_loss'     (reference :324-342, two passes)
+
+The sparse LiDAR (SAN) branch is materialised on request (``with_san=True``, SURVEY.md 8(f-1), parity unpinned: the reference
+runs it on MinkowskiEngine); without it ``input_depth`` raises NotImplementedError instead of being silently ignored.
 """
 import os
 
