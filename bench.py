@@ -308,11 +308,30 @@ def main():
         reducer = BucketedAllReduce(flat, force=True) if dist_on else None
         opt = FusedAdam(flat, lr=1e-4, reducer=reducer)
 
+        boundary = []                      # MTE_BENCH_BOUNDARY=1 (development): GPU time from the end of Adam to the first kernel of the next forward
+        if os.environ.get("MTE_BENCH_BOUNDARY"):
+            _img = K.image_to_act
+            state = {"adam": None}
+
+            def image_to_act(*a, **k):
+                if state["adam"] is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    boundary.append((state["adam"], e))
+                    state["adam"] = None
+                return _img(*a, **k)
+            K.image_to_act = image_to_act
+            import mindtheedge_amd.networks.layers.packnet.layers01 as _l01
+            _l01.K = K
+
         def eager_step():
             opt.zero_grad()
             out = model(batch)
             out["loss"].backward()
             opt.step()
+            if os.environ.get("MTE_BENCH_BOUNDARY"):
+                state["adam"] = torch.cuda.Event(enable_timing=True)
+                state["adam"].record()
             return out["loss"]
         step, launch_mode = eager_step, "eager"
         if dist_on:
@@ -355,6 +374,10 @@ def main():
     host_dt = time.perf_counter() - t0                   # time the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0
+    if args.mode == "train" and boundary:
+        gaps = [a.elapsed_time(b) for a, b in boundary[-args.steps + 1:]]
+        print("step boundary (end of Adam -> image conversion of the next step), ms: min %.3f median %.3f max %.3f"
+              % (min(gaps), sorted(gaps)[len(gaps) // 2], max(gaps)), file=sys.stderr)
     # Per-kernel HIP-event timing runs on `ksteps` further steps of the same workload, outside the clocked region:
     # an event pair around each of the ~280 conv launches per step costs ~50 us of GPU idle each (14 ms/step), which
     # would distort `value`; the kernel durations themselves are unaffected by the gaps.

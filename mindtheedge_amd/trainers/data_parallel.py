@@ -13,6 +13,8 @@ messages amortise the ring's per-link latency better than 218 small ones, and th
 (pack5.conv 151 MB, pack4.conv 38 MB) finish early in backward, so their all-reduces hide under the high-resolution
 layers' backward.  ``step()`` waits for the outstanding collectives and runs one fused Adam kernel over the flat buffers.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -199,6 +201,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.steps = 0
         self.hyper = torch.zeros(3, dtype=torch.float32, device=flat.flat.device)    # lr, 1 - b1^t, sqrt(1 - b2^t): read by the kernel
+        self._hyper_pinned = None
 
     def zero_grad(self, set_to_none=False):
         self.flatp.zero_grad()
@@ -235,7 +238,17 @@ class FusedAdam(torch.optim.Optimizer):
         self.steps += 1
         b1, b2 = g['betas']
         vals = [float(g['lr']), 1.0 - math.pow(float(b1), self.steps), math.sqrt(1.0 - math.pow(float(b2), self.steps))]
-        self.hyper.copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=True)
+        if self.hyper.is_cuda and not os.environ.get("MTE_ADAM_PAGEABLE_HYPER"):
+            # a copy from pageable memory makes the host wait for the stream (every step: the GPU then idles while the host catches
+            # up with the next forward pass); a ring of pinned slots keeps the upload asynchronous -- the host is never more than a
+            # couple of steps ahead of the device, 16 slots cannot wrap onto a transfer that is still pending
+            if self._hyper_pinned is None:
+                self._hyper_pinned = torch.empty((16, 3), dtype=torch.float32).pin_memory()
+            slot = self._hyper_pinned[self.steps % 16]
+            slot[0], slot[1], slot[2] = vals
+            self.hyper.copy_(slot, non_blocking=True)
+        else:
+            self.hyper.copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=True)
 
     def set_index_space(self, names, local_names):
         """Number the optimizer state like the reference's ``torch.optim.Adam(depth_net.parameters())`` does.
