@@ -34,8 +34,9 @@ class SfmModel(BaseModel):
         # never reaches the loss and is skipped here; in eval mode it IS the prediction the reference validates, and it is
         # taken when the network owns the sparse branch (PackNetSAN01(with_san=True), parity unpinned)
         batch_input.pop('input_depth', None)
-        if 'input_depth' in batch and getattr(self.depth_net, 'with_san', False) and (not self.training or self._train_with_lidar):
-            batch_input['input_depth'] = batch['input_depth']
+        has_san = getattr(self.depth_net, 'with_san', False)
+        if 'input_depth' in batch and ((self.training and self._train_with_lidar) or (not self.training and has_san)):
+            batch_input['input_depth'] = batch['input_depth']          # (a network without the branch raises in train mode: no silent RGB-only step)
         batch_input['output_features'] = output_features
         if flip:
             return flip_output(self.depth_net(**flip_batch_input(batch_input)))
