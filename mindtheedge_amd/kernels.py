@@ -162,6 +162,15 @@ def as_act(t, dtype=None):
 
 def _pl(t):
     """(device pointer, elements per pixel) of an NHWC activation."""
+    if t.dim() == 4:                    # fast path (~2000 calls per training step): the plain [B,C,H,W]-over-NHWC case
+        B, C, H, W = t.shape
+        sb, sc, sh, sw = t.stride()
+        if sc == 1 and W > 1 and H > 1 and sh == W * sw and (B == 1 or sb == H * sh) and sw >= C:
+            dt = t.dtype
+            if (dt is torch.bfloat16 and not (sw & 7)) or (dt is torch.float32 and not (sw & 3)):
+                p = t.data_ptr()
+                if not (p & 15):
+                    return p, sw
     if not is_act(t):
         raise MteError("expected an NHWC activation, got shape %s strides %s" % (tuple(t.shape), t.stride()))
     B, C, H, W = t.shape

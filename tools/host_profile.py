@@ -36,6 +36,27 @@ pr.disable()
 host = (time.perf_counter() - t0) / 4
 torch.cuda.synchronize()
 print("host ms/step under cProfile: %.1f" % (host * 1e3))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3): step()
+print("host ms/step, 3 steps enqueued after a sync, no profiler: %.1f" % ((time.perf_counter() - t0) / 3 * 1e3))
+torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(38)
 print(s.getvalue()[:9000])
+
+# ---- the backward half runs in the autograd engine's device thread: switch a profiler on from inside the first backward call
+bpr = cProfile.Profile()
+state = {"on": False}
+orig = K.DepthLossesFn.backward
+def first_backward(ctx, *a):
+    if not state["on"]:
+        bpr.enable(); state["on"] = True
+    return orig(ctx, *a)
+K.DepthLossesFn.backward = staticmethod(first_backward)
+for _ in range(4): step()
+torch.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(bpr, stream=s).sort_stats("tottime").print_stats(30)
+print("==== autograd thread (4 steps)")
+print(s.getvalue()[:7000])
