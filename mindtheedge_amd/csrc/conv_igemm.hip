@@ -337,7 +337,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             constexpr int ES = (int)sizeof(T);
             static_assert(BM * BN * ES <= ST * (BM + BN) * 64, "output tile must fit the ring");
             __syncthreads();                              // every wave is done reading the ring
-            float* s_gn = (float*)(smem + ST * (BM + BN) * 64);       // [2 samples][16 groups][2], extra 256 B of dynamic LDS
+            // [2 samples][16 groups][2] statistics scratch: behind the output staging when the ring is larger than the tile (then the
+            // launch needs no LDS beyond the ring -- a 256 x 128 workgroup takes exactly 96 KB and leaves 64 KB of the CU for a
+            // 128 x 128 weight-gradient workgroup of the other stream), else in 256 extra bytes
+            float* s_gn = (float*)(smem + ((BM * BN * ES + 256 <= ST * (BM + BN) * 64) ? BM * BN * ES : ST * (BM + BN) * 64));
             if (a.gn_stats && tid < 64) s_gn[tid] = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -470,6 +473,7 @@ inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems, i
     return (int)(s < 1 ? 1 : s);
 }
 
+int g_igemm_lds_tight = 1;                           // development knob (mte_debug_set(18, v)): no 256 extra LDS bytes where the statistics scratch fits the ring
 int g_igemm_ablate = 0;                              // development knob (mte_debug_set(17, v)): main-loop ablation, see ABL
 int g_igemm_ring6 = 0;                               // development knob (mte_debug_set(15, v)) for the 8-wave 256 x 128 tile: 1 = 6-slot ring, 3 = 3-slot ring with two workgroups per CU
 
@@ -488,7 +492,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
     if (a.splits > 1 && mte_memset_async(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
     if constexpr ((BN * 4) % NTHR == 0) {
         if (g_igemm_dma) {
-            const size_t lds4 = 4 * (BM + BN) * 64 + 256;
+            const size_t lds4 = 4 * (BM + BN) * 64 + (((long)BM * BN * (long)sizeof(T) + 256 <= 4L * (BM + BN) * 64) && g_igemm_lds_tight ? 0 : 256);
             const long es = (long)sizeof(T);
             const bool fast = g_igemm_dma == 1 && a.Cin_p % (4 * Elem<T>::PER16) == 0 &&
                               ((a.M - 1) * a.ldx + a.Cin_p) * es < 0x7ff00000L && (long)a.N * a.KH * a.KW * a.Cin_p * es < 0x7ff00000L;
@@ -1282,6 +1286,7 @@ int mte_debug_set(int key, int value) {
     if (key == 13) return mtei_set_gn(2, value);
     if (key == 15) { g_igemm_ring6 = value; return MTE_OK; }
     if (key == 17) { g_igemm_ablate = value; return MTE_OK; }
+    if (key == 18) { g_igemm_lds_tight = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
