@@ -235,15 +235,19 @@ struct PatchWgradArgs {
 // SL = 32-channel input slices per workgroup (2 halves the dy re-reads and doubles the MFMA work per staged tile:
 // the 3x3 high-resolution layers are HBM-bound, ~9 k MAC per 128 B).  LDS is single-buffered: the next tile waits in
 // registers while the current one is consumed.
-template <int K, int NT, int SL>
-__global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a) {
+// NW = waves per workgroup: 4, or 8 (two waves per SIMD share the staged tile: the kernel holds one 114 KB workgroup per CU, and
+// with a single wave per SIMD every LDS read latency and barrier of the k-loop was exposed).
+template <int K, int NT, int SL, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArgs a) {
+    constexpr int NTHR = NW * 64;
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
-    constexpr int UNITS = TAPS * SL;                               // (tap, slice) accumulator units, dealt round-robin to the 4 waves
-    constexpr int TPW = (UNITS + 3) / 4;                           // (dealing whole taps left 3x3 layers at 3:2:2:2 -- 25 % of the MFMA slots idle)
+    constexpr int UNITS = TAPS * SL;                               // (tap, slice) accumulator units, dealt round-robin to the waves
+    constexpr int TPW = (UNITS + NW - 1) / NW;                           // (dealing whole taps left 3x3 layers at 3:2:2:2 -- 25 % of the MFMA slots idle)
     constexpr int XRS = SL == 1 ? 64 : 192;                        // x / dy pixel row strides: odd multiples of 64 B
-    constexpr int XCH = PH * PW * 4 * SL, NXC = (XCH + 255) / 256;
+    constexpr int XCH = PH * PW * 4 * SL, NXC = (XCH + NTHR - 1) / NTHR;
     constexpr int YRS = NT == 1 ? 64 : 192;
-    constexpr int YCH = TH * TW * NT * 4, NYC = YCH / 256;
+    constexpr int YCH = TH * TW * NT * 4, NYC = YCH / NTHR;
+    static_assert(YCH % NTHR == 0, "the dy tile must split evenly over the threads");
     constexpr int XBYTES = PH * PW * XRS;
     extern __shared__ __attribute__((aligned(16))) char smem[];    // [XBYTES] then [TH*TW*YRS]
     char* X = smem;
@@ -265,19 +269,19 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
         const int x0 = tx_ * TW, y0 = ty_ * TH;
 #pragma unroll
         for (int i = 0; i < NXC; ++i) {
-            const int idc = tid + i * 256;
+            const int idc = tid + i * NTHR;
             const int p = idc / (4 * SL), kc = idc - p * (4 * SL);
             const int py = p / PW, px = p - py * PW;
             const int iy = y0 + py - PAD, ix = x0 + px - PAD;
             const int cc = slice * 4 * SL + kc;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if ((XCH % 256 == 0 || idc < XCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cpt)
+            if ((XCH % NTHR == 0 || idc < XCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cpt)
                 v = *(const u32x4_t*)(a.x + (((long)b * a.H + iy) * a.W + ix) * a.ldx + cc * 8);
             sx[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < NYC; ++i) {
-            const int idc = tid + i * 256;
+            const int idc = tid + i * NTHR;
             const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
             const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
             u32x4_t v = {0u, 0u, 0u, 0u};
@@ -288,13 +292,13 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NXC; ++i) {
-            const int idc = tid + i * 256;
+            const int idc = tid + i * NTHR;
             const int p = idc / (4 * SL), kc = idc - p * (4 * SL);
-            if (XCH % 256 == 0 || idc < XCH) *(u32x4_t*)(X + p * XRS + kc * 16) = sx[i];
+            if (XCH % NTHR == 0 || idc < XCH) *(u32x4_t*)(X + p * XRS + kc * 16) = sx[i];
         }
 #pragma unroll
         for (int i = 0; i < NYC; ++i) {
-            const int idc = tid + i * 256;
+            const int idc = tid + i * NTHR;
             const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
             *(u32x4_t*)(Y + pix * YRS + c * 16) = sy[i];
         }
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const int u = wave + 4 * i;
+                    const int u = wave + NW * i;
                     if (u < UNITS) {
                         const int tap = u / SL, sl = u - tap * SL;
                         const int dyy = tap / K, dxx = tap - dyy * K;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void conv_patch_wgrad_kernel(PatchWgradArgs a)
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int u = wave + 4 * i;
+        const int u = wave + NW * i;
         if (u >= UNITS) continue;
         const int tap = u / SL, sl = u - tap * SL;
         const int cc = (slice * SL + sl) * 32 + r;
@@ -398,7 +402,9 @@ template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
     return MTE_ERR_UNSUPPORTED;
 }
 
-template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream_t st, int parts_cap, int* parts_out) {
+int g_patch_wgrad_8w = 1;                            // development knob (mte_debug_set(11, 200 + v)): 0 = four waves per workgroup everywhere
+
+template <int K, int NT, int SL, int NW = 4> int launch_wgrad_sl(PatchWgradArgs a, hipStream_t st, int parts_cap, int* parts_out) {
     constexpr int PH = TH + K - 1, PW = TW + K - 1;
     constexpr int XRS = SL == 1 ? 64 : 192, YRS = NT == 1 ? 64 : 192;
     const size_t lds = PH * PW * XRS + TH * TW * YRS;
@@ -409,7 +415,7 @@ template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream
     a.groups = (int)groups;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_patch_wgrad_kernel<K, NT, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_patch_wgrad_kernel<K, NT, SL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MTE_ERR_LAUNCH;
         attr_set = true;
     }
@@ -421,13 +427,24 @@ template <int K, int NT, int SL> int launch_wgrad_sl(PatchWgradArgs a, hipStream
         if (parts_out) *parts_out = 1;
         if (mte_memset_async(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT, SL>), dim3((unsigned)groups, nslices), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT, SL, NW>), dim3((unsigned)groups, nslices), dim3(NW * 64), lds, st, a);
     return mte_check_launch();
 }
 template <int K, int NT> int launch_wgrad(const PatchWgradArgs& a, hipStream_t st, int parts_cap, int* parts_out) {
     // two slices per workgroup where the accumulators still fit (3x3 and 1x1; 5x5 with C_out <= 32) and there is more than one slice
+    // eight waves (two per SIMD on the one workgroup a CU holds) where a wave still gets enough accumulator units: two output
+    // tiles per unit, or >= 32 units.  Same-box A/B per launch: 7x7 32->32 @384x1280 0.510 -> 0.388 ms, 3x3 64->64 @192x640
+    // 0.146 -> 0.108, 5x5 256->64 @96x320 0.272 -> 0.205; the one-tile launches with 18 / 25 units lose 14-20 % and stay on four.
     if constexpr (K <= 3 || (K == 5 && NT == 1)) {
-        if (a.Cin_p > 32) return launch_wgrad_sl<K, NT, 2>(a, st, parts_cap, parts_out);
+        if (a.Cin_p > 32) {
+            if constexpr (K * K * 2 >= 16 && (NT == 2 || K * K * 2 >= 32)) {
+                if (g_patch_wgrad_8w) return launch_wgrad_sl<K, NT, 2, 8>(a, st, parts_cap, parts_out);
+            }
+            return launch_wgrad_sl<K, NT, 2>(a, st, parts_cap, parts_out);
+        }
+    }
+    if constexpr (K * K >= 16 && (NT == 2 || K * K >= 32)) {
+        if (g_patch_wgrad_8w) return launch_wgrad_sl<K, NT, 1, 8>(a, st, parts_cap, parts_out);
     }
     return launch_wgrad_sl<K, NT, 1>(a, st, parts_cap, parts_out);
 }
@@ -448,7 +465,7 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 
 }  // namespace
 
-extern "C" int mtei_set_patch_tall(int v) { if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
+extern "C" int mtei_set_patch_tall(int v) { if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
 
 extern "C" {
 
