@@ -434,6 +434,9 @@ def main():
             with open(args.dump_conv, "w") as f:
                 for ms_, name, shp, fl in sorted(rows, reverse=True):
                     f.write("%8.3f ms %7.1f TF  %-24s B,H,W,Cin_p,N,KH,KW=%s\n" % (ms_, fl / ms_ / 1e9, name, shp))
+                hrows = [(e0.elapsed_time(e1), name, by) for name, e0, e1, by in timer.hbm_records[:len(timer.hbm_records) // max(ksteps, 1)]]
+                for ms_, name, by in sorted(hrows, reverse=True):
+                    f.write("%8.3f ms %7.2f TB/s  %-24s %.1f MB\n" % (ms_, by / ms_ / 1e9, name, by / 1e6))
         if timer:
             s = timer.summary()
             tot_t = sum(v[1] for v in s.values())

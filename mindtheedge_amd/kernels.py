@@ -1142,7 +1142,15 @@ class ConcatFn(torch.autograd.Function):
 
 def new_concat_buffer(B, chans, with_inv, H, W, dtype=None, device="cuda"):
     """Decoder concat buffer for ConcatFn: channel blocks `chans` (+ one 8-channel block for an up-sampled inv-depth map)."""
-    return new_act(B, sum(chans) + (8 if with_inv else 0), H, W, dtype or compute_dtype(), device)
+    c = sum(chans) + (8 if with_inv else 0)
+    ld = (c + 31) // 32 * 32
+    if ld == c or os.environ.get("MTE_CONCAT_TIGHT"):
+        return new_act(B, c, H, W, dtype or compute_dtype(), device)
+    # pixel stride padded to a multiple of 64 bytes (72 -> 96, 136 -> 160, 200 -> 224 channels): with 144 / 272 / 400 bytes per pixel
+    # every channel block of every pixel starts inside a 64-byte sector and the producers' 64-byte runs straddle two of them --
+    # the GroupNorm pass writing the stem's skip into iconv1's buffer ran at 2.0 TB/s against 5.8 TB/s for the same pass into a
+    # dense tensor.  The logical channel count is unchanged (kernels take pointer + pixel stride), the tail is never touched.
+    return alias_of(new_act(B, ld, H, W, dtype or compute_dtype(), device)[:, :c])
 
 
 def image_to_act(rgb, flip=False, dtype=None):
