@@ -369,6 +369,7 @@ def prefetch_weight_packs():
     ev.record()                                              # the parameter update (and every earlier user of the packs)
     side.wait_event(ev)
     with torch.cuda.stream(side):
+        _refold_all()                                        # folded pack weights first: their packs are rebuilt in the loop below
         group = []
         for i, pk in enumerate(packs):
             w, dtype = pk._last[0](), pk._last[1]
@@ -868,6 +869,53 @@ def pack_fold_applicable(H2, W2, k):
     return H2 > 2 * hb and W2 > 2 * hb and (2.0 * hb / H2 + 2.0 * hb / W2) <= _cfg["pack_fold_max_overhead"]
 
 
+def _fold_key(w, w3, b, b3):
+    return (weights_epoch(), w.data_ptr(), w._version, w3.data_ptr(), w3._version, b.data_ptr(), b._version, b3.data_ptr(), b3._version)
+
+
+def _fold_now(f, w, w3, b, b3):
+    co, C4, k = f["geom"]
+    lib.mte_fold_pack_weights(w.detach().data_ptr(), w3.detach().contiguous().float().data_ptr(), b.detach().data_ptr(),
+                              b3.detach().contiguous().float().data_ptr(), f["Wf"].data_ptr(), f["bf"].data_ptr(), co, C4, k, _stream())
+    f["key"] = _fold_key(w, w3, b, b3)
+
+
+def _folded_weights(pack_fold, w, w3, b, b3, co, C, k, dev):
+    """(W', b') of the folded pack convolution, kept per layer and re-folded only when a parameter changed: by the optimizer hook
+    below on the weight-pack side stream right after the update (70 us + two pack kernels per layer that used to sit on the main
+    stream in front of the convolution), or here, inline, on first use / after an out-of-band parameter change."""
+    f = getattr(pack_fold, "fold", None)
+    if f is None or f["geom"] != (co, 4 * C, k) or f["Wf"].device != dev:
+        f = pack_fold.fold = {"geom": (co, 4 * C, k), "key": None,
+                              "Wf": torch.empty((co, 4 * C, k + 2, k + 2), dtype=torch.float32, device=dev),
+                              "bf": torch.empty((co,), dtype=torch.float32, device=dev)}
+        _fold_hooks.append(weakref.ref(pack_fold))
+    f["params"] = tuple(weakref.ref(t) for t in (w, w3, b, b3))
+    if f["key"] != _fold_key(w, w3, b, b3) or _FOLD_INLINE:
+        _fold_now(f, w, w3, b, b3)
+        pack_fold.key = None                               # the pack of W' is stale too
+    return f["Wf"], f["bf"]
+
+
+_FOLD_INLINE = bool(os.environ.get("MTE_FOLD_INLINE"))     # development A/B: re-fold in every forward pass (the round-1 behaviour)
+_fold_hooks = []            # weak references to the fold WeightPacks (prefetch_weight_packs re-folds them before it re-packs)
+
+
+def _refold_all():
+    """called by prefetch_weight_packs on the side stream, after the optimizer changed the parameters"""
+    live = []
+    for r in _fold_hooks:
+        pk = r()
+        f = getattr(pk, "fold", None) if pk is not None else None
+        if f is None:
+            continue
+        live.append(r)
+        ps = [p() for p in f.get("params", ())]
+        if len(ps) == 4 and all(p is not None for p in ps) and f["key"] != _fold_key(*ps):
+            _fold_now(f, *ps)
+    _fold_hooks[:] = live
+
+
 class PackFoldedConvGnEluFn(torch.autograd.Function):
     """PackLayerConv3d as ONE (k+2)x(k+2) convolution over the packed tensor: conv3d(1->4) is folded into the k x k conv
     weights (csrc/pack_fold.hip), halving the MACs of pack1 and removing the 16C-channel intermediate.  The k/2-pixel
@@ -887,11 +935,7 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         xp, ldx = _pl(x)
         pp, ldp = _pl(P)
         lib.mte_pixel_shuffle(xp, ldx, pp, ldp, B, H, W, C, 0, dt, st)
-        Wf = torch.empty((co, 4 * C, k + 2, k + 2), dtype=torch.float32, device=dev)
-        bf = torch.empty((co,), dtype=torch.float32, device=dev)
-        lib.mte_fold_pack_weights(w.detach().data_ptr(), w3c.data_ptr(), b.detach().data_ptr(), b3c.data_ptr(), Wf.data_ptr(), bf.data_ptr(),
-                                  co, 4 * C, k, st)
-        pack_fold.key = None
+        Wf, bf = _folded_weights(pack_fold, w, w3, b, b3, co, C, k, dev)
         wfp, _ = pack_fold.get(Wf, x.dtype, False)
         y = conv_forward(P, wfp, bf, co, k + 2, k + 2, pack=pack_fold, w=Wf)
         # exact border bands: group 1 = top/bottom rows, group 2 = left/right columns (rows pad .. H2-pad)
