@@ -64,3 +64,56 @@ def test_folded_pack_bf16(C, k, B, H, W):
     for key in r:
         err = rel_err(a[key], r[key])
         assert err < 6e-2 or float((a[key] - r[key]).abs().max()) < 1e-1, (key, err)
+
+
+def test_folded_weights_follow_parameter_changes():
+    """The folded weights are cached per layer (kernels._folded_weights): they must follow (a) an in-place parameter change,
+    (b) an optimizer step on the flat master buffers -- re-folded by the weight-pack prefetch on the side stream -- and
+    (c) stay put when nothing changed (inference)."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.layers.packnet.layers01 import PackLayerConv3d
+    from mindtheedge_amd.trainers.data_parallel import FlatParameters, FusedAdam
+    K.set_compute_dtype("fp32")
+    old = K._cfg["pack_fold_max_overhead"]
+    K._cfg["pack_fold_max_overhead"] = 100.0
+    try:
+        torch.manual_seed(3)
+        m = PackLayerConv3d(32, 3, d=4).cuda()
+        for p in m.parameters():
+            p.data.normal_(0, 0.2)
+        x = K.image_to_act((torch.rand(2, 32, 24, 40, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda())
+
+        def both():
+            K.use_pack_folding(True)
+            with torch.no_grad():
+                a = m(x).float()
+            K.use_pack_folding(False)
+            with torch.no_grad():
+                r = m(x).float()
+            K.use_pack_folding(True)
+            return a, r
+        a0, r0 = both()
+        assert rel_err(a0, r0) < 3e-4
+        a1, _ = both()
+        assert rel_err(a0, a1) < 1e-6                                # (c) cached fold, same result (GroupNorm statistics are atomic sums)
+        with torch.no_grad():
+            m.conv3d.weight.mul_(1.5)                                # (a) in-place change bumps the version counter
+            m.conv.conv_base.bias.add_(0.1)
+        a2, r2 = both()
+        assert rel_err(a2, r2) < 3e-4 and rel_err(a2, a0) > 1e-2
+        flat = FlatParameters(m.parameters())                        # (b) the optimizer writes through raw pointers: epoch bump + prefetch
+        opt = FusedAdam(flat, lr=5e-2)
+        K.use_pack_folding(True)
+        for _ in range(2):
+            opt.zero_grad()
+            y = m(x.detach())
+            (y.float() ** 2).mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        a3, r3 = both()
+        assert rel_err(a3, r3) < 3e-4 and rel_err(a3, a2) > 1e-3
+    finally:
+        K._cfg["pack_fold_max_overhead"] = old
+        K.use_pack_folding(True)
+        K.set_grad_sink(None)
+        K.set_compute_dtype("bf16")
