@@ -65,6 +65,8 @@ int mte_set_option(int option, int value);
  *   14 GroupNorm second passes walk the samples in reverse order (Infinity-Cache reuse; 1 [default])
  *   15 implicit GEMM, 8-wave 256x128 tile: 0 [default] 4-slot LDS ring, 3-slot / two workgroups per CU for MTE_CONV_SOLO launches;
  *      1 = 6 slots, 3 = always 3 slots x 2 workgroups, 4 = always 4 slots
+ *   18 implicit GEMM: statistics scratch inside the ring where it fits (1 [default]); 19: two-workgroup 256x128 variant beside the
+ *      weight-gradient stream for launches with at most this many K-steps and >= 512 tiles (72 [default], 0 = solo launches only)
  *   17 implicit GEMM main-loop ablation (tools/igemm_ablate.py): leave out 1 MFMAs | 2 in-loop LDS-DMA | 4 fragment reads; results are garbage */
 int mte_debug_set(int key, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over

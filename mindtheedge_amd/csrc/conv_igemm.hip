@@ -473,6 +473,7 @@ inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems, i
     return (int)(s < 1 ? 1 : s);
 }
 
+int g_igemm_pair_ksteps = 72;                        // development knob (mte_debug_set(19, v))
 int g_igemm_lds_tight = 1;                           // development knob (mte_debug_set(18, v)): no 256 extra LDS bytes where the statistics scratch fits the ring
 int g_igemm_ablate = 0;                              // development knob (mte_debug_set(17, v)): main-loop ablation, see ABL
 int g_igemm_ring6 = 0;                               // development knob (mte_debug_set(15, v)) for the 8-wave 256 x 128 tile: 1 = 6-slot ring, 3 = 3-slot ring with two workgroups per CU
@@ -512,7 +513,11 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
                 }
             }
             if constexpr (sizeof(T) == 2 && BM == 256 && BN == 128) {
-                if (fast && (g_igemm_ring6 == 3 || (g_igemm_ring6 == 0 && a.solo))) {
+                // two 74 KB workgroups per CU (3-slot ring): always for solo launches; beside the weight-gradient stream only for short
+                // reductions over several rounds of tiles, where the prologue / epilogue share is largest (same-box step 30.46 -> 30.30 ms;
+                // for every launch it costs the step 0.2 ms)
+                const bool pair = a.solo || (ksteps <= g_igemm_pair_ksteps && tiles >= 512);
+                if (fast && (g_igemm_ring6 == 3 || (g_igemm_ring6 == 0 && pair))) {
                     constexpr size_t lds3 = 3 * (BM + BN) * 64 + 256;
                     static bool attr3 = false;
                     if (!attr3) {
@@ -1287,6 +1292,7 @@ int mte_debug_set(int key, int value) {
     if (key == 15) { g_igemm_ring6 = value; return MTE_OK; }
     if (key == 17) { g_igemm_ablate = value; return MTE_OK; }
     if (key == 18) { g_igemm_lds_tight = value; return MTE_OK; }
+    if (key == 19) { g_igemm_pair_ksteps = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
