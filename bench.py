@@ -374,6 +374,13 @@ def main():
     host_dt = time.perf_counter() - t0                   # time the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0
+    # the host's own cost per step: three steps enqueued right after a sync (empty queues: `host_dt` above also contains the time the
+    # host spends blocked on full hardware queues while it runs ahead of the GPU)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        last = step()
+    host_free_dt = (time.perf_counter() - t1) / 3
+    sync()
     if args.mode == "train" and boundary:
         gaps = [a.elapsed_time(b) for a, b in boundary[-args.steps + 1:]]
         print("step boundary (end of Adam -> image conversion of the next step), ms: min %.3f median %.3f max %.3f"
@@ -425,7 +432,8 @@ def main():
                           "global_batch": B * world, "height": H, "width": W,
                           "parallelism": "dp%d (bucketed RCCL all-reduce overlapped with backward)" % world if world > 1 else "single GPU"},
                "final_loss" if args.mode == "train" else "mean_inv_depth": final,
-               "host_enqueue_ms_per_step": host_dt / args.steps * 1e3, "step_launch": launch_mode}
+               "host_enqueue_ms_per_step": host_dt / args.steps * 1e3, "host_enqueue_unthrottled_ms_per_step": host_free_dt * 1e3,
+               "step_launch": launch_mode}
         passes = 3.0 if args.mode == "train" else 1.0
         step_flops = conv_flops_per_image(H, W) * B * passes
         res["mfma_fraction_of_step"] = step_flops / (ms * 1e-3) / (BF16_DENSE_PEAK_TFLOPS * 1e12)
