@@ -280,9 +280,12 @@ def main():
     import random
 
     K.set_compute_dtype(args.dtype)
-    for kv in filter(None, os.environ.get("MTE_DEBUG_KNOBS", "").split(",")):      # development A/B knobs, e.g. "2=8,3=4096"
-        k, v = kv.split("=")
-        K.lib.mte_debug_set(int(k), int(v))
+    knobs = [kv.split("=") for kv in filter(None, os.environ.get("MTE_DEBUG_KNOBS", "").split(","))]
+    if knobs:                                            # development A/B knobs, e.g. "2=8,3=4096": only libmte_hip_dev.so has them
+        from mindtheedge_amd import _lib
+        K.lib.switch(_lib.DEV_LIB_PATH, True)
+        for k, v in knobs:
+            K.lib.mte_debug_set(int(k), int(v))
     if os.environ.get("MTE_NO_SIDE_STREAM"):
         K.use_wgrad_side_stream(False)
     torch.manual_seed(42)                                # default_config.py:16 seed; xavier init per PackNetSAN01.init_weights

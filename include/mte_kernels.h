@@ -34,11 +34,10 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
 /* ---- convolution: nn.Conv2d(k, stride 1) + ConstantPad2d(k//2)  (networks/layers/packnet/layers01.py:29-31,61,116-117)
  * y = conv(x, wpack) + bias.  wpack = [N][KH*KW][Cin_p] in `dtype` (see mte_pack_conv_weights).
  * Also the data-gradient: call with the "backward" pack and x := dy.
- * workspace (nullable): fp32 scratch of >= B*H*W*N elements; when given, shapes with few output tiles and a long
- * reduction (pack4/pack5.conv at low resolution) are split along K over several workgroups.
- * gn_stats (nullable, device, [MTE_GN_REP][B][16][2] doubles, see mte_gn_stats) + gn_stats_done (nullable, HOST int): when the launched variant can, the
- * GroupNorm(16) sum / sum-of-squares of the stored outputs are accumulated in the epilogue and *gn_stats_done = 1;
- * otherwise *gn_stats_done = 0 and the caller runs mte_gn_stats.
+ * workspace (nullable): fp32 scratch of >= 2*B*H*W*N elements; when given, shapes with few output tiles and a long
+ * reduction (pack4/pack5.conv at low resolution) are split along K over up to min(8, workspace_elems / (B*H*W*N)) workgroups
+ * per tile.  Every split STORES its partial tile into its own [M][N] slab and a finish kernel adds the slabs in split order:
+ * no floating-point atomics, the result is bit-reproducible and the workspace needs no clearing.
  * accumulate = 1: y += conv(x) (sum formed in fp32, rounded once): the second data gradient of an activation with two consumers
  * lands in the first one's buffer instead of going through a separate add.  `accumulate` is a bit set: MTE_CONV_ACCUMULATE (1) and
  * MTE_CONV_SOLO (2) = no kernel of another stream is expected to run beside this launch (forward pass, inference), so the 256 x 128
@@ -48,27 +47,12 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
 #define MTE_CONV_SOLO 2
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
-                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, int accumulate, mte_stream_t stream);
-/* Library options.  MTE_OPT_GN_PREZEROED (0): when 1, the GroupNorm statistics / reduction / bias-gradient outputs handed to
- * mte_gn_stats, mte_gn_elu_bwd and the gn_stats argument of the conv entry points are already zero (the caller clears
- * one arena per step with a single memset) and the library skips its own per-call hipMemsetAsync. */
+                     float* workspace, long workspace_elems, int accumulate, mte_stream_t stream);
+/* Library options.  MTE_OPT_GN_PREZEROED (0): when 1, the GroupNorm statistics / reduction / bias-gradient buffers handed to
+ * mte_gn_stats and mte_gn_elu_bwd are already zero (the caller clears one arena per step with a single fill) and the library
+ * skips its own per-call fills. */
 #define MTE_OPT_GN_PREZEROED 0
 int mte_set_option(int option, int value);
-/* development knobs for same-box A/B measurements (tools/sweep.sh); not part of the integration surface.  key:
- *   0 igemm loader (1 buffer-descriptor LDS-DMA [default], 2 pointer LDS-DMA, 0 register staging)
- *   1 conv3d kernels (0 gather, 1 LDS-tiled, 2 + four-plane unpack data gradient [default]; 100/101 large/half-size tiles)
- *   2 / 3 GroupNorm launch geometry (min rows per thread / target workgroups)
- *   4 wgrad kernel (1 LDS-DMA ring [default], 0 register-staged)      6 igemm tiles (0 128x128, 1 + 256x128, 2 + 256x256, 3 + 192x96 [default])
- *   7 min tiles for the big igemm tiles (224)   8 wgrad 8/16-wave tiles (1)   9 wgrad workgroup target (512)
- *   11 patch conv: 0/1 tall 16x32 tiles, >= 100 = workgroup target of the patch wgrad (512)
- *   13 GroupNorm single-pass slab kernels (1 [default], 0 = streaming kernels only)
- *   14 GroupNorm second passes walk the samples in reverse order (Infinity-Cache reuse; 1 [default])
- *   15 implicit GEMM, 8-wave 256x128 tile: 0 [default] 4-slot LDS ring, 3-slot / two workgroups per CU for MTE_CONV_SOLO launches;
- *      1 = 6 slots, 3 = always 3 slots x 2 workgroups, 4 = always 4 slots
- *   18 implicit GEMM: statistics scratch inside the ring where it fits (1 [default]); 19: two-workgroup 256x128 variant beside the
- *      weight-gradient stream for launches with at most this many K-steps and >= 512 tiles (72 [default], 0 = solo launches only)
- *   17 implicit GEMM main-loop ablation (tools/igemm_ablate.py): leave out 1 MFMAs | 2 in-loop LDS-DMA | 4 fragment reads; results are garbage */
-int mte_debug_set(int key, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
  * pixels is split over workgroups; when their number fits stage_parts each one stores its PARTIAL gradient in its own part
  * (plain stores; *parts_out = parts written, mte_unpack_conv_wgrad adds them), otherwise -- always with stage_parts = 1 --
@@ -93,23 +77,27 @@ int mte_conv2d_patch_supported(int W, int Cin_p, int N, int KH, int KW, int dtyp
 long mte_conv2d_patch_pack_elems(int Cin_p, int N, int KH, int KW);
 int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
-                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, int accumulate, mte_stream_t stream);
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, int accumulate, mte_stream_t stream);
 int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 
 /* ---- GroupNorm(16, C) + ELU, optionally over y1 + scale2[b,c]*y2 (residual tail with Dropout2d)
  *      (layers01.py:32-38 Conv2D; layers01.py:62-73 ResidualConv)
- * Statistics buffers hold MTE_GN_REP partial copies, [MTE_GN_REP][B][16][2] doubles (sum, sum of squares): producers spread
- * their atomics over the copies (same-address fp64 atomics serialise), consumers add them up. */
-#define MTE_GN_REP 16
+ * A statistics buffer is mte_gn_stats_elems(B) doubles: [B][16][2] (sum, sum of squares) -- what mte_gn_elu_fwd / _bwd read --
+ * followed by the statistics pass's workspace (one arrival ticket per sample, which must be zero on entry -- cleared here unless
+ * MTE_OPT_GN_PREZEROED -- and one record per workgroup).  The pass uses no floating-point atomics: per-thread sums, fixed wave
+ * butterflies, waves in order, and the LAST workgroup of a sample adds the workgroup records in slot order, so the forward pass is
+ * bit-reproducible run to run and under HIP-graph replay (round 3; the fp32 LDS / fp64 global atomics it replaces made two
+ * forward passes of one frame differ by 1-2 % in inverse depth after ~60 bf16 layers). */
+long mte_gn_stats_elems(int B);
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
                  int B, int HW, int C, int dtype, mte_stream_t stream);
-/* mte_gn_elu_fwd: stats_ready = 1: `stats` holds the sums of mte_gn_stats (or of a conv epilogue).  stats_ready = 0 (allowed where
+/* mte_gn_elu_fwd: stats_ready = 1: `stats` holds the sums of mte_gn_stats.  stats_ready = 0 (allowed where
  * mte_gn_fwd_is_single_pass(HW, C, y2 != NULL, dtype) returns 1: a (sample, group) slab fits one workgroup's registers): the
  * kernel loads each slab ONCE, computes its statistics on chip, normalises and stores `stats` in the same format as an
  * OUTPUT for the backward pass -- the forward is then one read + one write, and mte_gn_stats is not called.
  * mte_gn_elu_bwd takes the matching one-pass route by itself where the slab of (y, dz) fits (low-resolution layers).
- * development knob 13 (mte_debug_set): 0 = streaming two-pass kernels everywhere. */
+ * (development knob 13 of the -DMTE_DEV build: 0 = streaming two-pass kernels everywhere.) */
 int mte_gn_fwd_is_single_pass(int HW, int C, int has_y2, int dtype);
 int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats, int stats_ready,
                    const float* gamma, const float* beta, void* z, long ldz,
@@ -317,6 +305,26 @@ int mte_feat_l2(const void* a, long lda, const void* b, long ldb, double* sum, v
 int mte_edge_target_from_u8(const unsigned char* src, float* dst, long n, mte_stream_t stream);
 int mte_normal_target_from_u8(const unsigned char* src, float* dst, long n, mte_stream_t stream);
 int mte_resize_depth_preserve(const float* src, int B, int h, int w, float* dst, int H, int W, int* winner_ws, mte_stream_t stream);
+
+#ifdef MTE_DEV
+/* Development knobs for same-box A/B measurements (tools/sweep.sh) and kernel-variant cross-checks (tests/).  NOT part of the
+ * integration surface: exported only by libmte_hip_dev.so, the -DMTE_DEV build of the same sources (mindtheedge_amd/_build.py);
+ * libmte_hip.so, the shipped library, has neither this entry point nor the ablation arms of the implicit-GEMM template.  key:
+ *   0 igemm loader (1 buffer-descriptor LDS-DMA [default], 2 pointer LDS-DMA, 0 register staging)
+ *   1 conv3d kernels (0 gather, 1 LDS-tiled, 2 + four-plane unpack data gradient [default]; 100/101 large/half-size tiles)
+ *   2 / 3 GroupNorm launch geometry (min rows per thread / target workgroups)
+ *   4 wgrad kernel (1 LDS-DMA ring [default], 0 register-staged)      6 igemm tiles (0 128x128, 1 + 256x128, 2 + 256x256, 3 + 192x96 [default])
+ *   7 min tiles for the big igemm tiles (224)   8 wgrad 8/16-wave tiles (1)   9 wgrad workgroup target (512)
+ *   11 patch conv: 0/1 tall 16x32 tiles, >= 100 = workgroup target of the patch wgrad (512)
+ *   13 GroupNorm single-pass slab kernels (1 [default], 0 = streaming kernels only)
+ *   14 GroupNorm second passes walk the samples in reverse order (Infinity-Cache reuse; 1 [default])
+ *   15 implicit GEMM, 8-wave 256x128 tile: 0 [default] 4-slot LDS ring, 3-slot / two workgroups per CU for MTE_CONV_SOLO launches;
+ *      1 = 6 slots, 3 = always 3 slots x 2 workgroups, 4 = always 4 slots
+ *   19 implicit GEMM: two-workgroup 256x128 variant beside the
+ *      weight-gradient stream for launches with at most this many K-steps and >= 512 tiles (72 [default], 0 = solo launches only)
+ *   17 implicit GEMM main-loop ablation (tools/igemm_ablate.py): leave out 1 MFMAs | 2 in-loop LDS-DMA | 4 fragment reads; results are garbage */
+int mte_debug_set(int key, int value);
+#endif /* MTE_DEV */
 
 #ifdef __cplusplus
 }

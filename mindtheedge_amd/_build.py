@@ -1,4 +1,9 @@
-"""Builds libmte_hip.so (gfx950 only) in-tree with hipcc.  Cross-compiles without a GPU."""
+"""Builds the gfx950 kernel libraries in-tree with hipcc (cross-compiles without a GPU):
+
+  csrc/libmte_hip.so      the product: exports exactly the integration surface of include/mte_kernels.h
+  csrc/libmte_hip_dev.so  the same sources with -DMTE_DEV: adds mte_debug_set (launch-geometry / kernel-variant knobs) and the
+                          main-loop ablation arms of the implicit GEMM, for tools/ and the kernel-variant cross-checks in tests/
+"""
 import hashlib
 import os
 import subprocess
@@ -41,16 +46,22 @@ def _stamp(target, digest):
         f.write(digest + "\n")
 
 
-def build(force=False, verbose=False):
-    """Compile every .hip for gfx950 and link the C-ABI shared library next to the sources."""
+DEV_LIB = os.path.join(CSRC, "libmte_hip_dev.so")
+
+
+def build(force=False, verbose=False, dev=True):
+    """Compile every .hip for gfx950 and link the C-ABI shared library next to the sources (and, dev=True, its -DMTE_DEV twin)."""
     hipcc = _hipcc()
     hdr = os.path.join(CSRC, "common.hpp")
+    os.makedirs(os.path.join(CSRC, "dev"), exist_ok=True)
+    variants = [("", [], LIB)] + ([("dev", ["-DMTE_DEV"], DEV_LIB)] if dev else [])
     jobs = []
-    for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
-        dig = _digest([src, hdr], " ".join(FLAGS))
-        if force or _stale(obj, dig):
-            jobs.append(([hipcc] + FLAGS + ["-c", src, "-o", obj], obj, dig))
+    for sub, extra, _ in variants:
+        for s in SOURCES:
+            src, obj = os.path.join(CSRC, s), os.path.join(CSRC, sub, s.replace(".hip", ".o"))
+            dig = _digest([src, hdr], " ".join(FLAGS + extra))
+            if force or _stale(obj, dig):
+                jobs.append(([hipcc] + FLAGS + extra + ["-c", src, "-o", obj], obj, dig))
 
     def run(cmd):
         if verbose:
@@ -65,13 +76,14 @@ def build(force=False, verbose=False):
         _stamp(obj, dig)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(int(os.environ.get("MTE_BUILD_JOBS", "6")), len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
-    lib_dig = _digest(objs, "link")
-    if force or jobs or _stale(LIB, lib_dig):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-        _stamp(LIB, lib_dig)
+    for sub, _, target in variants:
+        objs = [os.path.join(CSRC, sub, s.replace(".hip", ".o")) for s in SOURCES]
+        lib_dig = _digest(objs, "link")
+        if force or _stale(target, lib_dig):
+            run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs)
+            _stamp(target, lib_dig)
     return LIB
 
 

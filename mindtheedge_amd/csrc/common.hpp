@@ -95,11 +95,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // per-layer hipMemsetAsync launches per training step.  Defined in norm_act.hip.
 extern int g_mte_gn_prezeroed;
 
-// GroupNorm statistics buffers are [MTE_GN_REP][B][16][2] doubles: producers spread their same-address fp64 atomics over
-// MTE_GN_REP partial copies (tile / block index mod MTE_GN_REP), consumers add the copies up.  One (sample, group) address
-// took 240 (implicit GEMM) to 1900 (full-resolution patch conv) serialised atomics per launch, and a kernel does not retire
-// before they land: statistics fused into the conv epilogues cost more than the stand-alone pass they replaced.
-#define MTE_GN_REP 16
+// GroupNorm statistics buffer of a batch of B samples, in doubles (mte_gn_stats_elems(B)):
+//   [0, 32 B)                       final (sum, sum of squares) per (sample, group): what every consumer reads
+//   [32 B, 32 B + round16(B))       arrival tickets of the statistics pass (one 32-bit counter per sample, 8 bytes apart; must be 0)
+//   then [B][MTE_GN_SLOTS(B)][32]   one record per statistics workgroup (written, never accumulated: needs no clearing)
+// The statistics pass is bit-reproducible: no floating-point atomics anywhere on the forward path (norm_act.hip).
+#define MTE_GN_SLOTS(B) ((B) >= 8 ? 64 : 512 / (B))
+static inline long mte_gn_stats_elems_(int B) { return (long)B * 32 + ((B + 15) & ~15) + (long)B * MTE_GN_SLOTS(B) * 32; }
+__host__ __device__ static inline unsigned* mte_gn_tickets(double* stats, int B) { return (unsigned*)(stats + (long)B * 32); }
+__host__ __device__ static inline double* mte_gn_partials(double* stats, int B) { return stats + (long)B * 32 + ((B + 15) & ~15); }
 
 // Zero / byte-pattern fill as a KERNEL.  hipMemsetAsync must not be used on this library's launch paths: captured into a HIP
 // graph (utils/graph.py) its memset node was seen NOT to take effect on replays issued after the device had gone idle

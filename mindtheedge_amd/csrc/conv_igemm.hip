@@ -31,9 +31,9 @@ struct ConvArgs {
     void* y; long ldy; int out_f32; // output pixels
     int B, H, W, Cin_p, N, KH, KW;
     long M;
-    int splits; float* ws;          // split-K: partial sums are atomically added into ws[M][N] (fp32), finished separately
+    int splits; float* ws;          // split-K: split s STORES its partial sums into its own slab ws[s][M][N] (fp32); splitk_finish_kernel adds
+                                    // the slabs in order -- no floating-point atomics, the result does not depend on the arrival order
     int accum;                      // 1: y += conv (sum formed in fp32, rounded once) -- second gradient of a two-consumer activation
-    double* gn_stats; int gn_gs;    // optional fused GroupNorm statistics: stats[MTE_GN_REP][B][16][2] += (sum, sumsq) of the stored outputs
     int solo;                       // host-side hint (MTE_CONV_SOLO): nothing runs beside this launch on another stream
 };
 
@@ -71,8 +71,9 @@ __device__ u32x4_t g_zero16 = {0u, 0u, 0u, 0u};      // source of zero chunks fo
 // and fragment reads one K-step ahead of the MFMAs were also tried: no gain, removed.  tools/igemm_ablate.py (ABL below) shows
 // why: LDS-DMA alone takes as long as the MFMAs alone (~ 50 of the CU's 64 B / clk L1 -> LDS path), so the tile's bytes per
 // flop, not the schedule, bound the loop.
-// ABL (development, tools/igemm_ablate.py): bit set of main-loop pieces to LEAVE OUT (1 MFMAs, 2 in-loop LDS-DMA, 4 fragment ds_reads) --
-// the time that remains when a piece is removed says which pipe the loop is waiting on.  Results are garbage when ABL != 0.
+// ABL (development builds only, -DMTE_DEV, tools/igemm_ablate.py): bit set of main-loop pieces to LEAVE OUT (1 MFMAs, 2 in-loop
+// LDS-DMA, 4 fragment ds_reads) -- the time that remains when a piece is removed says which pipe the loop is waiting on.  Results
+// are garbage when ABL != 0; the product library never instantiates ABL != 0.
 template <typename T, int WM, int WN, int TM, int TN, int LD, int RING = 4, int MINW = 1, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool DMA = LD != 0;
@@ -337,11 +338,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             constexpr int ES = (int)sizeof(T);
             static_assert(BM * BN * ES <= ST * (BM + BN) * 64, "output tile must fit the ring");
             __syncthreads();                              // every wave is done reading the ring
-            // [2 samples][16 groups][2] statistics scratch: behind the output staging when the ring is larger than the tile (then the
-            // launch needs no LDS beyond the ring -- a 256 x 128 workgroup takes exactly 96 KB and leaves 64 KB of the CU for a
-            // 128 x 128 weight-gradient workgroup of the other stream), else in 256 extra bytes
-            float* s_gn = (float*)(smem + ((BM * BN * ES + 256 <= ST * (BM + BN) * 64) ? BM * BN * ES : ST * (BM + BN) * 64));
-            if (a.gn_stats && tid < 64) s_gn[tid] = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = (wn * TN + j) * 32 + r;
@@ -358,17 +354,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             __syncthreads();
             constexpr int CPR = BN / PER16;                // 16-B chunks per tile row
             const int cvalid = (a.N - n0) / PER16;         // chunks of this tile inside N (N % 8 == 0)
-            // GroupNorm statistics of the tile as stored (rounded to T) ride on the store loop: a thread keeps the same 16-byte
-            // column chunk in every iteration (NTHR % CPR == 0), so it accumulates that chunk's PER16 column sums in registers
-            // while the chunk passes through them anyway, for the (at most two: H*W >= BM is checked on the host) samples of
-            // the tile, then folds them into the tile's per-group sums with a few LDS atomics.
-            static_assert(NTHR % CPR == 0, "a thread must stay on one column chunk");
-            const long hw = (long)a.H * a.W;
-            const int b0 = (int)(m0 / hw);
-            const long rsplit = (b0 + 1) * hw - m0;                     // tile rows < rsplit belong to sample b0
-            float cs[2][PER16], cq[2][PER16];
-#pragma unroll
-            for (int k = 0; k < PER16; ++k) { cs[0][k] = cs[1][k] = 0.f; cq[0][k] = cq[1][k] = 0.f; }
             const int cc = tid % CPR;
 #pragma unroll
             for (int it = 0; it < BM * CPR / NTHR; ++it) {
@@ -385,42 +370,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
                         c = pack16<T>(vn);
                     }
                     *(u32x4_t*)((T*)a.y + m * a.ldy + n0 + cc * PER16) = c;
-                    if (a.gn_stats) {
-                        float v[PER16];
-                        unpack16<T>(c, v);
-                        if (row < rsplit) {
-#pragma unroll
-                            for (int k = 0; k < PER16; ++k) { cs[0][k] += v[k]; cq[0][k] = fmaf(v[k], v[k], cq[0][k]); }
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < PER16; ++k) { cs[1][k] += v[k]; cq[1][k] = fmaf(v[k], v[k], cq[1][k]); }
-                        }
-                    }
-                }
-            }
-            if (a.gn_stats) {
-                if (cc < cvalid) {
-#pragma unroll
-                    for (int sm = 0; sm < 2; ++sm) {
-                        // fold the chunk's columns into groups (a group is gn_gs consecutive channels; chunks are aligned)
-                        float gs_ = 0.f, gq_ = 0.f;
-#pragma unroll
-                        for (int k = 0; k < PER16; ++k) {
-                            gs_ += cs[sm][k]; gq_ += cq[sm][k];
-                            const int ch = n0 + cc * PER16 + k;
-                            if (k == PER16 - 1 || (ch + 1) % a.gn_gs == 0) {
-                                const int g = ch / a.gn_gs;
-                                if (gs_ != 0.f || gq_ != 0.f) { atomicAdd(&s_gn[sm * 32 + g * 2], gs_); atomicAdd(&s_gn[sm * 32 + g * 2 + 1], gq_); }
-                                gs_ = 0.f; gq_ = 0.f;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid < 64) {
-                    const int b = b0 + (tid >> 5);
-                    const float v = s_gn[tid];
-                    if (b < a.B && v != 0.f) atomicAdd(&a.gn_stats[((long)(tile_m % MTE_GN_REP) * a.B + b) * 32 + (tid & 31)], (double)v);
                 }
             }
             return;
@@ -440,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
                 const long m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < a.M) {
                     const float v = acc[i][j][e] + bv;
-                    if (a.splits > 1) atomicAdd(a.ws + m * a.N + n, acc[i][j][e]);
+                    if (a.splits > 1) a.ws[((long)split * a.M + m) * a.N + n] = acc[i][j][e];
                     else if (a.out_f32) ((float*)a.y)[m * a.ldy + n] = a.accum ? v + ((float*)a.y)[m * a.ldy + n] : v;
                     else Elem<T>::st((T*)a.y + m * a.ldy + n, a.accum ? v + Elem<T>::ld((const T*)a.y + m * a.ldy + n) : v);
                 }
@@ -451,13 +400,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 
 int g_igemm_dma = 1;                                 // development knob (mte_debug_set(0, v))
 
-// y = T(ws + bias) after a split-K launch
+// y = T(sum_s ws[s] + bias) after a split-K launch: the slabs are added in split order (fixed), rounded once
 template <typename T>
-__global__ void splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* y, long ldy, long M, int N, int accum) {
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ bias, T* y, long ldy, long M, int N, int accum) {
     const long n4 = M * N / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long m = (i * 4) / N; const int n = (int)((i * 4) % N);
-        const f32x4_t v = ((const f32x4_t*)ws)[i];
+        f32x4_t v = ((const f32x4_t*)ws)[i];
+        for (int s = 1; s < splits; ++s) v += ((const f32x4_t*)ws)[(long)s * n4 + i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) Elem<T>::st(y + m * ldy + n + k, v[k] + (bias ? bias[n + k] : 0.f) + (accum ? Elem<T>::ld(y + m * ldy + n + k) : 0.f));
     }
@@ -470,33 +420,29 @@ inline int choose_splits(long tiles, int ksteps, long M, int N, long ws_elems, i
     long s = (want + tiles - 1) / tiles;
     const long max_s = ksteps / 16;                    // keep >= 16 K-steps (1 KiB of K per row) per split
     if (s > max_s) s = max_s;
+    if (s > ws_elems / (M * N)) s = ws_elems / (M * N);   // one [M][N] slab per split
     return (int)(s < 1 ? 1 : s);
 }
 
 int g_igemm_pair_ksteps = 72;                        // development knob (mte_debug_set(19, v))
-int g_igemm_lds_tight = 1;                           // development knob (mte_debug_set(18, v)): no 256 extra LDS bytes where the statistics scratch fits the ring
+#ifdef MTE_DEV
 int g_igemm_ablate = 0;                              // development knob (mte_debug_set(17, v)): main-loop ablation, see ABL
+#endif
 int g_igemm_ring6 = 0;                               // development knob (mte_debug_set(15, v)) for the 8-wave 256 x 128 tile: 1 = 6-slot ring, 3 = 3-slot ring with two workgroups per CU
 
 template <typename T, int WM, int WN, int TM, int TN>
-int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
+int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
     a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems, NTHR) : 1;
-    // GroupNorm statistics can ride on the LDS-staged epilogue of the DMA kernels (not: split-K, fp32 output, the register-staged 128x32 configuration)
-    const bool fuse = a.gn_stats && (BN * 4) % NTHR == 0 && g_igemm_dma && a.splits == 1 && !a.out_f32 && (long)a.H * a.W >= BM &&
-                      a.N % 16 == 0;
-    if (stats_done) *stats_done = fuse ? 1 : 0;
-    if (!fuse) a.gn_stats = nullptr;
-    else { a.gn_gs = a.N / 16; if (!g_mte_gn_prezeroed && mte_memset_async(a.gn_stats, 0, sizeof(double) * MTE_GN_REP * a.B * 32, st) != hipSuccess) return MTE_ERR_LAUNCH; }
-    if (a.splits > 1 && mte_memset_async(a.ws, 0, sizeof(float) * a.M * a.N, st) != hipSuccess) return MTE_ERR_LAUNCH;
     if constexpr ((BN * 4) % NTHR == 0) {
         if (g_igemm_dma) {
-            const size_t lds4 = 4 * (BM + BN) * 64 + (((long)BM * BN * (long)sizeof(T) + 256 <= 4L * (BM + BN) * 64) && g_igemm_lds_tight ? 0 : 256);
+            const size_t lds4 = 4 * (BM + BN) * 64;
             const long es = (long)sizeof(T);
             const bool fast = g_igemm_dma == 1 && a.Cin_p % (4 * Elem<T>::PER16) == 0 &&
                               ((a.M - 1) * a.ldx + a.Cin_p) * es < 0x7ff00000L && (long)a.N * a.KH * a.KW * a.Cin_p * es < 0x7ff00000L;
+#ifdef MTE_DEV
             if constexpr (sizeof(T) == 2 && ((BM == 256 && BN == 128) || (BM == 128 && BN == 128) || (BM == 256 && BN == 256))) {
                 if (fast && g_igemm_ablate) {
                     const dim3 g((unsigned)(tiles * a.splits)), b(NTHR);
@@ -512,13 +458,14 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
                     goto launched;
                 }
             }
+#endif
             if constexpr (sizeof(T) == 2 && BM == 256 && BN == 128) {
                 // two 74 KB workgroups per CU (3-slot ring): always for solo launches; beside the weight-gradient stream only for short
                 // reductions over several rounds of tiles, where the prologue / epilogue share is largest (same-box step 30.46 -> 30.30 ms;
                 // for every launch it costs the step 0.2 ms)
                 const bool pair = a.solo || (ksteps <= g_igemm_pair_ksteps && tiles >= 512);
                 if (fast && (g_igemm_ring6 == 3 || (g_igemm_ring6 == 0 && pair))) {
-                    constexpr size_t lds3 = 3 * (BM + BN) * 64 + 256;
+                    constexpr size_t lds3 = 3 * (BM + BN) * 64;
                     static bool attr3 = false;
                     if (!attr3) {
                         if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WM, WN, TM, TN, 2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return MTE_ERR_LAUNCH;
@@ -528,7 +475,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
                     goto launched;
                 }
                 if (fast && g_igemm_ring6 == 1) {
-                    constexpr size_t lds6 = 6 * (BM + BN) * 64 + 256;
+                    constexpr size_t lds6 = 6 * (BM + BN) * 64;
                     static bool attr = false;
                     if (!attr) {
                         if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WM, WN, TM, TN, 2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6) != hipSuccess) return MTE_ERR_LAUNCH;
@@ -549,7 +496,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st, int* stats_done) {
 launched:
     if (a.splits > 1) {
         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, a.ws, a.bias, (T*)a.y, a.ldy, a.M, a.N, a.accum);
+        hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, a.ws, a.splits, a.bias, (T*)a.y, a.ldy, a.M, a.N, a.accum);
     }
     return mte_check_launch();
 }
@@ -557,7 +504,7 @@ launched:
 int g_igemm_big_min_tiles = 224;
 int g_igemm_big = 3;                                 // development knob (mte_debug_set(6, v)): 0 128x128 only, 1 + 256x128, 2 + 256x256, 3 + 192x96
 
-template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st, int* stats_done) {
+template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         // 256 x 128 tile, 8 waves: 24 KB of operands per K-step feed twice the MFMA work of a 128 x 128 tile (16 KB).  The
         // 4-wave kernel runs at ~14 TB/s of L2->LDS traffic with three stages in flight -- the latency-bandwidth product,
@@ -573,21 +520,23 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         const int ksteps = a.KH * a.KW * (a.Cin_p / 32);
         // few tiles but a huge reduction (pack4/pack5.conv: K = 9 x 4096 / 8192): the big tiles keep their bytes-per-flop
         // advantage when the K range is split over workgroups (fp32 atomics into the workspace, then the finish kernel)
-        const bool can_split = a.ws && ws_elems >= a.M * a.N && a.N % 4 == 0;
-        const long reach256 = t256 * (can_split ? (ksteps / 16 < 8 ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : 8) : 1);
+        const bool can_split = a.ws && ws_elems >= 2 * a.M * a.N && a.N % 4 == 0;
+        long smax = can_split ? ws_elems / (a.M * a.N) : 1;                    // one [M][N] slab per split
+        if (smax > 8) smax = 8;
+        const long reach256 = t256 * (can_split ? (ksteps / 16 < smax ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : smax) : 1);
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
             (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160)))   // (96: below it choose_splits does split)
-            return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st, stats_done);   // 256 x 256, 16 waves (8 waves of 128 x 64: 7.82 vs 7.65 ms / step, not kept)
+            return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st);   // 256 x 256, 16 waves (8 waves of 128 x 64: 7.82 vs 7.65 ms / step, not kept)
         // 65..96 columns (the 72-channel decoder concat as data-gradient N): a 192 x 96 tile of 6 waves wastes a quarter of
         // the MFMA work instead of the 44 % a 128-wide tile does
         if (g_igemm_big >= 3 && dma_ok && !a.out_f32 && a.N > 64 && a.N <= 96 && ((a.M + 191) / 192) >= g_igemm_big_min_tiles)
-            return launch_igemm<T, 2, 3, 3, 1>(a, 0, st, stats_done);
+            return launch_igemm<T, 2, 3, 3, 1>(a, 0, st);
         if (g_igemm_big && dma_ok && !a.out_f32 && a.N > 64 && tiles_big >= g_igemm_big_min_tiles)
-            return launch_igemm<T, 4, 2, 2, 2>(a, 0, st, stats_done);
+            return launch_igemm<T, 4, 2, 2, 2>(a, 0, st);
     }
-    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st, stats_done);       // 128 x 32
-    if (a.N <= 64) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st, stats_done);        // 128 x 64
-    return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st, stats_done);                      // 128 x 128
+    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st);       // 128 x 32
+    if (a.N <= 64) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st);        // 128 x 64
+    return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st);                      // 128 x 128
 }
 
 // =====================================================================================================
@@ -1278,7 +1227,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, lo
 
 extern "C" {
 
-// development knobs: key 0 = igemm tile loader (1 = LDS-DMA ring with buffer descriptors where possible, 2 = pointer DMA only,
+#ifdef MTE_DEV
+// development knobs (libmte_hip_dev.so only, -DMTE_DEV): key 0 = igemm tile loader (1 = LDS-DMA ring with buffer descriptors where possible, 2 = pointer DMA only,
 // 0 = register staging); key 1 = conv3d pack stencils
 // (1 = LDS-tiled, 0 = gather).  Not part of the product contract.
 extern "C" int mtei_set_pack3d_lds(int value);
@@ -1291,7 +1241,6 @@ int mte_debug_set(int key, int value) {
     if (key == 13) return mtei_set_gn(2, value);
     if (key == 15) { g_igemm_ring6 = value; return MTE_OK; }
     if (key == 17) { g_igemm_ablate = value; return MTE_OK; }
-    if (key == 18) { g_igemm_lds_tight = value; return MTE_OK; }
     if (key == 19) { g_igemm_pair_ksteps = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
@@ -1302,20 +1251,21 @@ int mte_debug_set(int key, int value) {
     if (key == 7) { g_igemm_big_min_tiles = value; return MTE_OK; }
     return MTE_ERR_ARG;
 }
+#endif
 
 // y[B,H,W,(ldy)] = conv(x[B,H,W,(ldx)], wpack[N][KH*KW][Cin_p]) + bias; stride 1, zero pad k/2.
-// workspace (nullable): fp32 scratch of workspace_elems >= B*H*W*N elements enables split-K for small-M / huge-K shapes.
+// workspace (nullable): fp32 scratch of workspace_elems >= 2*B*H*W*N elements enables split-K for small-M / huge-K shapes
+// (one [M][N] slab per split, at most 8; slabs are added in order by a finish kernel: bit-reproducible, nothing to clear).
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
-                     float* workspace, long workspace_elems, double* gn_stats, int* gn_stats_done, int accumulate, hipStream_t stream) {
+                     float* workspace, long workspace_elems, int accumulate, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
-    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, accumulate & 1, gn_stats, 1, (accumulate >> 1) & 1};
-    if (gn_stats_done) *gn_stats_done = 0;
-    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream, gn_stats_done);
-    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream, gn_stats_done);
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, accumulate & 1, (accumulate >> 1) & 1};
+    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream);
+    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream);
     return MTE_ERR_UNSUPPORTED;
 }
 

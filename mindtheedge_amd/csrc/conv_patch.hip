@@ -30,7 +30,6 @@ struct PatchArgs {
     bf16_t* y; long ldy;
     int B, H, W, Cin_p, N;
     int accum;                                     // 1: y += conv (fp32 sum, rounded once)
-    double* gn_stats;                              // optional [MTE_GN_REP][B][16][2] fused GroupNorm(16) statistics
 };
 
 // ---- forward / dgrad --------------------------------------------------------------------------------------
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int PBYTES = PH * PW * 64;
     constexpr int OBYTES = TH * TW * NT * 64;                      // output staging (bf16 [256 px][32*NT])
     constexpr int NBUF = (TALL && K > 3) ? 1 : 2;                  // patch buffers (tall 5x5 / 7x7 tiles: single-slice layers only)
-    constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES) ? NBUF * PBYTES : OBYTES) + 128;    // + [16 groups][2] statistics
+    constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES) ? NBUF * PBYTES : OBYTES);
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,8 +141,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     }
     // ---- epilogue: stage the tile as bf16 [pixel][N] in LDS, then 16-byte coalesced stores
     constexpr int NB = NT * 64;                                    // bytes per pixel
-    float* s_gn = (float*)(smem + LDS_BYTES - 128);
-    if (a.gn_stats && tid < 32) s_gn[tid] = 0.f;
     {
         const int ch = nsel * 32 + r;
         const float bv = (a.bias && ch < a.N) ? a.bias[ch] : 0.f;
@@ -158,11 +155,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     __syncthreads();
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
-    // GroupNorm statistics of the stored (bf16-rounded) tile ride on the store loop: a thread keeps the same 16-byte channel
-    // chunk in every iteration (256 % (NT*4) == 0), so it sums that chunk's 8 channels in registers as they pass through
-    float cs[8], cq[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { cs[k] = 0.f; cq[k] = 0.f; }
     const int c = tid % (NT * 4);
 #pragma unroll
     for (int i = 0; i < OCH / 256; ++i) {
@@ -179,31 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
                 v16 = pack16<bf16_t>(vn);
             }
             *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
-            if (a.gn_stats) {
-                float v[8];
-                unpack16<bf16_t>(v16, v);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { cs[k] += v[k]; cq[k] = fmaf(v[k], v[k], cq[k]); }
-            }
         }
-    }
-    if (a.gn_stats) {
-        if (c < cpp) {
-            const int gsz = a.N >> 4;                               // channels per group
-            float gs_ = 0.f, gq_ = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                gs_ += cs[k]; gq_ += cq[k];
-                const int ch = c * 8 + k;
-                if (k == 7 || (ch + 1) % gsz == 0) {
-                    const int g = ch / gsz;
-                    atomicAdd(&s_gn[g * 2], gs_); atomicAdd(&s_gn[g * 2 + 1], gq_);
-                    gs_ = 0.f; gq_ = 0.f;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 32 && s_gn[tid] != 0.f) atomicAdd(&a.gn_stats[((long)(blockIdx.x % MTE_GN_REP) * a.B + b) * 32 + tid], (double)s_gn[tid]);
     }
 }
 
@@ -465,7 +433,9 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 
 }  // namespace
 
+#ifdef MTE_DEV
 extern "C" int mtei_set_patch_tall(int v) { if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
+#endif
 
 extern "C" {
 
@@ -491,12 +461,10 @@ int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N
 
 // y = conv(x, wpatch) + bias for C_out <= 64 (forward, or data-gradient with the backward pack); bf16 only.
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,
-                         int B, int H, int W, int Cin_p, int N, int KH, int KW, double* gn_stats, int accumulate, hipStream_t stream) {
+                         int B, int H, int W, int Cin_p, int N, int KH, int KW, int accumulate, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
-    if (gn_stats && N % 16 != 0) return MTE_ERR_ARG;
-    if (gn_stats && !g_mte_gn_prezeroed && mte_memset_async(gn_stats, 0, sizeof(double) * MTE_GN_REP * B * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, gn_stats};
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
 }
 

@@ -16,8 +16,9 @@
 //   128-byte lines that neighbouring groups share are fetched into one L2.
 // * STREAM kernels (everything larger): a thread owns one 16-byte channel chunk (8 bf16 / 4 f32 channels) and walks
 //   pixels, so every wave instruction moves 1 KiB of contiguous NHWC bytes; statistics accumulate in fp32 per
-//   thread, are combined per block through LDS and leave the block as one double-precision atomic per
-//   (sample, group).  The per-channel arithmetic is folded into affine constants (u = v*ka + kb for the ELU
+//   thread, are combined per block by a FIXED tree (wave butterflies, then the waves in order) and leave the block as
+//   one partial record per (sample, block); the last block of a sample to arrive adds the records up in a fixed
+//   order (see gn_stats_kernel) -- the forward pass is bit-reproducible run to run and under HIP-graph replay.  The per-channel arithmetic is folded into affine constants (u = v*ka + kb for the ELU
 //   argument, dv = dyh*ka - (c0 + v*c1) for the backward) and every optional input is a template flag: the
 //   backward apply kernel went from 208 to <100 VGPRs (2 -> 5 waves per SIMD), which is what an HBM stream needs.
 #include "common.hpp"
@@ -32,7 +33,7 @@ struct GnArgs {
     const void* y1; long ld1;
     const void* y2; long ld2;          // nullable
     const float* scale2;               // [B][C] or null
-    double* stats;                     // [MTE_GN_REP][B][16][2] (sum, sumsq) partial copies, summed by the consumers
+    double* stats;                     // mte_gn_stats_elems(B) doubles: [B][16][2] final (sum, sumsq), then tickets + per-block partial records (common.hpp)
     const float* gamma; const float* beta;
     void* z; long ldz;                 // forward output
     const void* dz; long lddz;         // backward input
@@ -102,12 +103,31 @@ template <bool HAS2> __device__ __forceinline__ void keep_packed(RawRow<HAS2>& r
     const int p_end = min(a.HW, p_begin + per_blk);                                \
     const int gs = a.C / GN_GROUPS;
 
-template <typename T, bool HAS2>
-__global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
-    GN_THREAD_MAP();
-    __shared__ float s_acc[GN_GROUPS * 2];
-    if (threadIdx.x < GN_GROUPS * 2) s_acc[threadIdx.x] = 0.f;
-    __syncthreads();
+// Statistics pass.  Bit-reproducible by construction (GPUTEST_r02: the LDS / fp64 atomics this replaces made two forward passes
+// of the same frame differ by 1-2 % in inverse depth -- a one-ulp change of one statistic is amplified by ~60 bf16 layers):
+//   thread   : fp32 sums over its pixels of its 16-byte channel chunk (fixed order)
+//   wave     : xor butterflies over the lanes that share a chunk column, then over the chunks of one group
+//   block    : the waves' group sums added in wave order -> ONE record of 32 doubles, written (returning agent-scope exchange:
+//              performed at the memory side before the ticket is drawn) into this block's own slot
+//   sample   : the block that draws the last ticket of sample b adds the records in slot order -> stats[b][16][2]
+// Grid (blocks_per_sample <= MTE_GN_SLOTS(B), B), NT = 1024 threads so that <= 64 blocks per sample still fill the chip at B = 8.
+template <typename T, bool HAS2, int NT>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
+    constexpr int P = Elem<T>::PER16;
+    constexpr int NW = NT / 64;
+    const int cpr = a.C / P;
+    const int cc = threadIdx.x % cpr, prow = threadIdx.x / cpr, rstep = NT / cpr;
+    const int b = a.reverse ? a.B - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int ch0 = cc * P;
+    const int per_blk = (a.HW + a.blocks_per_sample - 1) / a.blocks_per_sample;
+    const int p_begin = blockIdx.x * per_blk;
+    const int p_end = min(a.HW, p_begin + per_blk);
+    const int gs = a.C / GN_GROUPS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_part[NW * GN_GROUPS * 2];
+    __shared__ double s_fin[(NT / 32) * GN_GROUPS * 2];
+    __shared__ int s_last;
+    for (int i = threadIdx.x; i < NW * GN_GROUPS * 2; i += NT) s_part[i] = 0.f;
     float s[P], q[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) { s[i] = 0.f; q[i] = 0.f; }
@@ -127,39 +147,73 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
             for (int i = 0; i < P; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
         }
     }
-    // combine channels of the same group held by this thread, then LDS atomics
+    // channels of one group held by this thread: running sums, complete at the group's last channel (`last` below)
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int g = (ch0 + i) / gs;
-        const bool last = (i == P - 1) || ((ch0 + i + 1) / gs != g);
-        if (!last) { s[i + 1 < P ? i + 1 : i] += s[i]; q[i + 1 < P ? i + 1 : i] += q[i]; }
-        else { atomicAdd(&s_acc[2 * g], s[i]); atomicAdd(&s_acc[2 * g + 1], q[i]); }
+    for (int i = 0; i + 1 < P; ++i)
+        if ((ch0 + i + 1) / gs == (ch0 + i) / gs) { s[i + 1] += s[i]; q[i + 1] += q[i]; }
+    // lanes of this wave that hold the same chunk column (other pixel rows): butterfly (every lane ends with the total)
+    if (cpr < 64) {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            for (int off = cpr; off < 64; off <<= 1) { s[i] += __shfl_xor(s[i], off, 64); q[i] += __shfl_xor(q[i], off, 64); }
+    }
+    // chunks of one group (gs > P: the group total so far sits in element P - 1 of each of its gs / P chunk columns)
+    const int cpg = gs > P ? gs / P : 1;
+    for (int off = 1; off < cpg; off <<= 1) { s[P - 1] += __shfl_xor(s[P - 1], off, 64); q[P - 1] += __shfl_xor(q[P - 1], off, 64); }
+    __syncthreads();                                       // s_part is zero
+    if (lane < (cpr < 64 ? cpr : 64) && cc % cpg == 0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int g = (ch0 + i) / gs;
+            const bool last = (i == P - 1) || ((ch0 + i + 1) / gs != g);
+            if (last) { s_part[(wave * GN_GROUPS + g) * 2] = s[i]; s_part[(wave * GN_GROUPS + g) * 2 + 1] = q[i]; }
+        }
     }
     __syncthreads();
-    if (threadIdx.x < GN_GROUPS * 2)
-        atomicAdd(&a.stats[((long)(blockIdx.x % MTE_GN_REP) * a.B + b) * GN_GROUPS * 2 + threadIdx.x], (double)s_acc[threadIdx.x]);
+    const int slots = MTE_GN_SLOTS(a.B);
+    double* part = mte_gn_partials(a.stats, a.B) + ((long)b * slots + blockIdx.x) * (GN_GROUPS * 2);
+    if (threadIdx.x < GN_GROUPS * 2) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += s_part[w * GN_GROUPS * 2 + threadIdx.x];
+        const unsigned long long before = atomicExch((unsigned long long*)part + threadIdx.x, (unsigned long long)__double_as_longlong((double)tot));
+        asm volatile("" ::"v"(before));                    // returning: the record is at the memory side once the value is back
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(mte_gn_tickets(a.stats, a.B) + 2 * b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // every record of sample b is in memory: NT / 32 threads per value take the slots j = k, k + NT/32, ... in order, then the
+    // NT / 32 partial sums are added in order
+    {
+        const int v = threadIdx.x & 31, k = threadIdx.x >> 5;
+        const double* rec = mte_gn_partials(a.stats, a.B) + (long)b * slots * (GN_GROUPS * 2) + v;
+        double acc = 0.0;
+        for (int j = k; j < (int)gridDim.x; j += NT / 32)
+            acc += __hip_atomic_load(rec + (long)j * (GN_GROUPS * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fin[k * 32 + v] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < GN_GROUPS * 2) {
+        double tot = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < NT / 32; ++k) tot += s_fin[k * 32 + threadIdx.x];
+        a.stats[(long)b * GN_GROUPS * 2 + threadIdx.x] = tot;
+    }
 }
 
 // The fp64 mean / rstd of the 16 groups of sample b are evaluated once per block and shared through LDS (per-thread
-// evaluation -- 8 fp64 divisions + square roots per thread -- used to dominate the short low-resolution launches): 32 lanes
-// add up the MTE_GN_REP partial copies of one (group, sum | sum of squares) value each, 16 lanes finish.
+// evaluation -- 8 fp64 divisions + square roots per thread -- used to dominate the short low-resolution launches).
 __device__ __forceinline__ void block_group_stats(const GnArgs& a, int b, int gs, float* s_mr) {
-    __shared__ double s_sq[GN_GROUPS * 2];
-    if (threadIdx.x < GN_GROUPS * 2) {
-        const double* sp = a.stats + (long)b * GN_GROUPS * 2 + threadIdx.x;
-        double v[MTE_GN_REP];
-#pragma unroll
-        for (int r = 0; r < MTE_GN_REP; ++r) v[r] = sp[(long)r * a.B * GN_GROUPS * 2];      // independent loads, one latency
-        double acc = 0.0;
-#pragma unroll
-        for (int r = 0; r < MTE_GN_REP; ++r) acc += v[r];
-        s_sq[threadIdx.x] = acc;
-    }
-    __syncthreads();
     if (threadIdx.x < GN_GROUPS) {
+        const double* sp = a.stats + ((long)b * GN_GROUPS + threadIdx.x) * 2;
         const double n = (double)a.HW * gs;
-        const double m = s_sq[2 * threadIdx.x] / n;
-        double var = s_sq[2 * threadIdx.x + 1] / n - m * m;
+        const double m = sp[0] / n;
+        double var = sp[1] / n - m * m;
         if (var < 0.0) var = 0.0;
         s_mr[2 * threadIdx.x] = (float)m;
         s_mr[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -397,13 +451,10 @@ __global__ __launch_bounds__(NT) void gn_fwd_slab_kernel(GnArgs a) {
         }
     }
     const double Q = block_sum<NT>(q, s_w, lane, wave);
-    // statistics in the stream kernels' format (sum, sum of squares; copy 0 carries them, the other partial copies are zero):
+    // statistics in the stream kernels' format (sum, sum of squares):
     // sum (v - m)^2 = sum v^2 - 2 m S + n m^2 for ANY m, so sum v^2 = Q + 2 m S - n m^2 exactly
     const double sumsq = Q + 2.0 * (double)mean * S - n * (double)mean * (double)mean;
-    if (t < 2 * MTE_GN_REP) {
-        const int r = t >> 1, which = t & 1;
-        a.stats[((long)r * a.B + b) * GN_GROUPS * 2 + 2 * g + which] = r == 0 ? (which ? sumsq : S) : 0.0;
-    }
+    if (t < 2) a.stats[((long)b * GN_GROUPS + g) * 2 + t] = t ? sumsq : S;
     const double md = S / n;
     double var = sumsq / n - md * md;                      // what the consumers of `stats` will compute
     if (var < 0.0) var = 0.0;
@@ -458,13 +509,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
     __shared__ float s_part[(NT / 64) * 32];               // per-wave channel partials (a group has <= 32 channels)
     __shared__ float s_r1[32], s_r2[32], s_db[32], s_S[2];
     __shared__ double s_st[2];
-    if (t < 2) {                                           // this group's (sum, sum of squares): add the partial copies
-        const double* sp = a.stats + (long)b * GN_GROUPS * 2 + 2 * g + t;
-        double acc = 0.0;
-#pragma unroll
-        for (int r = 0; r < MTE_GN_REP; ++r) acc += sp[(long)r * a.B * GN_GROUPS * 2];
-        s_st[t] = acc;
-    }
+    if (t < 2) s_st[t] = a.stats[((long)b * GN_GROUPS + g) * 2 + t];      // this group's (sum, sum of squares)
     RawRow<HAS2> raw[NCH];
     u32x4_t gr[NCH];
 #pragma unroll
@@ -619,11 +664,19 @@ template <typename T, bool HAS2, bool HASDB> bool launch_bwd_slab(const GnArgs& 
 }
 
 template <typename T> int run_stats(GnArgs& a, hipStream_t stream) {
-    a.blocks_per_sample = gn_blocks(a.B, a.HW, 256 / (a.C / Elem<T>::PER16), true);
+    constexpr int NT = 1024;
+    const int rstep = NT / (a.C / Elem<T>::PER16);
+    // the same number of threads as 2048 workgroups of 256 would be; one record slot per block
+    long want = ((long)g_gn_target * 256 / NT + a.B - 1) / a.B;
+    const int min_rows = g_gn_min_rows < 16 ? g_gn_min_rows : 16;
+    const long maxb = ((long)a.HW + (long)min_rows * rstep - 1) / ((long)min_rows * rstep);
+    if (want > maxb) want = maxb;
+    if (want > MTE_GN_SLOTS(a.B)) want = MTE_GN_SLOTS(a.B);
+    a.blocks_per_sample = (int)(want < 1 ? 1 : want);
     a.reverse = g_gn_zigzag;                               // the producing conv wrote sample 0 first: start on the freshest bytes
     dim3 grid(a.blocks_per_sample, a.B);
-    if (a.y2) hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, dim3(256), 0, stream, a);
+    if (a.y2) hipLaunchKernelGGL((gn_stats_kernel<T, true, NT>), grid, dim3(NT), 0, stream, a);
+    else hipLaunchKernelGGL((gn_stats_kernel<T, false, NT>), grid, dim3(NT), 0, stream, a);
     return mte_check_launch();
 }
 
@@ -669,6 +722,7 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef MTE_DEV
 extern "C" int mtei_set_gn(int which, int value) {
     if (which == 2) { g_gn_slab = value; return MTE_OK; }
     if (which == 3) { g_gn_zigzag = value; return MTE_OK; }
@@ -676,6 +730,7 @@ extern "C" int mtei_set_gn(int which, int value) {
     if (which == 0) g_gn_min_rows = value; else g_gn_target = value;
     return MTE_OK;
 }
+#endif
 
 extern "C" {
 
@@ -687,12 +742,16 @@ int mte_gn_fwd_is_single_pass(int HW, int C, int has_y2, int dtype) {
     return (n > 0 && n <= GN_SLAB_MAX) ? 1 : 0;
 }
 
-// stats[MTE_GN_REP][B][16][2] (double; zeroed here; partial copies) <- per-(sample, group) sum and sum of squares of v = y1 + scale2*y2
+// doubles of a statistics buffer for batch B (final sums + arrival tickets + per-block records, see common.hpp)
+long mte_gn_stats_elems(int B) { return B < 1 ? 0 : mte_gn_stats_elems_(B); }
+
+// stats[0 .. B*32) <- per-(sample, group) sum and sum of squares of v = y1 + scale2*y2 (doubles; the rest of the buffer is the
+// pass's workspace: tickets -- zeroed here unless MTE_OPT_GN_PREZEROED -- and records).  Bit-reproducible.
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
                  int B, int HW, int C, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
-    if (!g_mte_gn_prezeroed && mte_memset_async(stats, 0, sizeof(double) * MTE_GN_REP * B * GN_GROUPS * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (!g_mte_gn_prezeroed && mte_memset_async(mte_gn_tickets(stats, B), 0, sizeof(double) * ((B + 15) & ~15), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
     return dtype == MTE_DT_BF16 ? run_stats<bf16_t>(a, stream) : run_stats<float>(a, stream);
 }

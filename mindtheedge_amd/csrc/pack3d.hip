@@ -1091,7 +1091,9 @@ int g_p3_mfma = 1;                                  // development knob (mte_deb
 
 }  // namespace
 
+#ifdef MTE_DEV
 extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
+#endif
 
 
 extern "C" {

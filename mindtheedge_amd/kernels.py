@@ -44,21 +44,50 @@ def weights_epoch():
 class GradSink:
     """Lets backward kernels write parameter gradients straight into pre-allocated storage (the flat gradient buffer
     of trainers.data_parallel.FlatParameters) instead of returning fresh tensors that autograd then adds into .grad:
-    every parameter on this path receives exactly one gradient per backward, so a plain store into the zeroed buffer
-    IS the accumulation.  ``ready(p)`` replaces the post-accumulate-grad hook (bucketed all-reduce trigger)."""
+    on the benchmarked path every parameter receives exactly one gradient per backward, so a plain store into the zeroed
+    buffer IS the accumulation.  ``ready(p)`` replaces the post-accumulate-grad hook (bucketed all-reduce trigger).
+
+    A store is only an accumulation ONCE per zeroed buffer.  The sink therefore hands a parameter's view out for one store
+    per ``reset()`` (= optimizer.zero_grad()): a second gradient for the same tensor -- a second backward pass without
+    zero_grad, or a parameter used twice in one graph -- goes back to autograd, which ADDS it into ``.grad`` (the same flat
+    memory).  A forward pass that knows it shares parameters between two sub-graphs (PackNetSAN01's RGB and RGB+LiDAR passes,
+    reference networks/depth/PackNetSAN01.py:324-338) calls ``suspend()``: until the next ``reset()`` EVERY gradient takes the
+    autograd route, so each parameter's AccumulateGrad node runs once with the sum of both uses and the all-reduce trigger
+    (post-accumulate hook) never fires on half a gradient."""
 
     def __init__(self):
         self.views = {}          # param.data_ptr() -> flat fp32 gradient view
         self.on_ready = None
+        self.written = set()     # parameters whose view already holds this step's (first) gradient
+        self.suspended = False
 
     def register(self, p, view):
         self.views[p.data_ptr()] = view
 
     def lookup(self, p):
-        v = self.views.get(p.data_ptr())
-        if v is not None and p.grad is not None and p.grad.data_ptr() == v.data_ptr() and v.shape == p.shape:
+        """the view a gradient of `p` may be STORED into, or None (not registered / already written / suspended)"""
+        if self.suspended:
+            return None
+        key = p.data_ptr()
+        v = self.views.get(key)
+        if v is not None and key not in self.written and p.grad is not None and p.grad.data_ptr() == v.data_ptr() and v.shape == p.shape:
             return v
         return None
+
+    def claim(self, p):
+        """lookup + mark as written: the caller stores this step's gradient of `p` into the returned view"""
+        v = self.lookup(p)
+        if v is not None:
+            self.written.add(p.data_ptr())
+        return v
+
+    def reset(self):
+        """the gradient buffer was cleared (zero_grad): every view may take one store again"""
+        self.written.clear()
+        self.suspended = False
+
+    def suspend(self):
+        self.suspended = True
 
     def ready(self, p):
         if self.on_ready is not None:
@@ -72,12 +101,18 @@ def set_grad_sink(sink):
     _sink["active"] = sink
 
 
+def suspend_grad_sink():
+    """called by a forward pass whose graph uses parameters more than once (see GradSink)"""
+    if _sink["active"] is not None:
+        _sink["active"].suspend()
+
+
 def _grad_dst(p, zero=False):
     """(tensor to write the gradient of `p` into, True if it is the sink's storage).  zero: the kernel ACCUMULATES into
     the destination (the sink's flat gradient buffer is cleared by zero_grad; a private one comes zeroed)."""
     sk = _sink["active"]
     if sk is not None:
-        v = sk.lookup(p)
+        v = sk.claim(p)
         if v is not None:
             return v, True
     if zero:
@@ -198,7 +233,7 @@ class _ZeroArena:
 
     def zeros(self, shape, dtype, device):
         if not self.enabled:             # from now on the library trusts GroupNorm accumulation buffers to arrive zeroed
-            lib.mte_set_option(0, 1)
+            lib.set_option(0, 1)
             self.enabled = True
         n = 1
         for d in shape:
@@ -401,20 +436,19 @@ def prefetch_weight_packs():
             pk._event = None
 
 
+SPLITK_SLABS = 8
+
+
 def _splitk_workspace(M, N, device):
-    """fp32 [M][N] scratch for split-K, offered only where the output has few 128x128 tiles (the library decides)."""
+    """fp32 scratch for split-K: one [M][N] slab per split (each split stores its partial tile, a finish kernel adds the slabs in
+    order -- bit-reproducible, nothing to clear), offered only where the output has few 128x128 tiles (the library decides)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 384:
         return None, 0
-    return torch.empty((M * N,), dtype=torch.float32, device=device), M * N
+    return torch.empty((SPLITK_SLABS * M * N,), dtype=torch.float32, device=device), SPLITK_SLABS * M * N
 
 
-# conv_epilogue_stats: accumulate GroupNorm statistics in the conv epilogues instead of a stand-alone pass.  Built, tested
-# and OFF: on T8 the stand-alone pass is 0.7 % faster end to end (it streams the conv output at ~5 TB/s and leaves it in
-# the Infinity Cache for the normalisation pass that follows, while the fused form lengthens ~45 conv kernels by LDS
-# atomics, one more barrier and a tail of fp64 atomics that must land before the kernel retires).
 _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30,
-        "conv_epilogue_stats": bool(os.environ.get("MTE_STATS_FUSION")),
         "no_fork_accumulate": bool(os.environ.get("MTE_NO_FORK_ACCUM")),
         "patch_wgrad_slabs": not os.environ.get("MTE_PATCH_WGRAD_ATOMICS")}
 
@@ -428,11 +462,6 @@ def pack_folding_enabled():
     return _cfg["pack_folding"]
 
 
-def use_conv_epilogue_stats(flag):
-    """Enable/disable GroupNorm statistics in the conv epilogues (see _cfg)."""
-    _cfg["conv_epilogue_stats"] = bool(flag)
-
-
 def use_patch_kernels(flag):
     """Enable/disable the LDS-patch conv kernels (tests compare them against the generic implicit GEMM)."""
     _cfg["patch_kernels"] = bool(flag)
@@ -442,24 +471,21 @@ def _patch_ok(W, cin_p, n, kh, kw, dtype):
     return _cfg["patch_kernels"] and dtype == torch.bfloat16 and lib.mte_conv2d_patch_supported(W, cin_p, n, kh, kw, DT_BF16) == 1
 
 
-def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, gn_stats=None, accumulate=False):
-    """-> y, or (y, stats_fused) when `gn_stats` ([B,16,2] fp64) is offered: the conv epilogue accumulates the GroupNorm(16)
-    statistics of its own output when the launched kernel variant can (saves one full read of y)."""
+def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumulate=False):
+    """y = conv_k(zero_pad(x)) + bias -> NHWC activation (written into `out` when given)"""
     B, Cp, H, W = x.shape
     if out is None:
         out = new_act(B, cout, H, W, x.dtype, x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(out)
-    want = gn_stats is not None and cout % 16 == 0 and _cfg["conv_epilogue_stats"]
     if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
         lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw,
-                                 gn_stats.data_ptr() if want else 0, 1 if accumulate else 0, _stream())
-        return (out, want) if gn_stats is not None else out
+                                 1 if accumulate else 0, _stream())
+        return out
     ws, ws_n = _splitk_workspace(B * H * W, cout, x.device)
-    done = ctypes.c_int(0)
     lib.mte_conv2d_igemm(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, 0, B, H, W, Cp, cout, kh, kw, _dt(x), _ptr(ws), ws_n,
-                         gn_stats.data_ptr() if want else 0, ctypes.byref(done), (1 if accumulate else 0) | _CONV_SOLO, _stream())
-    return (out, bool(done.value)) if gn_stats is not None else out
+                         (1 if accumulate else 0) | _CONV_SOLO, _stream())
+    return out
 
 
 _CONV_SOLO = 2      # MTE_CONV_SOLO: the forward pass has no weight-gradient kernels running beside it (see include/mte_kernels.h)
@@ -559,8 +585,9 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     return dw, dbias
 
 
-def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None):
-    """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations;
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None, sunk=False):
+    """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations; sunk: they are views
+    of the gradient sink (nothing on the backward chain reads them: the weight-gradient kernels may run on the side stream);
     fork_slot: see ForkFn -- the data gradient is accumulated into the gradient another consumer of x already produced"""
     cout, cin, kh, kw = w.shape
     B, Cp, H, W = x.shape
@@ -569,7 +596,7 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
     st = _stream()
     dw = dbias = dx = None
     if need_dw:
-        sunk = dw_out is not None and (dbias_out is not None or not need_dbias) and _sink["active"] is not None
+        sunk = bool(sunk) and dw_out is not None and (dbias_out is not None or not need_dbias)
         if sunk and _side["enabled"] and need_dx:
             if _side["keep_bytes"] > _SIDE_KEEP_LIMIT:
                 join_side_stream()
@@ -583,29 +610,39 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
         acc = 1 if target is not None else 0
         dxp, lddx = _pl(dx)
         if _patch_ok(W, cout, Cp, kh, kw, x.dtype):
-            lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, 0, acc, st)
+            lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
         else:
             _, wb = pack.get(w, x.dtype, True)
             ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
-            lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, 0, 0, acc, st)
+            lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, acc, st)
         if fork_slot is not None:
             fork_slot["buf"] = dx
     return dx, dw, dbias
 
 
-def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, stats=None):
-    """`stats`: statistics already accumulated by the producing conv's epilogue (skips the statistics pass)"""
+_stats_elems = {}
+
+
+def gn_stats_buffer(B, device):
+    """GroupNorm statistics buffer of a batch (include/mte_kernels.h, mte_gn_stats_elems): [B][16][2] sums that the normalisation
+    and its backward read, followed by the statistics pass's arrival tickets (must be zero: the arena is) and per-workgroup records."""
+    n = _stats_elems.get(B)
+    if n is None:
+        n = _stats_elems[B] = int(lib.mte_gn_stats_elems(B))
+    return _zeros((n,), torch.float64, device)
+
+
+def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
     B, C, H, W = y1.shape
     p1, l1 = _pl(y1)
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     st = _stream()
     ready = 1
-    if stats is None:
-        stats = _zeros((GN_REP, B, 16, 2), torch.float64, y1.device)
-        if lib.mte_gn_fwd_is_single_pass(H * W, C, 1 if y2 is not None else 0, _dt(y1)) == 1:
-            ready = 0                  # low-resolution layer: one kernel holds each (sample, group) slab on chip -- statistics + apply
-        else:
-            lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
+    stats = gn_stats_buffer(B, y1.device)
+    if lib.mte_gn_fwd_is_single_pass(H * W, C, 1 if y2 is not None else 0, _dt(y1)) == 1:
+        ready = 0                      # low-resolution layer: one kernel holds each (sample, group) slab on chip -- statistics + apply
+    else:
+        lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
     if tuple(z.shape) != (B, C, H, W) or z.dtype != y1.dtype:
         raise MteError("output destination has shape %s / %s, expected %s / %s" % (tuple(z.shape), z.dtype, (B, C, H, W), y1.dtype))
@@ -638,7 +675,6 @@ def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbia
 
 
 GN_EPS = 1e-5
-GN_REP = 16           # MTE_GN_REP of include/mte_kernels.h: partial copies of a GroupNorm statistics buffer
 
 _dropout_pool = {}
 
@@ -667,10 +703,8 @@ class ConvGnEluFn(torch.autograd.Function):
         ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
-        stats = _zeros((GN_REP, x.shape[0], 16, 2), torch.float64, x.device)
-        y, fused = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w, gn_stats=stats)
-        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, stats=stats if fused else None,
-                               out=None if out is None else alias_of(out))
+        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out))
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
         ctx.bias = b
@@ -686,7 +720,7 @@ class ConvGnEluFn(torch.autograd.Function):
         gw, sw = _grad_dst(w)
         dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
                                                 dgamma=gg, dbeta=gb, dbias=gbias)
-        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot)
+        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw)
         return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None, None
 
 
@@ -711,7 +745,8 @@ class ConvFn(torch.autograd.Function):
         dy = as_act(dy, x.dtype)
         gw, sw = _grad_dst(w)
         gbias, sbias = _grad_dst(b)
-        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias, fork_slot=ctx.fork_slot)
+        dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias, fork_slot=ctx.fork_slot,
+                                   sunk=sw and sbias)
         return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None
 
 
@@ -833,7 +868,7 @@ def _deliver(p, t):
     """hand a finished parameter gradient to the sink (flat buffer) or back to autograd"""
     sk = _sink["active"]
     if sk is not None:
-        v = sk.lookup(p)
+        v = sk.claim(p)
         if v is not None:
             v.copy_(t.view(v.shape))
             sk.ready(p)

@@ -20,6 +20,8 @@ from ..losses.supervised_loss import SupervisedLoss
 
 
 class SemiSupEdgeModel(SfmModel):
+    SIGMOID_THRESH = 4       # reference SemiSupEdgeModel.py:137-139: is_grad=True, is_sigmoid=True, sigmoid_thresh=4 (both loss paths use it)
+
     def __init__(self, supervised_loss_weight=0.9, depth_edges_loss_weight=10.0, **kwargs):
         super().__init__(**kwargs)
         assert 0. < supervised_loss_weight <= 1., "Model requires (0, 1] supervision"
@@ -63,9 +65,13 @@ class SemiSupEdgeModel(SfmModel):
         configuration (4 scales, cross-entropy head, sparse-silog on scale 0).  -> (edge_loss, supervised 'loss' [1]) or None when
         the configuration needs the per-scale path."""
         from .. import kernels as K
+        from ..losses.grad_loss import GradLoss
         head = getattr(self, 'edge_loss_head', None)
         sup = self._supervised_loss
-        if (not self.edges_depth_edge_loss_all_scales or head is None or type(head).__name__ != 'GradLoss' or getattr(sup, 'n', 0) != 1
+        # the fused launch IS GradLoss('cross_entropy') on four scales + 'sparse-silog' on scale 0: anything else (another head
+        # class, another edge loss type, another supervised method / scale count) takes the per-scale path and its own errors
+        if (not self.edges_depth_edge_loss_all_scales or not isinstance(head, GradLoss) or head.edge_loss_type != 'cross_entropy'
+                or getattr(sup, 'supervised_method', None) != 'sparse-silog' or getattr(sup, 'n', 0) != 1
                 or not inv_depths[0].is_cuda or tuple(batch['depth'].shape[-2:]) != tuple(inv_depths[0].shape[-2:])):
             return None
         sfx = ['', '_1', '_2', '_3']
@@ -73,7 +79,7 @@ class SemiSupEdgeModel(SfmModel):
         normals = [batch.get('normal' + s) for s in sfx]
         if any(tuple(e.shape[-2:]) != tuple(i.shape[-2:]) for e, i in zip(edges, inv_depths)):
             return None
-        losses = K.DepthLossesFn.apply(head.weight, head.depth_edges_loss_pos_to_neg_weight, 4.0, True, batch.get('rgb_edge'),
+        losses = K.DepthLossesFn.apply(head.weight, head.depth_edges_loss_pos_to_neg_weight, float(self.SIGMOID_THRESH), True, batch.get('rgb_edge'),
                                        batch['depth'], edges, normals, *inv_depths[:4])
         sup.add_metric('supervised_loss', losses[4])
         return losses[:4].sum() / 4, losses[4:5]
@@ -88,7 +94,7 @@ class SemiSupEdgeModel(SfmModel):
             edge_loss, sup_loss = fused
         else:
             edge_loss = self.compute_edge_loss_with_all_scales(inv_depths, batch, batch.get('rgb_edge'), is_grad=True,
-                                                               is_sigmoid=True, sigmoid_thresh=4)
+                                                               is_sigmoid=True, sigmoid_thresh=self.SIGMOID_THRESH)
             sup_loss = self.supervised_loss(inv_depths, batch['depth'], return_logs=return_logs, progress=progress)['loss']
         supervised_loss = self.supervised_loss_weight * sup_loss
         edge_loss = self.depth_edges_loss_weight * edge_loss

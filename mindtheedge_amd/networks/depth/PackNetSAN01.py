@@ -199,6 +199,10 @@ class PackNetSAN01(nn.Module):
         # reference :324-342: second pass with the LiDAR input through the sparse branch, and the feature-matching loss that
         # pulls the RGB-only pyramid towards the (detached) RGB+LiDAR one
         from ..layers.minkowski_encoder import feature_l2
+        # the 216 encoder / decoder tensors are used by BOTH passes: their gradients must be summed, not stored twice into the
+        # flat gradient buffer (and a bucket's all-reduce must not start on the first half) -- ordinary autograd accumulation
+        # until the next zero_grad
+        K.suspend_grad_sink()
         inv_depths_rgbd, feats_rgbd = self.run_network(rgb, input_depth)
         output['inv_depths_rgbd'] = inv_depths_rgbd
         loss = None

@@ -59,6 +59,8 @@ class FlatParameters:
             from .. import kernels as K
             K.join_side_stream()
         self.grad.zero_()
+        if self.sink is not None:
+            self.sink.reset()                                # every view may take one in-place store again
         for p, o in zip(self.params, self.offsets):          # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
@@ -240,13 +242,21 @@ class FusedAdam(torch.optim.Optimizer):
         vals = [float(g['lr']), 1.0 - math.pow(float(b1), self.steps), math.sqrt(1.0 - math.pow(float(b2), self.steps))]
         if self.hyper.is_cuda and not os.environ.get("MTE_ADAM_PAGEABLE_HYPER"):
             # a copy from pageable memory makes the host wait for the stream (every step: the GPU then idles while the host catches
-            # up with the next forward pass); a ring of pinned slots keeps the upload asynchronous -- the host is never more than a
-            # couple of steps ahead of the device, 16 slots cannot wrap onto a transfer that is still pending
+            # up with the next forward pass); a ring of pinned slots keeps the upload asynchronous.  Each slot carries the event of
+            # its last upload and is rewritten only after that copy has executed (with HIP-graph replay or an unthrottled loop the host
+            # can run more than 16 steps ahead of the device; the wait is almost always already satisfied)
             if self._hyper_pinned is None:
                 self._hyper_pinned = torch.empty((16, 3), dtype=torch.float32).pin_memory()
-            slot = self._hyper_pinned[self.steps % 16]
+                self._hyper_events = [None] * 16
+            i = self.steps % 16
+            if self._hyper_events[i] is not None:
+                self._hyper_events[i].synchronize()
+            slot = self._hyper_pinned[i]
             slot[0], slot[1], slot[2] = vals
             self.hyper.copy_(slot, non_blocking=True)
+            ev = self._hyper_events[i] or torch.cuda.Event()
+            ev.record()
+            self._hyper_events[i] = ev
         else:
             self.hyper.copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=True)
 
@@ -330,17 +340,18 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 def reference_parameter_names(depth_net):
-    """Parameter names of the REFERENCE PackNetSAN01 in ``parameters()`` order: encoder, decoder, mconvs, weight, bias
-    (networks/depth/PackNetSAN01.py:186-210).  A network built without the sparse branch gets the branch's names from a
-    meta-device instance (no memory), so optimizer indices agree with checkpoints written by the reference."""
+    """Parameter names of the REFERENCE PackNetSAN01 in ``parameters()`` order.  torch yields a module's OWN parameters before
+    those of its sub-modules, so the fusion vectors registered last in the constructor (networks/depth/PackNetSAN01.py:209-210)
+    come first: ``weight, bias, encoder.*, decoder.*, mconvs.*``.  A network built without the sparse branch gets the branch's
+    names from a meta-device instance (no memory) appended where the reference has them -- at the end -- so optimizer indices
+    agree with checkpoints written by the reference and between ``with_san=True`` / ``False`` builds of this package."""
     names = [n for n, _ in depth_net.named_parameters()]
     if getattr(depth_net, 'with_san', True) or not hasattr(depth_net, 'mconvs'):
         return names
     with torch.device('meta'):
         from ..networks.layers.minkowski_encoder import MinkowskiEncoder
         branch = ['mconvs.' + n for n, _ in MinkowskiEncoder([32, 64, 128, 256, 512], with_uncertainty=False).named_parameters()]
-    tail = [n for n in names if n in ('weight', 'bias')]
-    return [n for n in names if n not in ('weight', 'bias')] + branch + tail
+    return names + branch
 
 
 def broadcast_parameters(flat, src=0, group=None):

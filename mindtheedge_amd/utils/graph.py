@@ -52,7 +52,11 @@ class GraphedTrainStep:
       reference) and selects one of two captured graphs; Dropout2d factors are drawn by torch's generator inside the graph
       (graph-safe Philox offsets: fresh draws every replay).
     * Single-process only: the bucketed RCCL all-reduce is issued from grad-ready callbacks and stays on the eager path.
-    * If capture fails the object reports it (``.graphed is False``) and every call runs the eager step in this process."""
+    * If capture fails the object reports it (``.graphed is False``) and every call runs the eager step in this process.
+    * Construction leaves the training state untouched: the warm-up runs real optimisation steps on the example batch (kernel
+      attributes, workspaces and weight packs must exist before a capture), so parameters, Adam moments and step count, module
+      buffers (BatchNorm running statistics of the sparse branch) and the python / torch RNG states are snapshotted first and
+      restored afterwards, and the kernel-ready weight packs are rebuilt from the restored parameters."""
 
     def __init__(self, model, optimizer, example_batch, warmup=2):
         import random
@@ -66,6 +70,7 @@ class GraphedTrainStep:
         if not model.training:
             raise ValueError("capture the model in training mode")
         rng_state = random.getstate()
+        snap = self._snapshot()
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -95,6 +100,44 @@ class GraphedTrainStep:
         finally:
             self.model._pinned_flip = None
             random.setstate(rng_state)                      # warm-up / capture must not consume the training run's flip draws
+            self._restore(snap)
+
+    def _snapshot(self):
+        opt = self.opt
+        flat = getattr(opt, "flatp", None)
+        snap = {"torch_rng": torch.get_rng_state(), "cuda_rng": torch.cuda.get_rng_state(),
+                "buffers": [(b, b.detach().clone()) for b in self.model.buffers()]}
+        if flat is not None:
+            snap.update(flat=flat.flat.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), steps=opt.steps)
+        else:
+            import copy
+            snap.update(params=[(p, p.detach().clone()) for g in opt.param_groups for p in g["params"]],
+                        opt_state=copy.deepcopy(opt.state_dict()))
+        return snap
+
+    def _restore(self, snap):
+        from .. import kernels as K
+        torch.cuda.synchronize()
+        opt = self.opt
+        with torch.no_grad():
+            if "flat" in snap:
+                opt.flatp.flat.copy_(snap["flat"])
+                opt.exp_avg.copy_(snap["m"])
+                opt.exp_avg_sq.copy_(snap["v"])
+                opt.steps = snap["steps"]
+            else:
+                for p, v in snap["params"]:
+                    p.copy_(v)
+                opt.load_state_dict(snap["opt_state"])
+            for b, v in snap["buffers"]:
+                b.copy_(v)
+        torch.set_rng_state(snap["torch_rng"])
+        torch.cuda.set_rng_state(snap["cuda_rng"])
+        # a replay does not run the python that re-packs stale weights: rebuild every pack from the restored parameters now
+        K.bump_weights_epoch()
+        K.prefetch_weight_packs()
+        K.join_side_stream()
+        torch.cuda.synchronize()
 
     @property
     def graphed(self):

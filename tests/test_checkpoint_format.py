@@ -97,16 +97,23 @@ def _packnet_cfg(extra=None):
 
 
 def test_reference_numbering_of_the_real_network():
-    """The reference's Adam numbers ALL of depth_net.parameters(): encoder, decoder, the 70 sparse-branch tensors, then the
-    two fusion 5-vectors (networks/depth/PackNetSAN01.py:186-210, models/model_wrapper.py:149-154)."""
+    """The reference's Adam numbers ALL of depth_net.parameters().  torch yields a module's own parameters before its
+    sub-modules', so the order is: the two fusion 5-vectors, encoder, decoder, the 70 sparse-branch tensors
+    (networks/depth/PackNetSAN01.py:186-210, models/model_wrapper.py:149-154; checked against the imported reference:
+    named_parameters() starts ['weight', 'bias', 'encoder.pre_calc.conv_base.weight', ...])."""
     from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
     from mindtheedge_amd.trainers.data_parallel import reference_parameter_names
     w = ModelWrapper(_packnet_cfg())
     names = reference_parameter_names(w.depth_net)
-    assert len(names) == 218 + 70 and names[-2:] == ['weight', 'bias']
-    first_branch = next(i for i, n in enumerate(names) if n.startswith('mconvs.'))
-    assert first_branch == 216 and all(n.startswith('mconvs.') for n in names[216:286])
-    assert all(n.startswith('encoder.') or n.startswith('decoder.') for n in names[:216])
+    assert len(names) == 218 + 70 and names[:2] == ['weight', 'bias']
+    assert names[2] == 'encoder.pre_calc.conv_base.weight' and names[217] == 'decoder.disp1_layer.conv1.bias'
+    assert all(n.startswith('encoder.') or n.startswith('decoder.') for n in names[2:218])
+    assert all(n.startswith('mconvs.') for n in names[218:])
+    # a build that owns the branch and one that does not number the optimizer state identically
+    with torch.device('meta'):
+        full = PackNetSAN01(dropout=0.0, version='1A', with_san=True)
+    assert names == [n for n, _ in full.named_parameters()] == reference_parameter_names(full)
 
 
 def test_resume_from_a_reference_written_checkpoint(tmp_path):
@@ -141,7 +148,7 @@ def test_resume_from_a_reference_written_checkpoint(tmp_path):
             o = opt.flatp.offset_of[id(p)]
             assert float(opt.exp_avg[o]) == float(i) and float(opt.exp_avg_sq[o + p.numel() - 1]) == 2.0 * i, n
     out = opt.state_dict()
-    assert out['param_groups'][0]['params'] == list(range(288)) and set(out['state']) == set(state) | {286, 287}
+    assert out['param_groups'][0]['params'] == list(range(288)) and set(out['state']) == set(state) | {0, 1}
     # a frozen encoder must not shift the numbering (the reference numbers frozen tensors too)
     wf = ModelWrapper(_packnet_cfg({"freeze_encoder": True}), resume=ckpt)
     wf.configure_optimizers()

@@ -1,0 +1,123 @@
+"""GPU (-m gpu): the forward pass is BIT-reproducible (round 3).
+
+GPUTEST_r02 went red on an eager-vs-HIP-graph depth comparison.  Root cause (tools/determinism_probe.py at the round-2 head,
+profiles/r03_determinism_probe.txt): two eager forward passes of ONE frame differed in 20 of 20 runs by up to 3e-2 in inverse
+depth -- the GroupNorm statistics pass summed fp32 partials with LDS atomics and fp64 block sums with global atomics, split-K
+convolutions added fp32 partial tiles with atomics; a one-ulp change of one statistic is amplified by ~60 bf16-stored layers.
+The forward kernels now have no floating-point atomics: fixed reduction trees, per-workgroup records added in slot order by
+the last workgroup to arrive, split-K slabs added in split order.  These tests hold that property (reference call sites:
+infer_edges.py:331-353 -- the same frame must give the same depth file -- and networks/layers/packnet/layers01.py:32)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats(y, B, HW, C, K):
+    st = torch.zeros((int(K.lib.mte_gn_stats_elems(B)),), dtype=torch.float64, device="cuda")
+    p, ld = K._pl(y)
+    K.lib.mte_gn_stats(p, ld, 0, 0, 0, st.data_ptr(), B, HW, C, K._dt(y), K._stream())
+    return st[:B * 32].clone()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(1, 32, 384, 1280), (8, 32, 96, 160), (3, 64, 37, 52), (2, 128, 96, 320), (5, 256, 48, 40),
+                                   (2, 512, 24, 80), (1, 512, 12, 40), (9, 16, 20, 24), (7, 128, 9, 11)])
+def test_groupnorm_statistics_exact_and_bit_reproducible(shape, dtype):
+    """the statistics pass against float64 sums of the stored tensor; five launches give identical bits (one workgroup record per
+    slot, added in slot order by whichever workgroup arrives last); B = 1 .. 9 exercises every slot-count class"""
+    from mindtheedge_amd import kernels as K
+    B, C, H, W = shape
+    K.set_compute_dtype(dtype)
+    try:
+        g = torch.Generator().manual_seed(B + C + H)
+        y = K.as_act((torch.randn(B, C, H, W, generator=g) * 2.0 + 0.7).cuda(), K.compute_dtype())
+        runs = [_stats(y, B, H * W, C, K) for _ in range(5)]
+        torch.cuda.synchronize()
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0])
+        v = y.float()[:, :C].reshape(B, 16, -1).double()
+        exact = torch.stack([v.sum(-1), (v * v).sum(-1)], -1).reshape(-1)
+        n = v.shape[-1]
+        assert torch.allclose(runs[0] / n, exact / n, rtol=2e-5, atol=2e-6)
+        if dtype == "fp32" and C <= 256:     # the second input of the residual tail: v = y1 + scale * y2
+            y2 = K.as_act(torch.randn(B, C, H, W, generator=g).cuda(), K.compute_dtype())
+            sc = ((torch.rand(B, C, generator=g) >= 0.5).float() * 2.0).cuda()
+            outs = []
+            for _ in range(3):
+                st = torch.zeros((int(K.lib.mte_gn_stats_elems(B)),), dtype=torch.float64, device="cuda")
+                p1, l1 = K._pl(y)
+                p2, l2 = K._pl(y2)
+                K.lib.mte_gn_stats(p1, l1, p2, l2, sc.data_ptr(), st.data_ptr(), B, H * W, C, K._dt(y), K._stream())
+                outs.append(st[:B * 32].clone())
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+            v2 = (y.float()[:, :C] + y2.float()[:, :C] * sc[:, :, None, None]).reshape(B, 16, -1).double()
+            exact2 = torch.stack([v2.sum(-1), (v2 * v2).sum(-1)], -1).reshape(-1)
+            assert torch.allclose(outs[0] / n, exact2 / n, rtol=2e-5, atol=2e-6)
+    finally:
+        K.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("shape", [(1024, 512, 3, 2, 12, 40), (512, 256, 3, 1, 16, 24), (4096, 256, 3, 1, 24, 80), (256, 512, 1, 2, 12, 40)])
+def test_split_k_convolution_bit_reproducible(shape):
+    """few output tiles + a long reduction (pack4 / pack5.conv, unpack5): the K range is split over workgroups; every split stores
+    its own slab and the finish kernel adds the slabs in split order"""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+    b = (torch.rand(cout, generator=g) - 0.5).cuda()
+    xa = K.image_to_act(torch.rand(B, cin, H, W, generator=g).cuda() * 2 - 1)
+    wf, _ = K.WeightPack().get(w, xa.dtype, False)
+    outs = [K.conv_forward(xa, wf, b, cout, k, k).float().clone() for _ in range(6)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = torch.nn.functional.conv2d(xa.float()[:, :cin].cpu(), w.to(torch.bfloat16).float().cpu(), b.cpu(), padding=k // 2)
+    assert float((outs[0][:, :cout].cpu() - ref).abs().max() / ref.abs().max()) < 8e-3
+
+
+def _net(dropout=0.5):
+    from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
+    torch.manual_seed(42)
+    return PackNetSAN01(dropout=dropout, version="1A").cuda()
+
+
+@pytest.mark.parametrize("B,H,W,runs", [(1, 96, 160, 8), (3, 64, 128, 6), (1, 384, 1280, 4), (4, 384, 1280, 2)])
+def test_eval_forward_bit_reproducible_eager_and_graph(B, H, W, runs):
+    """the four inverse-depth maps of `runs` eager forward passes and `runs` HIP-graph replays of one frame are bit-identical
+    (sizes: the failing plumbing test's, a batch with split-K layers, the benchmark frame, the I4 configuration)"""
+    from mindtheedge_amd.utils.graph import GraphedDepth
+    net = _net().eval()
+    rgb = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(0)).cuda()
+    with torch.no_grad():
+        ref = [t.clone() for t in net(rgb)["inv_depths"][0]]
+        for _ in range(runs - 1):
+            out = net(rgb)["inv_depths"][0]
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b)
+    g = GraphedDepth(net, rgb)
+    for _ in range(runs):
+        out = g(rgb)["inv_depths"][0]
+        torch.cuda.synchronize()
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    # another frame through the same graph, then the first one again
+    rgb2 = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    other = [t.clone() for t in g(rgb2)["inv_depths"][0]]
+    assert not torch.equal(other[0], ref[0])
+    again = g(rgb)["inv_depths"][0]
+    for a, b in zip(again, ref):
+        assert torch.equal(a, b)
+
+
+def test_training_forward_bit_reproducible():
+    """the training-mode forward (no dropout draw, no flip) reproduces its inverse-depth maps bit for bit as well: same kernels"""
+    net = _net(dropout=None).train()
+    rgb = torch.rand(2, 3, 64, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        ref = [t.clone() for t in net(rgb)["inv_depths"]]
+    for _ in range(3):
+        out = net(rgb)["inv_depths"]
+        for a, b in zip(out, ref):
+            assert torch.equal(a.detach(), b)

@@ -73,11 +73,13 @@ def test_infer_edges_synthetic_frame_writes_depth_in_metres(tmp_path, capsys):
     d = np.load(os.path.join(outdir, "00000000_regular.npy"))
     assert d.shape == (96, 160) and d.dtype == np.float32
     assert np.isfinite(d).all() and d.min() >= 0.5 - 1e-6     # depth = 1 / inv, inv = sigmoid/0.5 in (0, 2)
-    # the same frame through the graph-replay path gives the same file (bf16 arithmetic is deterministic per kernel variant)
+    # the same frame through the graph-replay path gives the same FILE, bit for bit: the forward kernels have no floating-point
+    # atomics (tests/test_gpu_determinism.py) and eager / captured launches dispatch the same kernel variants.  (Round 2 compared
+    # depth to 2 % of its maximum here and failed on the driver's box: two forward passes of one frame then differed by 1-2 %.)
     out2 = os.path.join(tmp_path, "results_graph")
     _run_main("infer_edges", ["infer_edges.py", "--config", cfg, "--synthetic", "1", "--output", out2, "--graph"])
     d2 = np.load(os.path.join(out2, "00000000_regular.npy"))
-    assert np.abs(d2 - d).max() <= 2e-2 * np.abs(d).max()
+    assert np.array_equal(d2, d)
 
 
 def test_infer_depth_function_matches_wrapper_depth(tmp_path):
@@ -95,8 +97,7 @@ def test_infer_depth_function_matches_wrapper_depth(tmp_path):
         assert not w.training and tuple(depth.shape) == (2, 1, 64, 128)
         with torch.no_grad():
             want = inv2depth(w.depth(img, rgb_edge=None)["inv_depths"][0][0])
-        # two launches of the same bf16 forward differ by the order of the statistics / split-K atomics only
-        assert float((depth - want).abs().max() / want.abs().max()) < 2e-2
+        assert torch.equal(depth, want)                      # the forward pass is bit-reproducible
     finally:
         K.set_grad_sink(None)
         K.set_compute_dtype("bf16")

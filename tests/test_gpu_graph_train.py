@@ -39,10 +39,14 @@ def test_graphed_steps_equal_eager_steps():
     batches = [synthetic_batch(2, 64, 128, s, dev) for s in (1, 2, 3, 4, 5)]
     try:
         net, model, opt = _setup("fp32", None)
+        before = (opt.flatp.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.steps, torch.cuda.get_rng_state().clone())
         step = GraphedTrainStep(model, opt, batches[0])
         assert step.graphed, step.error
-        assert opt.steps > 0                                       # the warm-up steps trained the network: snapshot AFTER capture
         torch.cuda.synchronize()
+        # construction (warm-up steps + capture) leaves the training state where it was (round-2 advice: it used to train four steps)
+        assert opt.steps == before[3] == 0
+        assert torch.equal(opt.flatp.flat, before[0]) and torch.equal(opt.exp_avg, before[1]) and torch.equal(opt.exp_avg_sq, before[2])
+        assert torch.equal(torch.cuda.get_rng_state(), before[4])
         snap = (opt.flatp.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.steps)
 
         def restore():

@@ -11,6 +11,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import kernel_variant
+
 pytestmark = pytest.mark.gpu
 
 
@@ -39,24 +41,23 @@ def _run(dtype, B, C, H, W, has2, slab):
     gamma, beta = 1.0 + 0.25 * rnd(C), 0.1 * rnd(C)
     dz = rnd(B, C, H, W).to(tdt).float()
     want = _reference(y1, y2, scale2, gamma, beta, dz)
-    K.lib.mte_debug_set(13, 1 if slab else 0)
     try:
-        dev = torch.device("cuda")
-        a1 = K.as_act(y1.to(dev), tdt)
-        a2 = K.as_act(y2.to(dev), tdt) if has2 else None
-        sc = scale2.to(dev) if has2 else None
-        gm, bt = gamma.to(dev), beta.to(dev)
-        single = K.lib.mte_gn_fwd_is_single_pass(H * W, C, int(has2), K._dt(a1))
-        z, stats = K._gn_forward(a1, a2, sc, gm, bt, 1e-5)
-        out = K._gn_backward(K.as_act(dz.to(dev), tdt), a1, a2, sc, stats, gm, bt, 1e-5, has2, want_dbias=not has2)
-        torch.cuda.synchronize()
-        d1, d2, dgamma, dbeta = out[:4]
-        dbias = out[4] if not has2 else None
-        got = (z.float().cpu(), d1.float().cpu(), None if d2 is None else d2.float().cpu(), dgamma.cpu(), dbeta.cpu(),
-               None if dbias is None else dbias.cpu())
-        return got, want, single
+        with kernel_variant(13, 1 if slab else 0, 1):
+            dev = torch.device("cuda")
+            a1 = K.as_act(y1.to(dev), tdt)
+            a2 = K.as_act(y2.to(dev), tdt) if has2 else None
+            sc = scale2.to(dev) if has2 else None
+            gm, bt = gamma.to(dev), beta.to(dev)
+            single = K.lib.mte_gn_fwd_is_single_pass(H * W, C, int(has2), K._dt(a1))
+            z, stats = K._gn_forward(a1, a2, sc, gm, bt, 1e-5)
+            out = K._gn_backward(K.as_act(dz.to(dev), tdt), a1, a2, sc, stats, gm, bt, 1e-5, has2, want_dbias=not has2)
+            torch.cuda.synchronize()
+            d1, d2, dgamma, dbeta = out[:4]
+            dbias = out[4] if not has2 else None
+            got = (z.float().cpu(), d1.float().cpu(), None if d2 is None else d2.float().cpu(), dgamma.cpu(), dbeta.cpu(),
+                   None if dbias is None else dbias.cpu())
+            return got, want, single
     finally:
-        K.lib.mte_debug_set(13, 1)
         K.set_compute_dtype("bf16")
 
 
@@ -95,8 +96,5 @@ def test_slab_route_is_taken_for_the_low_resolution_layers():
     assert q(12 * 40, 512, 0, 0) == 1 and q(12 * 40, 512, 1, 0) == 1        # unpack5 / iconv5 inputs (bf16): slab
     assert q(24 * 80, 512, 0, 0) == 0 and q(48 * 160, 256, 0, 0) == 0       # measured: streaming kernels win from 24x80 up
     assert q(96 * 320, 128, 0, 0) == 0 and q(192 * 640, 64, 0, 0) == 0 and q(384 * 1280, 32, 0, 0) == 0
-    K.lib.mte_debug_set(13, 0)
-    try:
-        assert q(12 * 40, 512, 0, 0) == 0
-    finally:
-        K.lib.mte_debug_set(13, 1)
+    with kernel_variant(13, 0, 1):
+        assert K.lib.mte_gn_fwd_is_single_pass(12 * 40, 512, 0, 0) == 0

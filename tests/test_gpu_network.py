@@ -172,24 +172,6 @@ def test_side_stream_training_steps_match_single_stream():
         K.set_compute_dtype("bf16")
 
 
-def test_network_outputs_with_conv_epilogue_statistics():
-    """The (default-off) fused GroupNorm-statistics path must give the same network as the stand-alone statistics pass."""
-    from mindtheedge_amd import kernels as K
-    g = load_golden("net_packnetsan01_64x128")
-    net = _net("fp32")
-    try:
-        net.train()
-        ref = [t.detach().clone() for t in net(g["rgb"].cuda())["inv_depths"]]
-        K.use_conv_epilogue_stats(True)
-        out = net(g["rgb"].cuda())["inv_depths"]
-        for i in range(4):
-            assert rel_err(out[i].cpu(), g["train_inv%d" % i]) < 1e-3, i
-            assert rel_err(out[i].detach().cpu(), ref[i].cpu()) < 1e-5, i
-    finally:
-        K.use_conv_epilogue_stats(False)
-        K.set_compute_dtype("bf16")
-
-
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
 def test_dee_rgb_only_training_step_matches_reference(dtype, tol):
     """EdgeEstimationLIDARModel trained without a LiDAR input (reference EdgeEstimationLIDARModel.py:135-160 with

@@ -3,7 +3,7 @@
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import rel_err, kernel_variant
 
 pytestmark = pytest.mark.gpu
 
@@ -11,8 +11,7 @@ pytestmark = pytest.mark.gpu
 def _run(C, B, H, W, lds):
     from mindtheedge_amd import kernels as K
     K.set_compute_dtype("bf16")
-    K.lib.mte_debug_set(1, int(lds))          # 0 gather kernels, 1 LDS-tiled (plane by plane), 2 + four-plane unpack backward
-    try:
+    with kernel_variant(1, int(lds), 2):      # 0 gather kernels, 1 LDS-tiled (plane by plane), 2 + four-plane unpack backward [product]
         g = torch.Generator().manual_seed(C * 7 + H)
         x = K.image_to_act((torch.rand(B, C, H, W, generator=g) * 2 - 1).cuda()).detach().requires_grad_(True)
         w3 = ((torch.rand(4, 1, 3, 3, 3, generator=g) - 0.5) * 0.8).cuda().requires_grad_(True)
@@ -22,8 +21,6 @@ def _run(C, B, H, W, lds):
         (y.float() * G).sum().backward()
         torch.cuda.synchronize()
         return y.float().cpu(), x.grad.float().cpu(), w3.grad.cpu(), b3.grad.cpu()
-    finally:
-        K.lib.mte_debug_set(1, 2)
 
 
 @pytest.mark.parametrize("C,B,H,W", [(32, 2, 16, 32), (32, 1, 20, 36), (64, 1, 12, 40), (128, 1, 8, 16), (256, 1, 4, 16),
@@ -40,8 +37,7 @@ def test_lds_pack3d_matches_gather(C, B, H, W):
 def _run_unpack(C, B, H, W, lds):
     from mindtheedge_amd import kernels as K
     K.set_compute_dtype("bf16")
-    K.lib.mte_debug_set(1, int(lds))          # 0 gather kernels, 1 LDS-tiled (plane by plane), 2 + four-plane unpack backward
-    try:
+    with kernel_variant(1, int(lds), 2):      # 0 gather kernels, 1 LDS-tiled (plane by plane), 2 + four-plane unpack backward [product]
         g = torch.Generator().manual_seed(C * 3 + W)
         x = K.image_to_act((torch.rand(B, C, H, W, generator=g) * 2 - 1).cuda()).detach().requires_grad_(True)
         w3 = ((torch.rand(4, 1, 3, 3, 3, generator=g) - 0.5) * 0.8).cuda().requires_grad_(True)
@@ -51,8 +47,6 @@ def _run_unpack(C, B, H, W, lds):
         (y.float() * G).sum().backward()
         torch.cuda.synchronize()
         return y.float().cpu(), x.grad.float().cpu(), w3.grad.cpu(), b3.grad.cpu()
-    finally:
-        K.lib.mte_debug_set(1, 2)
 
 
 @pytest.mark.parametrize("C,B,H,W", [(32, 2, 12, 20), (32, 1, 17, 33), (64, 1, 9, 40), (128, 1, 8, 16), (256, 1, 5, 16), (512, 1, 4, 8)])

@@ -1,6 +1,7 @@
 """Development aid: run one conv shape (fwd, dgrad, wgrad) a few times -- for rocprofv3 --pmc / timing experiments."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MTE_USE_DEV_LIB", "1")      # development knobs live in libmte_hip_dev.so (-DMTE_DEV) only
 import torch
 from mindtheedge_amd import kernels as K
 

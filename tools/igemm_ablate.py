@@ -2,6 +2,7 @@
 4 fragment ds_reads).  Prints time per launch for each subset on a few layer shapes, 256x128 and 128x128 tiles."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MTE_USE_DEV_LIB", "1")      # development knobs live in libmte_hip_dev.so (-DMTE_DEV) only
 import torch
 from mindtheedge_amd import kernels as K
 

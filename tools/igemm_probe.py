@@ -1,6 +1,7 @@
 """development aid: forward implicit-GEMM time vs K depth for one output shape (fixed per-tile overhead vs per-K-step cost)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MTE_USE_DEV_LIB", "1")      # development knobs live in libmte_hip_dev.so (-DMTE_DEV) only
 import torch
 from mindtheedge_amd import kernels as K
 

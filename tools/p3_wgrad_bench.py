@@ -2,6 +2,7 @@
 matrix-core version (mte_debug_set(1, 201)) against the fp32-VALU LDS version (200), time per launch and max relative difference."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MTE_USE_DEV_LIB", "1")      # development knobs live in libmte_hip_dev.so (-DMTE_DEV) only
 import torch
 from mindtheedge_amd import kernels as K
 
