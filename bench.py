@@ -375,6 +375,8 @@ def main():
     for _ in range(args.steps):
         last = step()
     host_dt = time.perf_counter() - t0                   # time the host needed to ENQUEUE the steps (it runs ahead of the GPU)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0                  # this rank's own steps done (before the barrier): straggler spread across ranks
     sync()
     dt = time.perf_counter() - t0
     # the host's own cost per step: three steps enqueued right after a sync (empty queues: `host_dt` above also contains the time the
@@ -420,6 +422,11 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        tl = torch.tensor([dt_local, -dt_local], device=dev, dtype=torch.float64)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        rank_ms = (-float(tl[1]) / args.steps * 1e3, float(tl[0]) / args.steps * 1e3)
+    else:
+        rank_ms = (dt_local / args.steps * 1e3,) * 2
     final = float(last.detach().float().sum()) if args.mode == "train" else float(last.float().mean())
 
     if rank == 0:
@@ -436,7 +443,10 @@ def main():
                           "parallelism": "dp%d (bucketed RCCL all-reduce overlapped with backward)" % world if world > 1 else "single GPU"},
                "final_loss" if args.mode == "train" else "mean_inv_depth": final,
                "host_enqueue_ms_per_step": host_dt / args.steps * 1e3, "host_enqueue_unthrottled_ms_per_step": host_free_dt * 1e3,
-               "step_launch": launch_mode}
+               "step_launch": launch_mode,
+               # fastest / slowest rank's own ms per step, measured to its local device sync BEFORE the closing barrier: the spread
+               # is straggler time, to be read beside allreduce.allreduce_exposed_ms (both are inside ms_per_step)
+               "rank_ms_per_step_min": rank_ms[0], "rank_ms_per_step_max": rank_ms[1]}
         passes = 3.0 if args.mode == "train" else 1.0
         step_flops = conv_flops_per_image(H, W) * B * passes
         res["mfma_fraction_of_step"] = step_flops / (ms * 1e-3) / (BF16_DENSE_PEAK_TFLOPS * 1e12)

@@ -62,6 +62,13 @@ int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* d
 /* OIHW fp32 master weights -> forward pack [Cout][taps][Cin_p] and (optional) dgrad pack [Cin_p][taps rot180][Cout_p] */
 int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout, int Cin, int KH, int KW,
                           int Cin_p, int Cout_p, int dtype, mte_stream_t stream);
+/* Every kernel-ready weight copy of `njobs` conv layers in ceil(njobs / 48) launches (the ~100 layers of the network after an
+ * optimizer step: ~400 launch-bound per-layer launches otherwise).  `jobs` is a HOST array; per job, from the OIHW fp32 master `w`
+ * [Cout][Cin][taps]: wf = forward pack [Cout][taps][Cin_p]; wb (nullable) = data-gradient pack [Cin_p][taps rot180][Cout]; pf / pb
+ * (nullable, bf16 only) = the fragment-block packs of mte_conv2d_patch_fwd for wf / wb (mte_conv2d_patch_pack_elems(Cin_p, Cout, ..)
+ * / (Cout, Cin_p, ..) elements).  end_* are scratch the library fills.  Same values as mte_pack_conv_weights + _patch_repack. */
+typedef struct { const float* w; void* wf; void* wb; void* pf; void* pb; int Cout, Cin, taps, Cin_p; int end_f, end_b, end_pf, end_pb; } mte_pack_job;
+int mte_pack_conv_weights_multi(const void* jobs, int njobs, int dtype, mte_stream_t stream);
 /* dgrad pack derived from an existing forward pack */
 int mte_pack_conv_weights_bwd(const void* wfwd, void* wbwd, int Cout, int KH, int KW, int Cin_p, int dtype, mte_stream_t stream);
 /* sum of the `parts` partial stages -> OIHW fp32 gradient (drops channel padding).  The stage is scratch: with more than 32 parts

@@ -1148,6 +1148,105 @@ __global__ __launch_bounds__(256) void pack_weights_bwd_kernel(const T* __restri
     }
 }
 
+// ---- every weight pack of the network in ONE launch (per <= 48 layers).  After an optimizer step ~100 conv weights need their
+// kernel-ready copies rebuilt: forward pack, data-gradient pack and, for the LDS-patch layers, the two fragment-block packs -- up to
+// four tiny launches per layer, ~400 per training step, 2-10 us each and launch-bound (0.88 ms of GPU time and ~2 ms of host time
+// per step for 0.77 GB of traffic).  Here a job table travels as a kernel argument and every block finds its (job, phase) by a
+// scalar scan; all four packs are formed from the fp32 OIHW master directly, so the phases are independent of each other.
+struct PackJob {                    // == mte_pack_job of include/mte_kernels.h
+    const float* w;                 // OIHW fp32 master [Cout][Cin][taps]
+    void* wf;                       // [Cout][taps][Cin_p]                       (always)
+    void* wb;                       // [Cin_p][taps rot180][Cout]                (nullable)
+    void* pf;                       // fragment blocks of wf (conv_patch.hip)    (nullable, bf16 only)
+    void* pb;                       // fragment blocks of wb                     (nullable, bf16 only)
+    int Cout, Cin, taps, Cin_p;
+    int end_f, end_b, end_pf, end_pb;   // filled by the launcher: cumulative block ends of the job's four phases
+};
+constexpr int PACK_JOBS_MAX = 48;
+struct PackTable { int n; int pad_; PackJob j[PACK_JOBS_MAX]; };
+constexpr int PACK_FRAG_PER_BLOCK = 256 * 8;                        // fragment-pack elements per block (one 16-byte chunk per thread)
+
+template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v) { *(u32x4_t*)dst = pack16<bf16_t>(v); }
+template <> __device__ __forceinline__ void store8<float>(float* dst, const float* v) {
+    *(u32x4_t*)dst = pack16<float>(v); *(u32x4_t*)(dst + 4) = pack16<float>(v + 4);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb) {
+    __shared__ float s_w[64 * 65];                                   // phase f: [64 channels][taps <= 49]; phase b: [64][65] tile
+    int ji = 0;
+    while (ji + 1 < tb.n && (int)blockIdx.x >= tb.j[ji].end_pb) ++ji;    // wave-uniform scalar scan over <= 48 jobs
+    const PackJob& J = tb.j[ji];
+    const int start = ji ? tb.j[ji - 1].end_pb : 0;
+    const int bid = blockIdx.x;
+    const int Cout = J.Cout, Cin = J.Cin, taps = J.taps, Cin_p = J.Cin_p;
+    const float* __restrict__ w = J.w;
+    if (bid < J.end_f) {
+        // ---- forward pack: block = (n, 64-channel chunk); OIHW run of 64*taps floats -> LDS -> [tap][64 channels] runs
+        const int cchunks = (Cin_p + 63) >> 6;
+        const int lb = bid - start, n = lb / cchunks, c0 = (lb - n * cchunks) * 64;
+        const int nc = min(64, Cin - c0);
+        const float* src = w + ((long)n * Cin + c0) * taps;
+        for (int i = threadIdx.x; i < nc * taps; i += 256) s_w[i] = src[i];
+        __syncthreads();
+        const int ncp = min(64, Cin_p - c0);
+        T* wf = (T*)J.wf;
+        for (int i = threadIdx.x; i < taps * ncp; i += 256) {
+            const int tap = i / ncp, cl = i - tap * ncp;
+            Elem<T>::st(wf + ((long)n * taps + tap) * Cin_p + c0 + cl, cl < nc ? s_w[cl * taps + tap] : 0.f);
+        }
+        return;
+    }
+    if (bid < J.end_b) {
+        // ---- data-gradient pack: wb[(c*taps + (taps-1-tap))*Cout + n] = w[n][c][tap]; tile = 64 n x 64 consecutive (c, tap)
+        const int Kp = taps * Cin_p, Kr = taps * Cin;                // (c, tap) positions incl. / excl. channel padding
+        const int ktiles = (Kp + 63) >> 6;
+        const int lb = bid - J.end_f, n0 = (lb / ktiles) * 64, k0 = (lb % ktiles) * 64;
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int r = i >> 6, kk = i & 63;
+            const int n = n0 + r, k = k0 + kk;
+            s_w[r * 65 + kk] = (n < Cout && k < Kr) ? w[(long)n * Kr + k] : 0.f;
+        }
+        __syncthreads();
+        T* wb = (T*)J.wb;
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int kk = i >> 6, nn = i & 63;
+            const int k = k0 + kk, n = n0 + nn;
+            if (k < Kp && n < Cout) {
+                const int c = k / taps, tap = k - c * taps;
+                Elem<T>::st(wb + ((long)c * taps + (taps - 1 - tap)) * Cout + n, s_w[nn * 65 + kk]);
+            }
+        }
+        return;
+    }
+    // ---- fragment-block packs of the LDS-patch kernels: [slice][tap][kk][nt][lane = h*32 + r][8]; one 16-byte chunk per thread
+    const bool fwd = bid < J.end_pf;
+    const int N = fwd ? Cout : Cin_p, C = fwd ? Cin_p : Cout;        // GEMM columns / reduction channels of this direction
+    const int NT = (N + 31) >> 5;
+    const long total8 = (long)((C + 31) >> 5) * taps * 2 * NT * 64;
+    const long i8 = (long)(bid - (fwd ? J.end_b : J.end_pf)) * 256 + threadIdx.x;
+    if (i8 >= total8) return;
+    long t = i8;
+    const int lane = (int)(t & 63); t >>= 6;
+    const int nt = (int)(t % NT); t /= NT;
+    const int kk = (int)(t & 1); t >>= 1;
+    const int tap = (int)(t % taps); const int sl = (int)(t / taps);
+    const int n = nt * 32 + (lane & 31), c0 = sl * 32 + kk * 16 + (lane >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        float x = 0.f;
+        if (n < N && c < C) {
+            if (fwd) { if (c < Cin) x = w[((long)n * Cin + c) * taps + tap]; }                    // wf[n][tap][c]
+            else if (n < Cin) x = w[((long)c * Cin + n) * taps + (taps - 1 - tap)];               // wb[n' = cin][tap][c' = cout]
+        }
+        v[j] = x;
+    }
+    store8<T>((T*)(fwd ? J.pf : J.pb) + i8 * 8, v);
+}
+
 // staging [N][taps][Cin_p] fp32 -> OIHW fp32 gradient (overwrite).  One block = (output channel n, 64 input channels): the
 // [taps][64] slab is read along c (coalesced), transposed in LDS and written as one contiguous run of 64*taps floats.
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ st, float* __restrict__ dw, int Cout, int Cin, int taps, int Cin_p, int parts) {
@@ -1295,6 +1394,38 @@ int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout,
     } else {
         hipLaunchKernelGGL(pack_weights_fwd_kernel<float>, gf, dim3(256), lds, stream, w_oihw, (float*)wfwd, Cout, Cin, taps, Cin_p);
         if (wbwd) hipLaunchKernelGGL(pack_weights_bwd_kernel<float>, gb, dim3(256), 0, stream, (const float*)wfwd, (float*)wbwd, Cout, taps, Cin_p, Cout_p);
+    }
+    return mte_check_launch();
+}
+
+// Every weight pack of `njobs` conv layers (HOST array of mte_pack_job) in ceil(njobs / 48) launches: see pack_multi_kernel.
+int mte_pack_conv_weights_multi(const void* jobs_host, int njobs, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!jobs_host || njobs < 0 || (dtype != MTE_DT_BF16 && dtype != MTE_DT_F32)) return MTE_ERR_ARG;
+    const PackJob* src = (const PackJob*)jobs_host;
+    for (int j0 = 0; j0 < njobs; j0 += PACK_JOBS_MAX) {
+        PackTable tb{};
+        tb.n = njobs - j0 < PACK_JOBS_MAX ? njobs - j0 : PACK_JOBS_MAX;
+        long blocks = 0;
+        for (int i = 0; i < tb.n; ++i) {
+            PackJob J = src[j0 + i];
+            if (!J.w || !J.wf || J.taps < 1 || J.taps > 49 || J.Cin_p % 8 != 0 || J.Cin > J.Cin_p) return MTE_ERR_ARG;
+            if ((J.pf || J.pb) && dtype != MTE_DT_BF16) return MTE_ERR_ARG;
+            if (J.pb && !J.wb) return MTE_ERR_ARG;
+            blocks += (long)J.Cout * ((J.Cin_p + 63) / 64);
+            J.end_f = (int)blocks;
+            if (J.wb) blocks += (long)((J.Cout + 63) / 64) * ((J.taps * J.Cin_p + 63) / 64);
+            J.end_b = (int)blocks;
+            if (J.pf) blocks += ((long)((J.Cin_p + 31) / 32) * J.taps * 2 * ((J.Cout + 31) / 32) * 64 + 255) / 256;
+            J.end_pf = (int)blocks;
+            if (J.pb) blocks += ((long)((J.Cout + 31) / 32) * J.taps * 2 * ((J.Cin_p + 31) / 32) * 64 + 255) / 256;
+            J.end_pb = (int)blocks;
+            if (blocks > 0x7fffffffL) return MTE_ERR_UNSUPPORTED;
+            tb.j[i] = J;
+        }
+        if (blocks == 0) continue;
+        if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, tb);
+        else hipLaunchKernelGGL(pack_multi_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, tb);
     }
     return mte_check_launch();
 }

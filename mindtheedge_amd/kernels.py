@@ -343,6 +343,7 @@ class WeightPack:
         return self.pb
 
     pf_ok = pb_ok = False
+    _want_pf = _want_pb = False
 
     def _pack(self, w, dtype, need_bwd):
         """(re)build the forward (and data-gradient) pack on the current stream, re-using the buffers when they fit"""
@@ -381,17 +382,56 @@ class WeightPack:
         return self.wf, (self.wb if self.has_bwd else None)
 
 
+class _PackJob(ctypes.Structure):           # mte_pack_job of include/mte_kernels.h
+    _fields_ = [("w", ctypes.c_void_p), ("wf", ctypes.c_void_p), ("wb", ctypes.c_void_p), ("pf", ctypes.c_void_p), ("pb", ctypes.c_void_p),
+                ("Cout", ctypes.c_int), ("Cin", ctypes.c_int), ("taps", ctypes.c_int), ("Cin_p", ctypes.c_int),
+                ("end_f", ctypes.c_int), ("end_b", ctypes.c_int), ("end_pf", ctypes.c_int), ("end_pb", ctypes.c_int)]
+
+
+_PACK_CHUNKS = (16, 48)          # jobs per launch: a short first launch (stem .. conv2: the layers the next forward pass needs at once), then 48s
+_pack_jobs = {"sig": None, "chunks": []}
+
+
+def _pack_job_chunks(packs):
+    """ctypes job arrays for mte_pack_conv_weights_multi, cached while no pack changed its buffers: [(array, n, dtype code, packs)]"""
+    sig = (len(packs),) + tuple((id(pk), pk._last[0]().data_ptr(), pk.wf.data_ptr(), _ptr(pk.wb) if pk.has_bwd else 0,
+                                 _ptr(pk.pf) if pk._want_pf else 0, _ptr(pk.pb) if pk._want_pb else 0) for pk in packs)
+    if _pack_jobs["sig"] == sig:
+        return _pack_jobs["chunks"]
+    chunks = []
+    for dt in (torch.bfloat16, torch.float32):               # one element type per launch (in practice all packs share one)
+        part = [pk for pk in packs if pk._last[1] == dt and pk.wf is not None and pk.wf.dtype == dt]
+        i = 0
+        while i < len(part):
+            group = part[i:i + (_PACK_CHUNKS[0] if i == 0 else _PACK_CHUNKS[1])]
+            i += len(group)
+            arr = (_PackJob * len(group))()
+            for o, pk in zip(arr, group):
+                w = pk._last[0]()
+                cout, cin, kh, kw = w.shape
+                o.w, o.wf = w.data_ptr(), pk.wf.data_ptr()
+                o.wb = pk.wb.data_ptr() if pk.has_bwd else None
+                o.pf = pk.pf.data_ptr() if pk._want_pf else None
+                o.pb = pk.pb.data_ptr() if pk._want_pb else None
+                o.Cout, o.Cin, o.taps, o.Cin_p = cout, cin, kh * kw, round8(cin)
+            chunks.append((arr, len(group), DT_BF16 if dt == torch.bfloat16 else DT_F32, group))
+    _pack_jobs["sig"], _pack_jobs["chunks"] = sig, chunks
+    return chunks
+
+
 def prefetch_weight_packs():
     """Re-pack every conv weight that the last forward/backward used, now, on the side stream (called by the optimizer
-    right after it changed the parameters): the ~100 small pack kernels of a step then overlap the first layers of the
-    next forward instead of sitting in front of each layer's convolution.  Packs are rebuilt in place; each carries an
-    event that its next user waits on."""
+    right after it changed the parameters): the packs of a step then overlap the first layers of the next forward instead of
+    sitting in front of each layer's convolution.  All of them -- forward, data-gradient and LDS-patch fragment packs of ~100
+    layers -- are rebuilt in place by three launches of ONE multi-tensor kernel (mte_pack_conv_weights_multi; the per-layer launches
+    they replace were ~400 per step, launch-bound: 0.9 ms of GPU time and ~2 ms of host time).  Each launch's packs share an event
+    that their next user waits on."""
     if not _side["enabled"]:
         return
     packs = []
     for r in WeightPack._live:
         pk = r()
-        if pk is not None and pk._last is not None and pk.key is not None and pk._last[0]() is not None:
+        if pk is not None and pk._last is not None and pk.key is not None and pk._last[0]() is not None and pk._last[0]().is_cuda:
             packs.append(pk)
     WeightPack._live = [r for r in WeightPack._live if r() is not None]
     if not packs:
@@ -404,30 +444,29 @@ def prefetch_weight_packs():
     ev.record()                                              # the parameter update (and every earlier user of the packs)
     side.wait_event(ev)
     with torch.cuda.stream(side):
-        _refold_all()                                        # folded pack weights first: their packs are rebuilt in the loop below
-        group = []
-        for i, pk in enumerate(packs):
-            w, dtype = pk._last[0](), pk._last[1]
-            if not w.is_cuda:
-                continue
-            had_pf, had_pb = pk.pf_ok and pk.pkey == pk.key, pk.pb_ok and pk.pkey == pk.key
-            pk._pack(w, dtype, pk.has_bwd)
-            pk.key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
-            pk.pkey = pk.key
-            pk.pf_ok = pk.pb_ok = False
-            if had_pf:
-                pk._patch_pack(w, 'f')
-                pk.pf_ok = True
-            if had_pb and pk.has_bwd:
-                pk._patch_pack(w, 'b')
-                pk.pb_ok = True
-            group.append(pk)
-            if len(group) == 8 or i + 1 == len(packs):       # one event per group: a stream wait costs about as much as a pack kernel
-                ev = torch.cuda.Event()
-                ev.record(side)
-                for g in group:
-                    g._event = ev
-                group = []
+        _refold_all()                                        # folded pack weights first: their packs are rebuilt below
+        for pk in packs:
+            pk._want_pf = pk.pf_ok and pk.pkey == pk.key and pk.pf is not None
+            pk._want_pb = pk.pb_ok and pk.pkey == pk.key and pk.pb is not None and pk.has_bwd
+        st = _stream()
+        odd = [pk for pk in packs if not (pk._last[0]().is_contiguous() and pk._last[0]().dtype == torch.float32)]
+        if odd:                                              # (not the flat fp32 master layout: per-layer path)
+            packs = [pk for pk in packs if pk not in odd]
+            for pk in odd:
+                w, dtype = pk._last[0](), pk._last[1]
+                pk._pack(w, dtype, pk.has_bwd)
+                pk.key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
+                pk.pkey, pk.pf_ok, pk.pb_ok, pk._event = None, False, False, None
+        for arr, n, dtc, group in _pack_job_chunks(packs):
+            lib.mte_pack_conv_weights_multi(ctypes.addressof(arr), n, dtc, st)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            for pk in group:
+                w, dtype = pk._last[0](), pk._last[1]
+                pk.key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
+                pk.pkey = pk.key
+                pk.pf_ok, pk.pb_ok = pk._want_pf, pk._want_pb
+                pk._event = ev
     if torch.cuda.is_current_stream_capturing():
         # a HIP-graph capture must end with every forked stream joined; inside a graph the packs are DAG nodes that depend on
         # the optimizer only, so the replay still overlaps them with whatever else is ready

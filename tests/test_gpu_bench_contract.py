@@ -38,3 +38,5 @@ def test_bench_json_contract():
     assert ar["rccl_ranks"] == 1 and ar["allreduce_exposed_ms"] == 0.0
     assert max(ar["buckets_mb"]) > 150 and ar["message_mb"] == 32.0            # the 151 MB pack5.conv weight rides in one bucket ...
     assert max(ar["messages_per_bucket"]) >= 5                                   # ... which goes out as <= 32 MB messages
+    # round 3: per-rank step time (fastest / slowest rank, before the closing barrier) beside the max-over-ranks figure
+    assert 0 < d["rank_ms_per_step_min"] <= d["rank_ms_per_step_max"] <= d["ms_per_step"] * 1.001
