@@ -146,10 +146,13 @@ int mte_copy_rects(const void* ops, int n, int B, int C, int dtype, mte_stream_t
 int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,
                      int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);
 /* backward, two independent halves: _data writes dlogit [B,H,W] (fp32 scratch, also the input of _weight) and dx;
- * _weight accumulates dwb [C*9 + 1] = (dW OIHW, db), zeroed here */
+ * _weight writes dwb [C*9 + 1] = (dW OIHW, db): every workgroup stores one record of its sums into `records`
+ * (mte_invdepth_bwd_weight_workspace_elems(C) floats of scratch) and a second small launch adds the records in a fixed order
+ * (no atomics: the C*9+1 contended adds per workgroup cost as much as the stream itself on the 256-channel head) */
 int mte_invdepth_bwd_data(const float* w, const float* inv_out, const float* dout, float* dlogit,
                           void* dx, long lddx, int B, int H, int W, int C, float min_depth, int dtype, mte_stream_t stream);
-int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float* dwb,
+long mte_invdepth_bwd_weight_workspace_elems(int C);
+int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float* dwb, float* records,
                             int B, int H, int W, int C, int dtype, mte_stream_t stream);
 
 /* ---- layout / wiring helpers (networks/depth/PackNetSAN01.py:92-143 cat + Upsample; models/model_utils.py:98-117 flip) */

@@ -27,54 +27,109 @@ struct HeadArgs {
     float* out;                             // [B,H,W] inv-depth
     const float* dlogit;                    // [B,H,W]
     void* dx; long lddx;
-    float* dw;                              // [C*9 + 1] (dw then db), atomically accumulated
+    float* dw;                              // weight gradient: per-workgroup records [grid][rec_stride] of (dw [C*9], db)
+    long rec_stride;
     int B, H, W, C;
     float inv_min_depth;                    // 1 / min_depth = 2
     long npix;
 };
 
-// thread = (pixel, 8-channel block); the C/8 lanes of a pixel are adjacent lanes of one wave
+// ---- InvDepth head kernels, row-marching form.  thread = (image column x, 8-channel block j); the C/8 lanes of a pixel are
+// adjacent lanes of one wave, a wave covers 64 / (C/8) consecutive columns (1 KiB of contiguous NHWC bytes per load instruction).
+// A thread walks DOWN a strip of rows and keeps the 3 x 3 window of its column in registers: every new row costs three chunk
+// loads (columns x-1, x, x+1 of the incoming row, one row ahead of the arithmetic) instead of nine -- the nine-loads-per-pixel
+// form moved 9x the activation bytes through the CU's 64 B/clk vector-cache path and ran 3-4x off the HBM roofline
+// (profiles/r02_v4: forward 168 us, weight gradient 203 us for the 252 MB full-resolution feature map).
+template <typename T> struct Ch8;                                  // 8 channels of one pixel as loaded
+template <> struct Ch8<bf16_t> {
+    u32x4_t a;
+    __device__ __forceinline__ void load(const bf16_t* p) { a = *(const u32x4_t*)p; }
+    __device__ __forceinline__ void zero() { a = u32x4_t{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ void get(float* v) const { unpack16<bf16_t>(a, v); }
+    __device__ __forceinline__ void keep() { asm volatile("" : "+v"(a)); }
+};
+template <> struct Ch8<float> {
+    u32x4_t a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const u32x4_t*)p; b = *(const u32x4_t*)(p + 4); }
+    __device__ __forceinline__ void zero() { a = u32x4_t{0u, 0u, 0u, 0u}; b = a; }
+    __device__ __forceinline__ void get(float* v) const { unpack16<float>(a, v); unpack16<float>(b, v + 4); }
+    __device__ __forceinline__ void keep() { asm volatile("" : "+v"(a), "+v"(b)); }
+};
+
+constexpr int HEAD_ROWS = 20;                                       // rows per strip (two halo rows re-read per strip); multiple of the ring periods 4, 5, 20
+
+// A launch runs as many workgroups as the chip holds at once (occupancy x 256 CUs, found once per kernel) and gives every one a
+// contiguous, balanced range of strips: with one workgroup per strip the last partial round of workgroups ran at a fraction of the
+// occupancy for a whole strip's duration (1,920 strips on 768 resident workgroups = 3 rounds of time for 2.5 rounds of work).
+// Every load is UNCONDITIONAL (clamped address, value zeroed afterwards where the tap is outside the image): a load inside a branch
+// makes the compiler wait with vmcnt(0) before the first use, which serialised the whole register ring on the row just issued
+// (first version of this form: 112 us against 157 us for the nine-loads form; the loop was paying one memory latency per row).
+#define HEAD_MAP()                                                                   \
+    const int cb = a.C >> 3, j = threadIdx.x % cb, c0 = j * 8, pxw = 256 / cb;       \
+    const int strips_x = (a.W + pxw - 1) / pxw, strips_y = (a.H + HEAD_ROWS - 1) / HEAD_ROWS; \
+    const long nstrips = (long)strips_x * strips_y * a.B;                            \
+    const int s_first = (int)(nstrips * blockIdx.x / gridDim.x), s_last = (int)(nstrips * (blockIdx.x + 1) / gridDim.x);
+#define HEAD_STRIP()                                                                 \
+    int sid = strip;                                                                 \
+    const int sx = sid % strips_x; sid /= strips_x;                                  \
+    const int sy = sid % strips_y; const int b = sid / strips_y;                     \
+    const int x = sx * pxw + threadIdx.x / cb;                                       \
+    const int y0 = sy * HEAD_ROWS, y1 = min(a.H, y0 + HEAD_ROWS);                    \
+    const bool xin = x < a.W;                                                        \
+    const int xc[3] = {min(max(x - 1, 0), a.W - 1), min(x, a.W - 1), min(x + 1, a.W - 1)};   \
+    const bool xok[3] = {xin && x >= 1, xin, xin && x + 1 < a.W};
+
 template <typename T>
 __global__ __launch_bounds__(256) void invdepth_fwd_kernel(HeadArgs a) {
-    const int cb = a.C >> 3;
-    const int j = threadIdx.x % cb;
-    const int c0 = j * 8;
+    HEAD_MAP();
     float wr[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 8; ++i) wr[t][i] = a.w[(c0 + i) * 9 + t];
     const float bias = a.bias[0];
-    const long ppb = 256 / cb;                                  // pixels per block iteration
-    const long iters = (a.npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
-    for (long it = 0; it < iters; ++it) {
-        const long pixl = (it * gridDim.x + blockIdx.x) * ppb + threadIdx.x / cb;
-        const bool live = pixl < a.npix;
-        const long pix = live ? pixl : a.npix - 1;
-        const int x = (int)(pix % a.W); const long t2 = pix / a.W; const int y = (int)(t2 % a.H);
-        // all nine 16-byte loads are issued before the first multiply (clamped addresses, out-of-image taps masked afterwards)
-        u32x4_t raw[9];
-        bool ok[9];
+#pragma unroll 1
+    for (int strip = s_first; strip < s_last; ++strip) {
+        HEAD_STRIP();
+        const T* img = (const T*)a.x + (long)b * a.H * a.W * a.ldx + c0;
+        float* out = a.out + (long)b * a.H * a.W;
+        Ch8<T> r[5][3];                                             // rows y-1, y, y+1 and two rows in flight (roles rotate; indices are compile-time)
+        bool rok[5];                                                // the row is inside the image
+        auto load_row = [&](int y, Ch8<T> (&d)[3], bool& ok) {
+            ok = (unsigned)y < (unsigned)a.H;
+            const long row = (long)min(max(y, 0), a.H - 1) * a.W;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            ok[t] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const long q = ok[t] ? pix + (long)(t / 3 - 1) * a.W + (t % 3 - 1) : pix;
-            if constexpr (sizeof(T) == 2) raw[t] = *(const u32x4_t*)((const T*)a.x + q * a.ldx + c0);
+            for (int cx = 0; cx < 3; ++cx) d[cx].load(img + (row + xc[cx]) * a.ldx);
+        };
+        auto dot_row = [&](const Ch8<T> (&d)[3], bool ok, int trow, float acc) {
+#pragma unroll
+            for (int cx = 0; cx < 3; ++cx) {
+                float v[8];
+                Ch8<T> t = d[cx];
+                t.keep();                                           // unpack HERE (the compiler otherwise keeps the ring as unpacked floats: 2x the registers)
+                t.get(v);
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) part = fmaf(v[i], wr[trow * 3 + cx][i], part);
+                acc += (ok && xok[cx]) ? part : 0.f;
+            }
+            return acc;
+        };
+        load_row(y0 - 1, r[0], rok[0]); load_row(y0, r[1], rok[1]); load_row(y0 + 1, r[2], rok[2]); load_row(y0 + 2, r[3], rok[3]);
+#define HEAD_FWD_STEP(K, R0, R1, R2, R4)                                                          \
+    {                                                                                             \
+        const int yy = y + K;                                                                     \
+        load_row(yy + 3, r[R4], rok[R4]);                                                         \
+        float acc = dot_row(r[R0], rok[R0], 0, 0.f);                                              \
+        acc = dot_row(r[R1], rok[R1], 1, acc);                                                    \
+        acc = dot_row(r[R2], rok[R2], 2, acc);                                                    \
+        for (int o = cb >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);                      \
+        if (xin && j == 0 && yy < y1) out[(long)yy * a.W + x] = a.inv_min_depth / (1.f + __expf(-(acc + bias))); \
+    }
+        for (int y = y0; y < y1; y += 5) {
+            HEAD_FWD_STEP(0, 0, 1, 2, 4) HEAD_FWD_STEP(1, 1, 2, 3, 0) HEAD_FWD_STEP(2, 2, 3, 4, 1) HEAD_FWD_STEP(3, 3, 4, 0, 2) HEAD_FWD_STEP(4, 4, 0, 1, 3)
         }
-        float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float v[8];
-            if constexpr (sizeof(T) == 2) unpack16<T>(raw[t], v);
-            else ld8<T>((const T*)a.x + (ok[t] ? pix + (long)(t / 3 - 1) * a.W + (t % 3 - 1) : pix) * a.ldx + c0, v);
-            float part = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) part = fmaf(v[i], wr[t][i], part);
-            acc += ok[t] ? part : 0.f;
-        }
-        for (int o = cb >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (live && j == 0) a.out[pix] = a.inv_min_depth / (1.f + __expf(-(acc + bias)));
+#undef HEAD_FWD_STEP
     }
 }
 
@@ -89,51 +144,51 @@ __global__ void invdepth_dlogit_kernel(const float* __restrict__ dout, const flo
 // Backward of the head, as two independent streams over the pixels (the logit gradient dlogit is one fp32 per pixel):
 //   data   : dx[q][c]  = sum_t dlogit[q - t] * w[c][t]        -- needs no activation at all: a pure 16-B store stream
 //   weight : dw[c][t] += sum_q dlogit[q - t] * x[q][c], db += sum_q dlogit[q]   -- a pure load stream with 72 register
-//            accumulators per thread, one LDS + one global atomic pass per block
+//            accumulators per thread, one record of sums per workgroup
 // Split because together they need 72 weights + 72 accumulators per thread (256 VGPRs, 8 waves/CU, latency-bound);
-// apart each keeps < 128 VGPRs, and the weight half can run on the weight-gradient side stream.
+// apart each keeps < 160 VGPRs, and the weight half can run on the weight-gradient side stream.
+// Both march down rows with the 3 x 3 window of dlogit in registers: tap t = (ty, tx) of pixel (y, x) meets dlogit(y + 1 - ty, x + 1 - tx).
+struct DlRow { float v[3]; bool ok; };                             // raw loads + "row inside the image"; masked where it is USED (HEAD_DL)
+#define HEAD_LOAD_DL(Y, D)                                                                        \
+    {                                                                                             \
+        (D).ok = (unsigned)(Y) < (unsigned)a.H;                                                   \
+        const long row_ = (long)min(max((Y), 0), a.H - 1) * a.W;                                  \
+        _Pragma("unroll") for (int cx = 0; cx < 3; ++cx) (D).v[cx] = dl[row_ + xc[cx]];           \
+    }
+#define HEAD_DL(D, CX) (((D).ok && xok[CX]) ? (D).v[CX] : 0.f)
+
 template <typename T>
 __global__ __launch_bounds__(256) void invdepth_bwd_data_kernel(HeadArgs a) {
-    const int cb = a.C >> 3;
-    const int j = threadIdx.x % cb;
-    const int c0 = j * 8;
+    HEAD_MAP();
     float wr[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 8; ++i) wr[t][i] = a.w[(c0 + i) * 9 + t];
-    const long ppb = 256 / cb;
-    const long stride = (long)gridDim.x * ppb;
-    constexpr int U = 2;
 #pragma unroll 1
-    for (long base = blockIdx.x * ppb + threadIdx.x / cb; base < a.npix; base += stride * U) {
-        float dl[U][9];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long pix = base + u * stride;
-            if (pix < a.npix) {
-                const int x = (int)(pix % a.W); const int y = (int)((pix / a.W) % a.H);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int oy = t / 3 - 1, ox = t % 3 - 1;
-                    const bool ok = (unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W;
-                    dl[u][t] = ok ? a.dlogit[pix - (long)oy * a.W - ox] : 0.f;
-                }
-            }
+    for (int strip = s_first; strip < s_last; ++strip) {
+        HEAD_STRIP();
+        const float* dl = a.dlogit + (long)b * a.H * a.W;
+        T* dx = (T*)a.dx + (long)b * a.H * a.W * a.lddx + c0;
+        DlRow d[4];
+        HEAD_LOAD_DL(y0 - 1, d[0]) HEAD_LOAD_DL(y0, d[1]) HEAD_LOAD_DL(y0 + 1, d[2])
+#define HEAD_BD_STEP(K, R0, R1, R2, R3)                                                           \
+    {                                                                                             \
+        const int yy = y + K;                                                                     \
+        HEAD_LOAD_DL(yy + 2, d[R3])                                                               \
+        float dxv[8];                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) dxv[i] = 0.f;                               \
+        _Pragma("unroll") for (int ty = 0; ty < 3; ++ty)                                          \
+            _Pragma("unroll") for (int tx = 0; tx < 3; ++tx) {                                    \
+                const float g = ty == 0 ? HEAD_DL(d[R2], 2 - tx) : (ty == 1 ? HEAD_DL(d[R1], 2 - tx) : HEAD_DL(d[R0], 2 - tx)); \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) dxv[i] = fmaf(g, wr[ty * 3 + tx][i], dxv[i]); \
+            }                                                                                     \
+        if (xin && yy < y1) st8<T>(dx + ((long)yy * a.W + x) * a.lddx, dxv);                      \
+    }
+        for (int y = y0; y < y1; y += 4) {
+            HEAD_BD_STEP(0, 0, 1, 2, 3) HEAD_BD_STEP(1, 1, 2, 3, 0) HEAD_BD_STEP(2, 2, 3, 0, 1) HEAD_BD_STEP(3, 3, 0, 1, 2)
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long pix = base + u * stride;
-            if (pix >= a.npix) break;
-            float dxv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dxv[i] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) dxv[i] = fmaf(dl[u][t], wr[t][i], dxv[i]);
-            st8<T>((T*)a.dx + pix * a.lddx + c0, dxv);
-        }
+#undef HEAD_BD_STEP
     }
 }
 
@@ -142,49 +197,50 @@ __global__ __launch_bounds__(256) void invdepth_bwd_weight_kernel(HeadArgs a) {
     extern __shared__ float sdw[];                               // [C*9 + 1] block-level gradient accumulators
     for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) sdw[i] = 0.f;
     __syncthreads();
-    const int cb = a.C >> 3;
-    const int j = threadIdx.x % cb;
-    const int c0 = j * 8;
+    HEAD_MAP();
     float gw[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 8; ++i) gw[t][i] = 0.f;
     float gb = 0.f;
-    const long ppb = 256 / cb;
-    const long stride = (long)gridDim.x * ppb;
-    constexpr int U = 4;                                         // 16-byte activation loads in flight per thread
 #pragma unroll 1
-    for (long base = blockIdx.x * ppb + threadIdx.x / cb; base < a.npix; base += stride * U) {
-        u32x4_t xr[U];
-        float dl[U][9];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                              // every load of the batch first: activations and logit gradients
-            const long pix = base + u * stride;
-            if (pix < a.npix) {
-                if constexpr (sizeof(T) == 2) xr[u] = *(const u32x4_t*)((const T*)a.x + pix * a.ldx + c0);
-                const int x = (int)(pix % a.W); const int y = (int)((pix / a.W) % a.H);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int oy = t / 3 - 1, ox = t % 3 - 1;
-                    const bool ok = (unsigned)(y - oy) < (unsigned)a.H && (unsigned)(x - ox) < (unsigned)a.W;
-                    dl[u][t] = ok ? a.dlogit[pix - (long)oy * a.W - ox] : 0.f;
-                }
-            }
+    for (int strip = s_first; strip < s_last; ++strip) {
+        HEAD_STRIP();
+        const float* dl = a.dlogit + (long)b * a.H * a.W;
+        const T* img = (const T*)a.x + (long)b * a.H * a.W * a.ldx + c0;
+        DlRow d[5];
+        Ch8<T> xr[4];                                                // this row's activations and three rows in flight: one 16-byte load per
+        bool xrok[4];                                                // thread and row is all this stream reads, so its depth is the memory parallelism
+#define HEAD_LOAD_X(Y, S) { xrok[S] = xin && (Y) < y1; xr[S].load(img + ((long)min((Y), a.H - 1) * a.W + xc[1]) * a.ldx); }
+        HEAD_LOAD_DL(y0 - 1, d[0]) HEAD_LOAD_DL(y0, d[1]) HEAD_LOAD_DL(y0 + 1, d[2]) HEAD_LOAD_DL(y0 + 2, d[3])
+        HEAD_LOAD_X(y0, 0) HEAD_LOAD_X(y0 + 1, 1) HEAD_LOAD_X(y0 + 2, 2)
+#define HEAD_BW_STEP(K, R0, R1, R2, R4, X0, X3)                                                   \
+    {                                                                                             \
+        const int yy = y + K;                                                                     \
+        HEAD_LOAD_DL(yy + 3, d[R4])                                                               \
+        HEAD_LOAD_X(yy + 3, X3)                                                                   \
+        float v[8];                                                                               \
+        { Ch8<T> t = xr[X0]; t.keep(); t.get(v); }                                                \
+        const bool live = xrok[X0];                                                               \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = live ? v[i] : 0.f;                   \
+        if (j == 0 && live) gb += HEAD_DL(d[R1], 1);                                              \
+        _Pragma("unroll") for (int ty = 0; ty < 3; ++ty)                                          \
+            _Pragma("unroll") for (int tx = 0; tx < 3; ++tx) {                                    \
+                const float g = ty == 0 ? HEAD_DL(d[R2], 2 - tx) : (ty == 1 ? HEAD_DL(d[R1], 2 - tx) : HEAD_DL(d[R0], 2 - tx)); \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) gw[ty * 3 + tx][i] = fmaf(g, v[i], gw[ty * 3 + tx][i]); \
+            }                                                                                     \
+    }
+        // ring roles after k steps: dlogit rows (k, k+1, k+2 | in flight k+3 | free k+4) mod 5, activations (k | .. | free k+3) mod 4: period 20
+        for (int y = y0; y < y1; y += 20) {
+            HEAD_BW_STEP(0, 0, 1, 2, 4, 0, 3) HEAD_BW_STEP(1, 1, 2, 3, 0, 1, 0) HEAD_BW_STEP(2, 2, 3, 4, 1, 2, 1) HEAD_BW_STEP(3, 3, 4, 0, 2, 3, 2)
+            HEAD_BW_STEP(4, 4, 0, 1, 3, 0, 3) HEAD_BW_STEP(5, 0, 1, 2, 4, 1, 0) HEAD_BW_STEP(6, 1, 2, 3, 0, 2, 1) HEAD_BW_STEP(7, 2, 3, 4, 1, 3, 2)
+            HEAD_BW_STEP(8, 3, 4, 0, 2, 0, 3) HEAD_BW_STEP(9, 4, 0, 1, 3, 1, 0) HEAD_BW_STEP(10, 0, 1, 2, 4, 2, 1) HEAD_BW_STEP(11, 1, 2, 3, 0, 3, 2)
+            HEAD_BW_STEP(12, 2, 3, 4, 1, 0, 3) HEAD_BW_STEP(13, 3, 4, 0, 2, 1, 0) HEAD_BW_STEP(14, 4, 0, 1, 3, 2, 1) HEAD_BW_STEP(15, 0, 1, 2, 4, 3, 2)
+            HEAD_BW_STEP(16, 1, 2, 3, 0, 0, 3) HEAD_BW_STEP(17, 2, 3, 4, 1, 1, 0) HEAD_BW_STEP(18, 3, 4, 0, 2, 2, 1) HEAD_BW_STEP(19, 4, 0, 1, 3, 3, 2)
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long pix = base + u * stride;
-            if (pix >= a.npix) break;
-            float v[8];
-            if constexpr (sizeof(T) == 2) unpack16<T>(xr[u], v);
-            else ld8<T>((const T*)a.x + pix * a.ldx + c0, v);            // fp32 validation mode: 8 channels = two chunks
-            if (j == 0) gb += dl[u][4];
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) gw[t][i] = fmaf(dl[u][t], v[i], gw[t][i]);
-        }
+#undef HEAD_BW_STEP
+#undef HEAD_LOAD_X
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -192,7 +248,37 @@ __global__ __launch_bounds__(256) void invdepth_bwd_weight_kernel(HeadArgs a) {
         for (int i = 0; i < 8; ++i) atomicAdd(&sdw[(c0 + i) * 9 + t], gw[t][i]);
     if (j == 0) atomicAdd(&sdw[a.C * 9], gb);
     __syncthreads();
-    for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) atomicAdd(&a.dw[i], sdw[i]);
+    // one record per workgroup (plain stores; invdepth_reduce_kernel adds the records up): C*9+1 same-address global atomics per
+    // workgroup cost 13-33 us per launch at ~0.09 TB/s of contended adds -- as much as the stream itself on the 256-channel head
+    float* rec = a.dw + (long)blockIdx.x * a.rec_stride;
+    for (int i = threadIdx.x; i < a.C * 9 + 1; i += 256) rec[i] = sdw[i];
+}
+
+// out[i] = sum_p rec[p][i]: block = 64 outputs x 16 record lanes (eight loads in flight per thread), records added in a fixed order
+__global__ __launch_bounds__(1024) void invdepth_reduce_kernel(const float* __restrict__ rec, long stride, int parts, int n, float* __restrict__ out) {
+    __shared__ float s[16][64];
+    const int lo = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + lo;
+    float acc = 0.f;
+    if (o < n) {
+        int p = q;
+        for (; p + 7 * 16 < parts; p += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = rec[(long)(p + k * 16) * stride + o];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; p < parts; p += 16) acc += rec[(long)p * stride + o];
+    }
+    s[q][lo] = acc;
+    __syncthreads();
+    if (q == 0 && o < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s[k][lo];
+        out[o] = t;
+    }
 }
 
 template <typename T>
@@ -346,6 +432,23 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __res
 
 inline int stream_grid(long n, int per = 256) { long g = (n + per - 1) / per; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 inline bool head_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <= 64 && (cb & (cb - 1)) == 0; }
+inline long head_strips(int B, int H, int W, int C) {               // strips of the row-marching head kernels (see HEAD_MAP)
+    const int pxw = 256 / (C >> 3);
+    return (long)((W + pxw - 1) / pxw) * ((H + HEAD_ROWS - 1) / HEAD_ROWS) * B;
+}
+// workgroups the chip holds at once for kernel `f` (256 threads, `lds` dynamic bytes); queried once per kernel
+template <typename F> int head_resident(F f, size_t lds, int* cache) {
+    if (*cache == 0) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        *cache = per_cu * cus;
+    }
+    return *cache;
+}
+inline long head_record_stride(int C) { return ((long)C * 9 + 1 + 3) / 4 * 4; }
+constexpr int HEAD_WGRAD_MAX_BLOCKS = 1024;
 
 }  // namespace
 
@@ -357,10 +460,12 @@ int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias,
     if (!x || !w || !bias || !out || !head_ok(C)) return MTE_ERR_ARG;
     HeadArgs a{}; a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.C = C;
     a.inv_min_depth = 1.f / min_depth; a.npix = (long)B * H * W;
-    const int ppb = 256 / (C / 8);
-    const int grid = stream_grid(a.npix, ppb * 4);
-    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(invdepth_fwd_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
+    long grid = head_strips(B, H, W, C);
+    static int res_b = 0, res_f = 0;
+    const long res = dtype == MTE_DT_BF16 ? head_resident(invdepth_fwd_kernel<bf16_t>, 0, &res_b) : head_resident(invdepth_fwd_kernel<float>, 0, &res_f);
+    if (grid > res) grid = res;
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_fwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(invdepth_fwd_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
 
@@ -372,28 +477,35 @@ int mte_invdepth_bwd_data(const float* w, const float* inv_out, const float* dou
     const long npix = (long)B * H * W;
     hipLaunchKernelGGL(invdepth_dlogit_kernel, dim3(stream_grid(npix)), dim3(256), 0, stream, dout, inv_out, dlogit, npix, 1.f / min_depth);
     HeadArgs a{}; a.w = w; a.dlogit = dlogit; a.dx = dx; a.lddx = lddx; a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
-    const int ppb = 256 / (C / 8);
-    const int grid = stream_grid(npix, ppb * 4);
-    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_data_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(invdepth_bwd_data_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
+    long grid = head_strips(B, H, W, C);
+    static int res_b = 0, res_f = 0;
+    const long res = dtype == MTE_DT_BF16 ? head_resident(invdepth_bwd_data_kernel<bf16_t>, 0, &res_b) : head_resident(invdepth_bwd_data_kernel<float>, 0, &res_f);
+    if (grid > res) grid = res;
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_data_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(invdepth_bwd_data_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
 
-int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float* dwb,
+// floats of `records` scratch mte_invdepth_bwd_weight needs (one record of C*9+1 sums per workgroup)
+long mte_invdepth_bwd_weight_workspace_elems(int C) { return head_ok(C) ? HEAD_WGRAD_MAX_BLOCKS * head_record_stride(C) : 0; }
+
+int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float* dwb, float* records,
                             int B, int H, int W, int C, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!x || !dlogit || !dwb || !head_ok(C)) return MTE_ERR_ARG;
+    if (!x || !dlogit || !dwb || !records || !head_ok(C)) return MTE_ERR_ARG;
     const long npix = (long)B * H * W;
-    if (mte_memset_async(dwb, 0, sizeof(float) * (C * 9 + 1), stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    HeadArgs a{}; a.x = x; a.ldx = ldx; a.dlogit = dlogit; a.dw = dwb; a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
-    const int ppb = 256 / (C / 8);
-    // few, long-running blocks: every block ends with C*9+1 same-address global atomics (contended adds are ~14x slower);
-    // each block should stream >= ~4x more 16-byte chunks than it issues atomics: npix * C/8 / g >= 4 * 9C
-    long g = npix / 288; if (g > 1024) g = 1024; if (g < 64) g = 64;
-    if (g > (npix + ppb - 1) / ppb) g = (npix + ppb - 1) / ppb;
+    HeadArgs a{}; a.x = x; a.ldx = ldx; a.dlogit = dlogit; a.dw = records; a.rec_stride = head_record_stride(C);
+    a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
     const size_t lds = sizeof(float) * (C * 9 + 4);
+    long g = head_strips(B, H, W, C);
+    static int res_b = 0, res_f = 0;
+    const long res = dtype == MTE_DT_BF16 ? head_resident(invdepth_bwd_weight_kernel<bf16_t>, lds, &res_b) : head_resident(invdepth_bwd_weight_kernel<float>, lds, &res_f);
+    if (g > res) g = res;
+    if (g > HEAD_WGRAD_MAX_BLOCKS) g = HEAD_WGRAD_MAX_BLOCKS;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(invdepth_bwd_weight_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, a);
+    const int n = C * 9 + 1;
+    hipLaunchKernelGGL(invdepth_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, stream, records, a.rec_stride, (int)g, n, dwb);
     return mte_check_launch();
 }
 

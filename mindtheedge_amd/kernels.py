@@ -1131,7 +1131,8 @@ class InvDepthFn(torch.autograd.Function):
         def weight_grads():
             xp, ldx = _pl(x)
             dwb = torch.empty((C * 9 + 1,), dtype=torch.float32, device=x.device)
-            lib.mte_invdepth_bwd_weight(xp, ldx, dlogit.data_ptr(), dwb.data_ptr(), B, H, W, C, _dt(x), _stream())
+            rec = torch.empty((int(lib.mte_invdepth_bwd_weight_workspace_elems(C)),), dtype=torch.float32, device=x.device)
+            lib.mte_invdepth_bwd_weight(xp, ldx, dlogit.data_ptr(), dwb.data_ptr(), rec.data_ptr(), B, H, W, C, _dt(x), _stream())
             return _deliver(w, dwb[:C * 9].view(1, C, 3, 3)), _deliver(b, dwb[C * 9:])
 
         if _side["enabled"] and _all_sunk(w, b):
