@@ -81,6 +81,7 @@ int mte_colsum(const void* y, long ld, long M, int N, float* out, int dtype, mte
  * same math as mte_conv2d_igemm / mte_conv2d_wgrad, different tiling (the 8x32-pixel tile's input patch is staged once
  * per 32-channel slice and reused by all k*k taps).  *_supported and *_pack_elems are queries (they return a value). */
 int mte_conv2d_patch_supported(int W, int Cin_p, int N, int KH, int KW, int dtype);
+int mte_conv2d_patch_wgrad_supported(int W, int Cin_p, int N, int KH, int KW, int dtype);   /* + 3x3 layers with 65..128 output channels (weight gradient only) */
 long mte_conv2d_patch_pack_elems(int Cin_p, int N, int KH, int KW);
 int mte_conv2d_patch_repack(const void* wgeneric, void* wpatch, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy,

@@ -205,16 +205,23 @@ struct PatchWgradArgs {
 // registers while the current one is consumed.
 // NW = waves per workgroup: 4, or 8 (two waves per SIMD share the staged tile: the kernel holds one 114 KB workgroup per CU, and
 // with a single wave per SIMD every LDS read latency and barrier of the k-loop was exposed).
-template <int K, int NT, int SL, int NW = 4>
+// NH = 2 (round 3, 65..128 output channels): the dy tile holds NH * NT tiles of 32 channels and the waves are split over the two
+// halves (wave & 1), each half dealing the (tap, slice) units to its NW / 2 waves -- the 128-channel 3x3 layers at 96x320 used to run
+// on the generic per-tap weight gradient, which re-streams x and dy nine times from L2 (3.0x HBM-side traffic, 510-540 TFLOP/s).
+template <int K, int NT, int SL, int NW = 4, int NH = 1, int THW = 8>
 __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArgs a) {
+    constexpr int TH = THW;                                        // tile rows (shadows the file-level 8; the wide variant stages 4-row tiles:
+                                                                   // with 8 rows the next tile parked in registers pushed it past 256 VGPRs)
     constexpr int NTHR = NW * 64;
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int UNITS = TAPS * SL;                               // (tap, slice) accumulator units, dealt round-robin to the waves
-    constexpr int TPW = (UNITS + NW - 1) / NW;                           // (dealing whole taps left 3x3 layers at 3:2:2:2 -- 25 % of the MFMA slots idle)
+    constexpr int SLOTS = NW / NH;                                 // waves that share the units of one output half
+    constexpr int TPW = (UNITS + SLOTS - 1) / SLOTS;                     // (dealing whole taps left 3x3 layers at 3:2:2:2 -- 25 % of the MFMA slots idle)
     constexpr int XRS = SL == 1 ? 64 : 192;                        // x / dy pixel row strides: odd multiples of 64 B
     constexpr int XCH = PH * PW * 4 * SL, NXC = (XCH + NTHR - 1) / NTHR;
-    constexpr int YRS = NT == 1 ? 64 : 192;
-    constexpr int YCH = TH * TW * NT * 4, NYC = YCH / NTHR;
+    constexpr int NTT = NT * NH;                                   // 32-channel tiles of the staged dy tile
+    constexpr int YRS = NTT == 1 ? 64 : (NTT == 2 ? 192 : 320);
+    constexpr int YCH = TH * TW * NTT * 4, NYC = YCH / NTHR;
     static_assert(YCH % NTHR == 0, "the dy tile must split evenly over the threads");
     constexpr int XBYTES = PH * PW * XRS;
     extern __shared__ __attribute__((aligned(16))) char smem[];    // [XBYTES] then [TH*TW*YRS]
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
 #pragma unroll
         for (int i = 0; i < NYC; ++i) {
             const int idc = tid + i * NTHR;
-            const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
+            const int pix = idc / (NTT * 4), c = idc - pix * (NTT * 4);
             const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (yy < a.H && c < npp) v = *(const u32x4_t*)(a.dy + (((long)b * a.H + yy) * a.W + xx) * a.lddy + c * 8);
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
 #pragma unroll
         for (int i = 0; i < NYC; ++i) {
             const int idc = tid + i * NTHR;
-            const int pix = idc / (NT * 4), c = idc - pix * (NT * 4);
+            const int pix = idc / (NTT * 4), c = idc - pix * (NTT * 4);
             *(u32x4_t*)(Y + pix * YRS + c * 16) = sy[i];
         }
     };
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
     // transposing-read lane roles: 16-lane group g: channels 16*(g&1) + 4p.., pixels 8*(g>>1) + q (+4 for the 2nd read)
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
     const int chb = 16 * (g & 1) + 4 * pp, pxb = 8 * (g >> 1) + q;
+    const int nh = NH == 2 ? (wave & 1) : 0, slot = NH == 2 ? (wave >> 1) : wave;      // output half of this wave, its place among the half's waves
 
     if (t_begin < t_end) {
         load_tile(t_begin);
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
                 u32x4_t fy[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const char* base = Y + (row * TW + col0 + pxb) * YRS + (n * 32 + chb) * 2;
+                    const char* base = Y + (row * TW + col0 + pxb) * YRS + ((nh * NT + n) * 32 + chb) * 2;
                     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
                     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * YRS));
                     uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
                 }
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const int u = wave + NW * i;
+                    const int u = slot + SLOTS * i;
                     if (u < UNITS) {
                         const int tap = u / SL, sl = u - tap * SL;
                         const int dyy = tap / K, dxx = tap - dyy * K;
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int u = wave + NW * i;
+        const int u = slot + SLOTS * i;
         if (u >= UNITS) continue;
         const int tap = u / SL, sl = u - tap * SL;
         const int cc = (slice * SL + sl) * 32 + r;
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = n * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int co = (nh * NT + n) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (co < a.N) {
                     float* dst = a.dw + (long)blockIdx.x * a.part_stride + ((long)co * TAPS + tap) * a.Cin_p + cc;
                     if (a.part_stride) *dst = acc[i][n][e]; else atomicAdd(dst, acc[i][n][e]);
@@ -371,19 +379,22 @@ template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
 }
 
 int g_patch_wgrad_8w = 1;                            // development knob (mte_debug_set(11, 200 + v)): 0 = four waves per workgroup everywhere
+int g_patch_wgrad_wide = 1;                          // development knob (mte_debug_set(11, 300 + v)): 0 = 65..128 output channels stay on the generic weight gradient
 
-template <int K, int NT, int SL, int NW = 4> int launch_wgrad_sl(PatchWgradArgs a, hipStream_t st, int parts_cap, int* parts_out) {
+template <int K, int NT, int SL, int NW = 4, int NH = 1, int THW = 8> int launch_wgrad_sl(PatchWgradArgs a, hipStream_t st, int parts_cap, int* parts_out) {
+    constexpr int TH = THW;
     constexpr int PH = TH + K - 1, PW = TW + K - 1;
-    constexpr int XRS = SL == 1 ? 64 : 192, YRS = NT == 1 ? 64 : 192;
+    constexpr int XRS = SL == 1 ? 64 : 192, YRS = NT * NH == 1 ? 64 : (NT * NH == 2 ? 192 : 320);
     const size_t lds = PH * PW * XRS + TH * TW * YRS;
     const int nslices = (a.Cin_p + 32 * SL - 1) / (32 * SL);
     const long ntiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
-    long groups = (g_patch_wgrad_wgs + nslices - 1) / nslices;     // ~2 workgroups per CU in total
+    // ~2 workgroups per CU in total; the 147 KB wide variant (NH = 2) holds one per CU: one round of workgroups, half the slabs to add up
+    long groups = ((NH == 2 ? 256 : g_patch_wgrad_wgs) + nslices - 1) / nslices;
     if (groups > ntiles) groups = ntiles;
     a.groups = (int)groups;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_patch_wgrad_kernel<K, NT, SL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_patch_wgrad_kernel<K, NT, SL, NW, NH, THW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MTE_ERR_LAUNCH;
         attr_set = true;
     }
@@ -395,7 +406,7 @@ template <int K, int NT, int SL, int NW = 4> int launch_wgrad_sl(PatchWgradArgs 
         if (parts_out) *parts_out = 1;
         if (mte_memset_async(a.dw, 0, sizeof(float) * (size_t)a.N * K * K * a.Cin_p, st) != hipSuccess) return MTE_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT, SL, NW>), dim3((unsigned)groups, nslices), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_patch_wgrad_kernel<K, NT, SL, NW, NH, THW>), dim3((unsigned)groups, nslices), dim3(NW * 64), lds, st, a);
     return mte_check_launch();
 }
 template <int K, int NT> int launch_wgrad(const PatchWgradArgs& a, hipStream_t st, int parts_cap, int* parts_out) {
@@ -426,6 +437,10 @@ template <int NT> int dispatch_wgrad(const PatchWgradArgs& a, int K, hipStream_t
     return MTE_ERR_UNSUPPORTED;
 }
 
+// weight gradient only: 65..128 output channels, 3x3, at least one 64-channel slice pair (the wide variant of conv_patch_wgrad_kernel)
+inline bool patch_wgrad_wide_ok(int W, int Cin_p, int N, int KH, int KW) {
+    return g_patch_wgrad_wide && W % TW == 0 && Cin_p % 8 == 0 && Cin_p >= 64 && N % 8 == 0 && N > 64 && N <= 128 && KH == 3 && KW == 3;
+}
 inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
     if (KH == 7 && N > 32) return false;             // 13 taps x 2 tiles of accumulators per wave would spill in wgrad
     return W % TW == 0 && Cin_p % 8 == 0 && N % 8 == 0 && N <= 64 && KH == KW && (KH == 1 || KH == 3 || KH == 5 || KH == 7);
@@ -434,7 +449,7 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 }  // namespace
 
 #ifdef MTE_DEV
-extern "C" int mtei_set_patch_tall(int v) { if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
+extern "C" int mtei_set_patch_tall(int v) { if (v >= 300 && v < 310) { g_patch_wgrad_wide = v - 300; return MTE_OK; } if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
 #endif
 
 extern "C" {
@@ -442,6 +457,11 @@ extern "C" {
 // 1 if the LDS-patch kernels cover this conv shape (bf16, C_out <= 64, W % 32 == 0, k in {1,3,5,7}), else 0.
 int mte_conv2d_patch_supported(int W, int Cin_p, int N, int KH, int KW, int dtype) {
     return (dtype == MTE_DT_BF16 && patch_shape_ok(W, Cin_p, N, KH, KW)) ? 1 : 0;
+}
+
+// 1 if mte_conv2d_patch_wgrad covers this shape: everything mte_conv2d_patch_supported covers, plus 3x3 layers with 65..128 output channels
+int mte_conv2d_patch_wgrad_supported(int W, int Cin_p, int N, int KH, int KW, int dtype) {
+    return (dtype == MTE_DT_BF16 && (patch_shape_ok(W, Cin_p, N, KH, KW) || patch_wgrad_wide_ok(W, Cin_p, N, KH, KW))) ? 1 : 0;
 }
 
 // elements (bf16) of the fragment-block weight pack for mte_conv2d_patch_fwd
@@ -472,9 +492,13 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
 int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!x || !dy || !dw_stage || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
+    if (!x || !dy || !dw_stage) return MTE_ERR_ARG;
     PatchWgradArgs a{(const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, dw_stage, B, H, W, Cin_p, N, 1};
     if (parts_out) *parts_out = 1;
+    if (!patch_shape_ok(W, Cin_p, N, KH, KW)) {
+        if (!patch_wgrad_wide_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
+        return launch_wgrad_sl<3, 2, 2, 8, 2, 4>(a, stream, stage_parts, parts_out);
+    }
     return N <= 32 ? dispatch_wgrad<1>(a, KH, stream, stage_parts, parts_out) : dispatch_wgrad<2>(a, KH, stream, stage_parts, parts_out);
 }
 

@@ -606,7 +606,7 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     # generic kernel's <= 32 splits -- the patch kernel's 128..512 workgroup groups stay on atomics: summing that many parts
     # in the unpack pass measured 7 % slower)
     per = cout * kh * kw * Cp
-    patch = _patch_ok(W, Cp, cout, kh, kw, x.dtype)
+    patch = _cfg["patch_kernels"] and x.dtype == torch.bfloat16 and lib.mte_conv2d_patch_wgrad_supported(W, Cp, cout, kh, kw, DT_BF16) == 1
     # the LDS-patch kernel runs 128..512 workgroups per layer: one slab each (plain stores), combined by a two-level reduction
     # (mte_unpack_conv_wgrad) -- its slabs are 70-210 KB, so even 512 of them stay near 100 MB
     cap = max(1, min(512, (192 << 20) // (4 * per))) if patch and _cfg["patch_wgrad_slabs"] else max(1, min(32, (96 << 20) // (4 * per)))
