@@ -89,6 +89,18 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
 int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
 
+/* ---- stem convolution: exactly 8 input channels (the zero-padded rgb image), C_out <= 32, k in {3,5,7}, W % 32 == 0, bf16
+ * (encoder.pre_calc = Conv2D(3, 32, 5, 1): networks/depth/PackNetSAN01.py:27, layers01.py:29-31).  With 8 channels a pixel is one
+ * 16-byte chunk, so the reduction runs over (tap, channel) and an MFMA covers two taps: a quarter of the MFMA work the 32-channel
+ * slices of the LDS-patch kernels spend on it.  wf = the GENERIC forward pack [N][taps][8] of mte_pack_conv_weights (no special pack);
+ * _wgrad fills dw_stage like mte_conv2d_patch_wgrad (one slab per workgroup, *parts_out slabs, summed by mte_unpack_conv_wgrad).
+ * The image needs no data gradient. */
+int mte_conv2d_stem_supported(int W, int Cin_p, int N, int KH, int KW, int dtype);
+int mte_conv2d_stem_fwd(const void* x, long ldx, const void* wf, const float* bias, void* y, long ldy,
+                        int B, int H, int W, int N, int KH, int KW, mte_stream_t stream);
+int mte_conv2d_stem_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
+                          int B, int H, int W, int N, int KH, int KW, mte_stream_t stream);
+
 /* ---- GroupNorm(16, C) + ELU, optionally over y1 + scale2[b,c]*y2 (residual tail with Dropout2d)
  *      (layers01.py:32-38 Conv2D; layers01.py:62-73 ResidualConv)
  * A statistics buffer is mte_gn_stats_elems(B) doubles: [B][16][2] (sum, sum of squares) -- what mte_gn_elu_fwd / _bwd read --

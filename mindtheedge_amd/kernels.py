@@ -506,6 +506,12 @@ def use_patch_kernels(flag):
     _cfg["patch_kernels"] = bool(flag)
 
 
+def _stem_ok(W, cin_p, n, kh, kw, dtype):
+    """the 8-input-channel stem kernels (csrc/conv_stem.hip) cover this shape"""
+    return (_cfg["patch_kernels"] and cin_p == 8 and dtype == torch.bfloat16
+            and lib.mte_conv2d_stem_supported(W, cin_p, n, kh, kw, DT_BF16) == 1)
+
+
 def _patch_ok(W, cin_p, n, kh, kw, dtype):
     return _cfg["patch_kernels"] and dtype == torch.bfloat16 and lib.mte_conv2d_patch_supported(W, cin_p, n, kh, kw, DT_BF16) == 1
 
@@ -517,6 +523,9 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumul
         out = new_act(B, cout, H, W, x.dtype, x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(out)
+    if not accumulate and _stem_ok(W, Cp, cout, kh, kw, x.dtype):
+        lib.mte_conv2d_stem_fwd(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, B, H, W, cout, kh, kw, _stream())
+        return out
     if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
         lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw,
                                  1 if accumulate else 0, _stream())
@@ -612,7 +621,9 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     cap = max(1, min(512, (192 << 20) // (4 * per))) if patch and _cfg["patch_wgrad_slabs"] else max(1, min(32, (96 << 20) // (4 * per)))
     stage = torch.empty((cap, cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
     parts = ctypes.c_int(1)
-    if patch:
+    if _stem_ok(W, Cp, cout, kh, kw, x.dtype):
+        lib.mte_conv2d_stem_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, cout, kh, kw, st)
+    elif patch:
         lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, Cp, cout, kh, kw, st)
     else:
         lib.mte_conv2d_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, Cp, cout, kh, kw, _dt(x), st)

@@ -24,6 +24,8 @@ SHAPES = [  # cin, cout, k, B, H, W
     (32, 64, 1, 2, 8, 64), (97, 64, 3, 1, 24, 32), (1024, 64, 3, 1, 8, 32), (64, 32, 3, 2, 10, 32), (16, 16, 3, 1, 8, 32),
     (32, 64, 3, 1, 7, 64),
     # round 3: 65..128 output channels, 3x3 -- the wide LDS-patch WEIGHT gradient (forward / data gradient stay on the implicit GEMM)
+    # round 3: the 8-input-channel stem kernels (csrc/conv_stem.hip): reduction over (tap, channel), ragged heights, k = 3 / 5 / 7
+    (3, 32, 5, 1, 37, 96), (3, 16, 3, 2, 9, 32), (3, 32, 7, 1, 16, 32), (8, 24, 5, 2, 16, 64),
     (128, 128, 3, 2, 16, 64), (200, 128, 3, 1, 12, 32), (64, 128, 3, 2, 8, 64), (256, 128, 3, 1, 13, 32), (72, 96, 3, 2, 9, 32), (64, 72, 3, 1, 6, 96),
 ]
 
