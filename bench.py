@@ -56,7 +56,8 @@ class ConvTimer:
         self.K, self.records, self.enabled = K, [], False
         lib = K.lib
         self._orig = {}
-        for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad"):
+        for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad",
+                     "mte_conv2d_stem_fwd", "mte_conv2d_stem_wgrad"):
             self._orig[name] = getattr(lib, name)
         self.hbm_records = []           # (name, e0, e1, algorithmic bytes) of the GroupNorm+ELU passes (HBM-bound family)
         for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd"):
@@ -118,6 +119,10 @@ class ConvTimer:
                         shp = args[7:14]           # (x, ldx, w, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, ...)
                     elif name == "mte_conv2d_patch_fwd":
                         shp = args[6:13]           # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, KH, KW, stream)
+                    elif name == "mte_conv2d_stem_fwd":
+                        shp = args[6:9] + (8,) + args[9:12]      # (x, ldx, wf, bias, y, ldy, B, H, W, N, KH, KW, stream): 8 input channels
+                    elif name == "mte_conv2d_stem_wgrad":
+                        shp = args[7:10] + (8,) + args[10:13]    # (x, ldx, dy, lddy, dw, stage_parts, parts_out, B, H, W, N, KH, KW, stream)
                     else:
                         shp = args[7:14]           # (x, ldx, dy, lddy, dw, stage_parts, parts_out, B, H, W, Cin_p, N, KH, KW, ...)
                     B, H, W, Cin_p, N, KH, KW = shp
@@ -468,7 +473,7 @@ def main():
                 alg = conv2d_flops_per_image(H, W) * B * passes * ksteps          # algorithmic conv2d FLOPs of the timed launches
                 ach = alg / tot_t / 1e12
                 res["roofline"] = {"bound": "mfma", "kernel": "conv2d MFMA family (mte_conv2d_igemm fwd+dgrad, mte_conv2d_wgrad, "
-                                                              "mte_conv2d_patch_fwd, mte_conv2d_patch_wgrad)",
+                                                              "mte_conv2d_patch_fwd, mte_conv2d_patch_wgrad, mte_conv2d_stem_fwd, mte_conv2d_stem_wgrad)",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": pmc_traffic_per_launch(args, B, H, W),
                                    "launches_per_step": n / ksteps, "avg_launch_ms": tot_t / n * 1e3,

@@ -39,6 +39,34 @@ def test_network_outputs(dtype, tol):
         K.set_compute_dtype("bf16")
 
 
+def _check_gradients(dtype, grads, g):
+    """the fixture's full gradient tensors and the sum of squares of all 216 against the reference's.
+    fp32 mode: element-wise, 5e-3 of the tensor's maximum; sums of squares to 1 %.  bf16 mode (round 3; was a 25 % max-norm bound):
+    direction and size of every full tensor -- cosine >= 0.99, norm within 3 %, worst element within 15 % of the tensor's maximum --
+    and the norm of every one of the 216 tensors within [0.85, 1.12] of the reference's (measured on MI355X with the bit-reproducible
+    forward: cosine >= 0.9965, norm ratios 0.977 .. 1.012, worst element 9.5 %, per-tensor norm ratios 0.911 .. 1.054)."""
+    names = [str(n) for n in g["grad_names"]]
+    if dtype == "fp32":
+        for k, v in g.items():
+            if k.startswith("grad."):
+                assert rel_err(grads[k[5:]].grad.cpu(), v) < 5e-3, k
+        bad = [(n, ss) for n, ss in zip(names, g["grad_sumsq"].tolist())
+               if abs(float((grads[n].grad.double() ** 2).sum()) - ss) > 1e-2 * max(ss, 1e-10)]
+        assert not bad, bad[:8]
+        return
+    for k, v in g.items():
+        if k.startswith("grad."):
+            a, b = grads[k[5:]].grad.cpu().double().flatten(), v.double().flatten()
+            cos, ratio = float((a * b).sum() / (a.norm() * b.norm())), float(a.norm() / b.norm())
+            assert cos >= 0.99 and abs(ratio - 1.0) <= 0.03 and rel_err(grads[k[5:]].grad.cpu(), v) <= 0.15, (k, cos, ratio)
+    bad = []
+    for n, ss in zip(names, g["grad_sumsq"].tolist()):
+        r = (float((grads[n].grad.double() ** 2).sum()) / max(ss, 1e-30)) ** 0.5
+        if not 0.85 <= r <= 1.12:
+            bad.append((n, r))
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
 def test_model_loss_and_gradients(dtype, tol):
     from mindtheedge_amd import kernels as K
@@ -60,17 +88,7 @@ def test_model_loss_and_gradients(dtype, tol):
         assert rel_err(out["metrics"]["supervised_loss"].cpu(), g["supervised_loss"]) < tol
         out["loss"].sum().backward()
         grads = dict(net.named_parameters())
-        gtol = 5e-3 if dtype == "fp32" else 0.25
-        for k, v in g.items():
-            if k.startswith("grad."):
-                assert rel_err(grads[k[5:]].grad.cpu(), v) < gtol, k
-        names = [str(n) for n in g["grad_names"]]
-        bad = []
-        for n, ss in zip(names, g["grad_sumsq"].tolist()):
-            got = float((grads[n].grad.double() ** 2).sum())
-            if abs(got - ss) > 2 * gtol * max(ss, 1e-10):
-                bad.append((n, got, ss))
-        assert not bad, bad[:8]
+        _check_gradients(dtype, grads, g)
         # H1: forced whole-batch flip gives the reference's flipped-run loss
         gf = load_golden("model_semisup_64x128_flip")
         model.flip_lr_prob = 1.0
@@ -196,16 +214,7 @@ def test_dee_rgb_only_training_step_matches_reference(dtype, tol):
         assert rel_err(out["inv_depths"][3].float().cpu(), g["prob3"]) < (tol if dtype == "fp32" else 5e-2)
         out["loss"].sum().backward()
         grads = dict(net.named_parameters())
-        gtol = 5e-3 if dtype == "fp32" else 0.25
-        for k, v in g.items():
-            if k.startswith("grad."):
-                assert rel_err(grads[k[5:]].grad.cpu(), v) < gtol, k
-        bad = []
-        for n, ss in zip([str(n) for n in g["grad_names"]], g["grad_sumsq"].tolist()):
-            got = float((grads[n].grad.double() ** 2).sum())
-            if abs(got - ss) > 2 * gtol * max(ss, 1e-10):
-                bad.append((n, got, ss))
-        assert not bad, bad[:8]
+        _check_gradients(dtype, grads, g)
         with pytest.raises(NotImplementedError):
             model({**batch, "input_depth": batch["edge"]})
     finally:

@@ -135,9 +135,15 @@ def test_training_step_fp32_mode_matches_oracle_at_384x1280(oracle_step):
 
 
 # bf16 benchmark mode: activations and weights are STORED in bf16 (8 significant bits, rounding 2^-9 = 2e-3 per
-# element) through ~60 stacked conv + GroupNorm layers.  Measured at 384x1280 (printed by the tests, GPUTEST log):
+# element) through ~60 stacked conv + GroupNorm layers.  Round 3 took the error apart (profiles/r03_bf16_error_simulation.txt: the
+# CPU oracle with bf16 rounding injected at the HIP path's storage sites reproduces it -- max 2.5e-2, mean 3.3e-3 -- and shows that
+# rounding ONLY the input image already costs max 8.9e-3 / mean 1.1e-3, any single storage class ~1.7e-3 mean, and fp32 storage for
+# the last 1..10 decoder layers buys < 12 %; profiles/r03_bf16_error_by_layer.txt: per-layer HIP-vs-oracle error, 3.8e-3 rms after the
+# stem, 2.4e-2 at the bottleneck, 3.7e-3 after the full-resolution head).  The forward pass is bit-reproducible since round 3, so the
+# measured values below do not move from run to run:
 #   * loss scalars (sums over 650k pixels average the rounding noise out): 2e-5 -- inside the north star's 1e-3;
-#   * inverse depth per pixel: max 2-3.5e-2, mean 2-3e-3 (random walk of ~120 roundings of 2^-9);
+#   * inverse depth per pixel: max 1.9e-2 (full resolution) .. 3.1e-2 (coarse scales), mean 3.0e-3 .. 5.0e-3; bound 4e-2 = 1.6x the
+#     simulated storage-rounding maximum (was 6e-2);
 #   * gradients of a SMOOTH functional of the outputs (probe loss sum_s <inv_s, R_s>): a few percent rms per tensor;
 #   * gradients of the depth-edge loss at this (random-weight) operating point are ILL-CONDITIONED, not inaccurate: the
 #     predicted depth is nearly flat, the loss differentiates |Sobel(depth)| whose sign then follows the per-pixel
@@ -145,8 +151,8 @@ def test_training_step_fp32_mode_matches_oracle_at_384x1280(oracle_step):
 #     autocast -- give per-element gradients that differ by O(1) while the loss agrees to 2e-5.  For that loss the test
 #     bounds the direction (cosine) and the size of the whole gradient; the arithmetic of the backward kernels at full
 #     size is pinned by the smooth probe and, exactly, by the fp32-mode test above (same kernel templates).
-BF16_INV_BOUND = 6e-2
-BF16_INV_MEAN_BOUND = 6e-3
+BF16_INV_BOUND = 4e-2
+BF16_INV_MEAN_BOUND = 6e-3       # (measured 3.0e-3 at full resolution .. 5.0e-3 at 48x160: the coarse heads sit deeper in the decoder)
 BF16_PROBE_GRAD_RMS_BOUND = 0.12
 
 
