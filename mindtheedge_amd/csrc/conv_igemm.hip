@@ -51,7 +51,35 @@ template <> struct Mma<float> {
     }
 };
 
-__device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 64 + ((kc ^ ((row >> 2) & 3)) << 4); }
+// MFMA shape of the forward / data-gradient kernel.  1 (round 3): v_mfma_f32_16x16x32_bf16 -- the same FLOPs per issue cycle as
+// 32x32x16, but MFMA-dense loops on random data hold a higher clock with it (MI355X_MICROARCH.md, DVFS item 7: 1.12-1.15x the FLOP/s
+// at equal cycles per FLOP).  One K-step (64 B per row) is exactly one 16x16x32 reduction: lane (r16 = lane & 15, q = lane >> 4) reads
+// the 16-byte chunk q of tile row r16 -- the same LDS bytes per MFMA FLOP as before.  0 = the 32x32x16 form (same-box A/B builds).
+#ifndef MTE_IGEMM_MFMA16
+#define MTE_IGEMM_MFMA16 1
+#endif
+#if MTE_IGEMM_MFMA16
+// chunk c of row r sits at slot c ^ ((r >> 1) & 3): conflict-free for the 16-row fragment reads (every ds_read_b128 lane group
+// {0-3, 12-15, 20-27}, ... meets 16 distinct 16-byte slots; the (r >> 2) form of the 32-row reads is 2-way conflicted here)
+__device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 3; }
+#else
+__device__ __forceinline__ int lds_swz(int row) { return (row >> 2) & 3; }
+#endif
+__device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 64 + ((kc ^ lds_swz(row)) << 4); }
+
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<float> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i]), __uint_as_float(b[i]), c, 0, 0, 0);
+    }
+};
 
 __device__ u32x4_t g_zero16 = {0u, 0u, 0u, 0u};      // source of zero chunks for the LDS-DMA loader (image border / K tail)
 
@@ -112,7 +140,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
     // ---- per-thread loader state: all chunks of a thread share the K-chunk index kc.  Register staging: kc = tid&3 and
     // the swizzle is applied when writing LDS.  DMA: LDS slot (tid&3) of row r must hold source chunk (tid&3) ^ swz(r),
     // and swz(r) = (r>>2)&3 = (tid>>4)&3 for every row this thread touches.
-    const int kc = DMA ? ((tid & 3) ^ ((tid >> 4) & 3)) : (tid & 3);
+    // (row = (tid >> 2) + i * NTHR / 4 and NTHR / 16 is a multiple of 4, so lds_swz(row) is the same for every row this thread fills)
+    const int kc = DMA ? ((tid & 3) ^ lds_swz(tid >> 2)) : (tid & 3);
     int c, ty, tx;                                     // chunk-in-tap, tap row/col of global chunk q = 4*s + kc
     {
         const int q0 = 4 * s_begin + kc, tap0 = q0 / cpt;
@@ -244,6 +273,36 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
         }
     };
 
+    const int wm = wave / WN, wn = wave % WN;
+#if MTE_IGEMM_MFMA16
+    static_assert(ABL == 0, "the ablation arms exist for the 32x32x16 form only");
+    // a wave's (TM*32) x (TN*32) sub-tile as 2TM x 2TN blocks of 16 x 16: D[row = 4 * (lane >> 4) + e][col = lane & 15]
+    constexpr int AM = TM * 2, AN = TN * 2;
+    f32x4_t acc[AM][AN];
+#pragma unroll
+    for (int i = 0; i < AM; ++i)
+#pragma unroll
+        for (int j = 0; j < AN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, q16 = lane >> 4;
+    auto compute = [&](int slot) {
+        const char* pA = sA + slot * BM * 64;
+        const char* pB = sB + slot * BN * 64;
+        u32x4_t fa[AM], fb[AN];
+#pragma unroll
+        for (int i = 0; i < AM; ++i) fa[i] = *(const u32x4_t*)(pA + lds_chunk_off((wm * AM + i) * 16 + r16, q16));
+#pragma unroll
+        for (int j = 0; j < AN; ++j) fb[j] = *(const u32x4_t*)(pB + lds_chunk_off((wn * AN + j) * 16 + r16, q16));
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int j = 0; j < AN; ++j) Mma16<T>::run(fa[i], fb[j], acc[i][j]);
+    };
+    // element e of block (i, j): tile row / column
+    auto acc_row = [&](int i, int e) { return (wm * AM + i) * 16 + 4 * q16 + e; };
+    auto acc_col = [&](int j) { return (wn * AN + j) * 16 + r16; };
+    constexpr int AE = 4;
+#else
+    constexpr int AM = TM, AN = TN;
     f32x16_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -252,7 +311,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
     auto compute = [&](int slot) {
@@ -285,6 +343,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             }
         }
     };
+    auto acc_row = [&](int i, int e) { return (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h; };
+    auto acc_col = [&](int j) { return (wn * TN + j) * 32 + r; };
+    constexpr int AE = 16;
+#endif
     if constexpr (DMA) {
         // ST-slot LDS ring filled by LDS-DMA ST-1 K-steps ahead.  vmcnt is COUNTED (the younger stages stay in
         // flight across the barrier): the only wait per K-step is for the stage about to be consumed, so HBM/L2
@@ -339,17 +401,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             static_assert(BM * BN * ES <= ST * (BM + BN) * 64, "output tile must fit the ring");
             __syncthreads();                              // every wave is done reading the ring
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = (wn * TN + j) * 32 + r;
+            for (int j = 0; j < AN; ++j) {
+                const int col = acc_col(j);
                 const int n = n0 + col;
                 const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < AM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        Elem<T>::st((T*)(smem + (row * BN + col) * ES), acc[i][j][e] + bv);
-                    }
+                    for (int e = 0; e < AE; ++e)
+                        Elem<T>::st((T*)(smem + (acc_row(i, e) * BN + col) * ES), acc[i][j][e] + bv);
             }
             __syncthreads();
             constexpr int CPR = BN / PER16;                // 16-B chunks per tile row
@@ -378,15 +438,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 
     // ---- epilogue: D[row][col]: col = lane&31 (channel n), row = (e&3) + 8*(e>>2) + 4*h (pixel m)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + r;
+    for (int j = 0; j < AN; ++j) {
+        const int n = n0 + acc_col(j);
         if (n >= a.N) continue;
         const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < AM; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            for (int e = 0; e < AE; ++e) {
+                const long m = m0 + acc_row(i, e);
                 if (m < a.M) {
                     const float v = acc[i][j][e] + bv;
                     if (a.splits > 1) a.ws[((long)split * a.M + m) * a.N + n] = acc[i][j][e];
@@ -442,7 +502,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
             const long es = (long)sizeof(T);
             const bool fast = g_igemm_dma == 1 && a.Cin_p % (4 * Elem<T>::PER16) == 0 &&
                               ((a.M - 1) * a.ldx + a.Cin_p) * es < 0x7ff00000L && (long)a.N * a.KH * a.KW * a.Cin_p * es < 0x7ff00000L;
-#ifdef MTE_DEV
+#if defined(MTE_DEV) && !MTE_IGEMM_MFMA16
             if constexpr (sizeof(T) == 2 && ((BM == 256 && BN == 128) || (BM == 128 && BN == 128) || (BM == 256 && BN == 256))) {
                 if (fast && g_igemm_ablate) {
                     const dim3 g((unsigned)(tiles * a.splits)), b(NTHR);
