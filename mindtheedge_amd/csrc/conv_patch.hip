@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int NCH = (PCH + 255) / 256;
     constexpr int PBYTES = PH * PW * 64;
     constexpr int OBYTES = TH * TW * NT * 64;                      // output staging (bf16 [256 px][32*NT])
-    constexpr int NBUF = (TALL && K > 3) ? 1 : 2;                  // patch buffers (tall 5x5 / 7x7 tiles: single-slice layers only)
+    // patch buffers (tall 5x5 / 7x7 tiles: single-slice layers only).  Round 3 tried ONE buffer for the tall 3x3 tiles too (39 KB instead
+    // of 78 KB of LDS per workgroup): the kernel holds 196-224 VGPRs, so two workgroups per CU is all it gets either way, and forcing
+    // three or four waves per SIMD spills (72 -> 32 at 384x1280: 400 -> 694 us)
+    constexpr int NBUF = (TALL && K > 3) ? 1 : 2;
     constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES) ? NBUF * PBYTES : OBYTES);
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -414,6 +417,11 @@ template <int K, int NT> int launch_wgrad(const PatchWgradArgs& a, hipStream_t s
     // eight waves (two per SIMD on the one workgroup a CU holds) where a wave still gets enough accumulator units: two output
     // tiles per unit, or >= 32 units.  Same-box A/B per launch: 7x7 32->32 @384x1280 0.510 -> 0.388 ms, 3x3 64->64 @192x640
     // 0.146 -> 0.108, 5x5 256->64 @96x320 0.272 -> 0.205; the one-tile launches with 18 / 25 units lose 14-20 % and stay on four.
+    if constexpr (K == 3 && NT == 1) {
+        // 65..96 input channels (iconv1: the 72-channel decoder concat): all three 32-channel slices in ONE workgroup -- the 192-byte
+        // pixel rows of the two-slice layout are exactly full, dy is read once instead of once per slice pair (0.40 -> 0.29 ms)
+        if (a.Cin_p > 64 && a.Cin_p <= 96 && g_patch_wgrad_8w) return launch_wgrad_sl<K, NT, 3, 8>(a, st, parts_cap, parts_out);
+    }
     if constexpr (K <= 3 || (K == 5 && NT == 1)) {
         if (a.Cin_p > 32) {
             if constexpr (K * K * 2 >= 16 && (NT == 2 || K * K * 2 >= 32)) {

@@ -261,7 +261,7 @@ int mte_conv2d_stem_wgrad(const void* x, long ldx, const void* dy, long lddy, fl
     StemArgs a{}; a.x = (const bf16_t*)x; a.ldx = ldx; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.dw = dw_stage;
     a.B = B; a.H = H; a.W = W; a.N = N;
     const long ntiles = (long)(W / TW) * ((H + 7) / 8) * B;
-    long groups = stage_parts > 1 ? (stage_parts < 1024 ? stage_parts : 1024) : 1024;      // one slab per workgroup where the stage has room
+    long groups = stage_parts > 1 ? (stage_parts < 2048 ? stage_parts : 2048) : 1024;      // one slab per workgroup where the stage has room
     if (groups > ntiles) groups = ntiles;
     a.groups = (int)groups;
     const long per = (long)N * KH * KW * 8;

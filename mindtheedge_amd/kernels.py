@@ -619,9 +619,12 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     # the LDS-patch kernel runs 128..512 workgroups per layer: one slab each (plain stores), combined by a two-level reduction
     # (mte_unpack_conv_wgrad) -- its slabs are 70-210 KB, so even 512 of them stay near 100 MB
     cap = max(1, min(512, (192 << 20) // (4 * per))) if patch and _cfg["patch_wgrad_slabs"] else max(1, min(32, (96 << 20) // (4 * per)))
+    stem = _stem_ok(W, Cp, cout, kh, kw, x.dtype)
+    if stem:
+        cap = 2048                       # 25 KB slabs: eight 256-thread workgroups per CU keep this bandwidth-bound stream busy
     stage = torch.empty((cap, cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
     parts = ctypes.c_int(1)
-    if _stem_ok(W, Cp, cout, kh, kw, x.dtype):
+    if stem:
         lib.mte_conv2d_stem_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, cout, kh, kw, st)
     elif patch:
         lib.mte_conv2d_patch_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, Cp, cout, kh, kw, st)
