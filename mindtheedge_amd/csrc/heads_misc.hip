@@ -460,10 +460,11 @@ int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias,
     if (!x || !w || !bias || !out || !head_ok(C)) return MTE_ERR_ARG;
     HeadArgs a{}; a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.C = C;
     a.inv_min_depth = 1.f / min_depth; a.npix = (long)B * H * W;
-    long grid = head_strips(B, H, W, C);
-    static int res_b = 0, res_f = 0;
-    const long res = dtype == MTE_DT_BF16 ? head_resident(invdepth_fwd_kernel<bf16_t>, 0, &res_b) : head_resident(invdepth_fwd_kernel<float>, 0, &res_f);
-    if (grid > res) grid = res;
+    // one workgroup per strip: workgroups are dispatched in order, so the ones running together walk down horizontally ADJACENT strips and
+    // DRAM sees whole image rows requested at once (balanced strip ranges over the resident workgroups -- kept for the weight gradient, whose
+    // per-workgroup record must stay small in number -- measured 6 % slower here: 118 vs 111 us on the full-resolution head)
+    const long grid = head_strips(B, H, W, C);
+    if (grid > 0x7fffffffL) return MTE_ERR_UNSUPPORTED;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_fwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(invdepth_fwd_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     return mte_check_launch();
@@ -477,10 +478,8 @@ int mte_invdepth_bwd_data(const float* w, const float* inv_out, const float* dou
     const long npix = (long)B * H * W;
     hipLaunchKernelGGL(invdepth_dlogit_kernel, dim3(stream_grid(npix)), dim3(256), 0, stream, dout, inv_out, dlogit, npix, 1.f / min_depth);
     HeadArgs a{}; a.w = w; a.dlogit = dlogit; a.dx = dx; a.lddx = lddx; a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
-    long grid = head_strips(B, H, W, C);
-    static int res_b = 0, res_f = 0;
-    const long res = dtype == MTE_DT_BF16 ? head_resident(invdepth_bwd_data_kernel<bf16_t>, 0, &res_b) : head_resident(invdepth_bwd_data_kernel<float>, 0, &res_f);
-    if (grid > res) grid = res;
+    const long grid = head_strips(B, H, W, C);
+    if (grid > 0x7fffffffL) return MTE_ERR_UNSUPPORTED;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_data_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(invdepth_bwd_data_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     return mte_check_launch();

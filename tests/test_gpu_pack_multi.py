@@ -78,7 +78,8 @@ def test_network_step_uses_the_multi_tensor_pack():
             out["loss"].backward()
             opt.step()
             losses.append(float(out["loss"].sum()))
-        n_ev = sum(1 for r in K.WeightPack._live if r() is not None and r()._event is not None)
+        packs = [m.pack for m in net.modules() if isinstance(getattr(m, "pack", None), K.WeightPack)]     # (this network's packs only)
+        n_ev = sum(1 for pk in packs if pk._event is not None)
         torch.cuda.synchronize()
         return losses, n_ev
 

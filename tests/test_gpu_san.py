@@ -317,3 +317,65 @@ def test_edge_estimation_lidar_model_training_step():
     grads = [p.grad for p in wrap.depth_net.parameters()]
     assert all(g is not None and torch.isfinite(g).all() for g in grads)
     assert all(float(p.grad.abs().max()) > 0 for p in wrap.depth_net.mconvs.parameters())
+
+
+def test_two_pass_gradients_with_the_flat_gradient_sink_equal_plain_autograd():
+    """round-2 advisor finding: the RGB and the RGB+LiDAR pass share the 216 encoder / decoder tensors, and the flat gradient sink
+    STORES a parameter's gradient (one store per zero_grad) -- the second pass used to overwrite the first.  With the sink suspended
+    for shared-parameter graphs the gradients accumulated into the flat buffer must equal those of plain autograd accumulation, twice in
+    a row (zero_grad re-arms the sink), and a bucket's all-reduce trigger must fire once per parameter, after its LAST use
+    (reference PackNetSAN01.py:324-342: one backward through both passes)."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
+    from mindtheedge_amd.trainers.data_parallel import FlatParameters
+    K.set_compute_dtype("fp32")
+    K.set_grad_sink(None)
+    try:
+        rgb = torch.rand(2, 3, 64, 128, generator=torch.Generator().manual_seed(1)).cuda()
+        d = _lidar(2, 64, 128, seed=6, density=0.1).cuda()
+
+        def build():
+            torch.manual_seed(0)
+            net = PackNetSAN01(dropout=None, version="1A", with_san=True).cuda().train()
+            _randomise(net.mconvs, seed=9)
+            return net
+
+        def loss_of(net):
+            out = net(rgb, input_depth=d)
+            return out["depth_loss"] + sum(i.float().mean() for i in out["inv_depths"]) + 2.0 * sum(i.float().mean() for i in out["inv_depths_rgbd"])
+
+        ref_net = build()
+        loss_of(ref_net).backward()
+        ref = {n: p.grad.detach().clone() for n, p in ref_net.named_parameters()}
+        net = build()
+        flat = FlatParameters(net.parameters())
+        assert flat.sink is not None
+        fired = []
+        flat.sink.on_ready = lambda p: fired.append(id(p))
+        hooks = [p.register_post_accumulate_grad_hook(lambda p: fired.append(id(p))) for p in net.parameters()]
+        for rep in range(2):
+            flat.zero_grad()
+            fired.clear()
+            loss_of(net).backward()
+            K.join_side_stream()
+            torch.cuda.synchronize()
+            assert flat.sink.suspended                                   # the two-pass forward asked for autograd accumulation
+            worst = 0.0
+            for n, p in net.named_parameters():
+                e = float((p.grad - ref[n]).abs().max() / ref[n].abs().max().clamp(min=1e-30))
+                worst = max(worst, e)
+                assert e < 2e-4, (rep, n, e)                             # fp32 mode: atomics-order noise only
+            assert len(fired) == len(set(fired)) == sum(1 for _ in net.parameters())     # once per parameter
+        for h in hooks:
+            h.remove()
+        # a single-pass step afterwards goes back to in-place stores (zero_grad re-arms the sink)
+        flat.zero_grad()
+        assert not flat.sink.suspended
+        out = net(rgb)
+        sum(i.float().mean() for i in out["inv_depths"]).backward()
+        K.join_side_stream()
+        torch.cuda.synchronize()
+        assert not flat.sink.suspended and len(flat.sink.written) >= 200
+    finally:
+        K.set_grad_sink(None)
+        K.set_compute_dtype("bf16")

@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from mindtheedge_amd import kernels as K  # noqa: E402
 
+for kv in filter(None, os.environ.get("MTE_DEBUG_KNOBS", "").split(",")):       # e.g. MTE_USE_DEV_LIB=1 MTE_DEBUG_KNOBS=11=0
+    K.lib.mte_debug_set(*(int(v) for v in kv.split("=")))
 B = 8
 shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(72, 32, 3, 384, 1280, 96), (3, 32, 5, 384, 1280), (128, 128, 3, 96, 320)]
 

@@ -9,7 +9,9 @@ from collections import defaultdict
 def family(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     for key, fam in (("conv_igemm", "conv igemm (fwd+dgrad)"), ("splitk_finish", "conv igemm (fwd+dgrad)"), ("conv_wgrad", "conv wgrad generic"),
-                     ("conv_patch_fwd", "conv patch fwd+dgrad"), ("conv_patch_wgrad", "conv patch wgrad"), ("gn_", "GroupNorm+ELU"),
+                     ("conv_patch_fwd", "conv patch fwd+dgrad"), ("conv_patch_wgrad", "conv patch wgrad"), ("conv_stem", "conv stem fwd+wgrad"),
+                     ("pack_multi", "weight packs"), ("pack_weights", "weight packs"), ("unpack_wgrad", "wgrad unpack/reduce"), ("reduce_parts", "wgrad unpack/reduce"),
+                     ("gn_", "GroupNorm+ELU"),
                      ("pack3d", "conv3d pack/unpack"), ("unpack3d", "conv3d pack/unpack"), ("invdepth", "invdepth head"),
                      ("adam", "adam"), ("fillBuffer", "memset"), ("copyBuffer", "memcpy")):
         if key in n:
