@@ -378,8 +378,10 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
         }
     }
     if constexpr (HASDB) {
+        // with a second input the bias gradient asked for is that of the SECOND input's producer (the 1x1 shortcut conv of a residual
+        // block): sum of d2 = scale2[b][c] * d1 over the pixels -- the factor is constant per (sample, channel), so it multiplies the sum
 #pragma unroll
-        for (int i = 0; i < P; ++i) atomicAdd(&s_db[ch0 + i], db[i]);
+        for (int i = 0; i < P; ++i) atomicAdd(&s_db[ch0 + i], HAS2 ? db[i] * sc[i] : db[i]);
         __syncthreads();
         for (int i = threadIdx.x; i < a.C; i += 256) atomicAdd(&a.dbias[i], s_db[i]);
     }
@@ -780,7 +782,8 @@ int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const flo
 }
 
 // Backward of z = ELU(GN(y1 + scale2*y2)).  red[B][C][2] is scratch (zeroed here).  Writes d1 (grad of y1),
-// optionally d2 (grad of y2 = scale2 * d1), dgamma/dbeta [C] (overwritten) and, if non-null, dbias [C] += column sums of d1.
+// optionally d2 (grad of y2 = scale2 * d1), dgamma/dbeta [C] (overwritten) and, if non-null, dbias [C] += column sums of d1 -- or, when y2 is
+// given, of d2 (the bias gradient of the conv that produced y2: the residual block's 1x1 shortcut).
 int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
                    const double* stats, const float* gamma, const float* beta, float* red,
                    void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,

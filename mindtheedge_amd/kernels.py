@@ -425,9 +425,7 @@ def prefetch_weight_packs():
     sitting in front of each layer's convolution.  All of them -- forward, data-gradient and LDS-patch fragment packs of ~100
     layers -- are rebuilt in place by three launches of ONE multi-tensor kernel (mte_pack_conv_weights_multi; the per-layer launches
     they replace were ~400 per step, launch-bound: 0.9 ms of GPU time and ~2 ms of host time).  Each launch's packs share an event
-    that their next user waits on."""
-    if not _side["enabled"]:
-        return
+    that their next user waits on.  With the side stream switched off (serial profiling runs) the same launches go to the current stream."""
     packs = []
     for r in WeightPack._live:
         pk = r()
@@ -437,12 +435,15 @@ def prefetch_weight_packs():
     if not packs:
         return
     packs.sort(key=lambda pk: pk._order)
-    if not _side["streams"]:
-        _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
-    side = _side["streams"][0]
-    ev = torch.cuda.Event()
-    ev.record()                                              # the parameter update (and every earlier user of the packs)
-    side.wait_event(ev)
+    if _side["enabled"]:
+        if not _side["streams"]:
+            _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
+        side = _side["streams"][0]
+        ev = torch.cuda.Event()
+        ev.record()                                          # the parameter update (and every earlier user of the packs)
+        side.wait_event(ev)
+    else:
+        side = torch.cuda.current_stream()
     with torch.cuda.stream(side):
         _refold_all()                                        # folded pack weights first: their packs are rebuilt below
         for pk in packs:
@@ -459,15 +460,17 @@ def prefetch_weight_packs():
                 pk.pkey, pk.pf_ok, pk.pb_ok, pk._event = None, False, False, None
         for arr, n, dtc, group in _pack_job_chunks(packs):
             lib.mte_pack_conv_weights_multi(ctypes.addressof(arr), n, dtc, st)
-            ev = torch.cuda.Event()
-            ev.record(side)
+            ev = None
+            if _side["enabled"]:
+                ev = torch.cuda.Event()
+                ev.record(side)
             for pk in group:
                 w, dtype = pk._last[0](), pk._last[1]
                 pk.key = (w.data_ptr(), w._version, weights_epoch(), dtype, tuple(w.shape))
                 pk.pkey = pk.key
                 pk.pf_ok, pk.pb_ok = pk._want_pf, pk._want_pb
                 pk._event = ev
-    if torch.cuda.is_current_stream_capturing():
+    if _side["enabled"] and torch.cuda.is_current_stream_capturing():
         # a HIP-graph capture must end with every forked stream joined; inside a graph the packs are DAG nodes that depend on
         # the optimizer only, so the replay still overlaps them with whatever else is ready
         torch.cuda.current_stream().wait_stream(side)
@@ -781,7 +784,9 @@ class ConvFn(torch.autograd.Function):
     """Plain conv + bias (the 1x1 shortcut of ResidualConv, layers01.py:61)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, pack):
+    def forward(ctx, x, w, b, pack, bias_grad=True):
+        """bias_grad=False: the consumer produces the bias gradient (ResidualTailFn: the column sums of this conv's output gradient fall
+        out of the GroupNorm backward pass that computes it -- no stand-alone column-sum launch)"""
         ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
@@ -789,6 +794,7 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.pack = pack
         ctx.bias = b
+        ctx.bias_grad = bool(bias_grad)
         return y
 
     @staticmethod
@@ -797,20 +803,27 @@ class ConvFn(torch.autograd.Function):
         b = ctx.bias
         dy = as_act(dy, x.dtype)
         gw, sw = _grad_dst(w)
+        if not ctx.bias_grad:
+            dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw)
+            return dx, _grad_ret(w, dw, sw), None, None, None
         gbias, sbias = _grad_dst(b)
         dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias, fork_slot=ctx.fork_slot,
                                    sunk=sw and sbias)
-        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None
+        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None, None
 
 
 class ResidualTailFn(torch.autograd.Function):
     """ELU(GroupNorm16(a + scale[b,c] * s)) -- ResidualConv tail with Dropout2d folded in (layers01.py:65-73)."""
 
     @staticmethod
-    def forward(ctx, a, s, scale, gamma, beta):
+    def forward(ctx, a, s, scale, gamma, beta, bias_s=None):
+        """bias_s: the bias parameter of the conv that produced `s` (the block's 1x1 shortcut).  Its value is already inside `s`; it is an
+        input here only so that its GRADIENT -- sum of ds over batch and pixels -- can come out of this op's backward pass, where ds is
+        formed anyway (the shortcut conv is then built with bias_grad=False)."""
         z, stats = _gn_forward(a, s, scale, gamma, beta, GN_EPS)
         ctx.save_for_backward(a, s, stats, gamma, beta)
         ctx.scale = scale
+        ctx.bias_s = bias_s
         return z
 
     @staticmethod
@@ -818,8 +831,13 @@ class ResidualTailFn(torch.autograd.Function):
         a, s, stats, gamma, beta = ctx.saved_tensors
         gg, sg = _grad_dst(gamma)
         gb, sb = _grad_dst(beta)
+        if ctx.bias_s is not None and ctx.needs_input_grad[5]:
+            gbs, sbs = _grad_dst(ctx.bias_s, zero=True)
+            da, ds, dgamma, dbeta, dbs = _gn_backward(dz, a, s, ctx.scale, stats, gamma, beta, GN_EPS, True, want_dbias=True,
+                                                      dgamma=gg, dbeta=gb, dbias=gbs)
+            return da, ds, None, _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), _grad_ret(ctx.bias_s, dbs, sbs)
         da, ds, dgamma, dbeta = _gn_backward(dz, a, s, ctx.scale, stats, gamma, beta, GN_EPS, True, dgamma=gg, dbeta=gb)
-        return da, ds, None, _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb)
+        return da, ds, None, _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None
 
 
 class Pack3dFn(torch.autograd.Function):

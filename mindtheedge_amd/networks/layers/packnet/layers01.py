@@ -105,10 +105,10 @@ class ResidualConv(nn.Module):
         x = _enter(x, sc.in_channels)
         xa, xb = K.fork(x)
         y = self.conv2(self.conv1(xa))
-        s = K.ConvFn.apply(xb, sc.weight, sc.bias, sc.pack)
+        s = K.ConvFn.apply(xb, sc.weight, sc.bias, sc.pack, False)          # (its bias gradient comes out of the tail's backward pass)
         if channel_scale is None and self.dropout and self.training:
             channel_scale = K.dropout2d_scale(x.shape[0], sc.out_channels, self.dropout, x.device)
-        return K.ResidualTailFn.apply(y, s, channel_scale, self.normalize.weight, self.normalize.bias)
+        return K.ResidualTailFn.apply(y, s, channel_scale, self.normalize.weight, self.normalize.bias, sc.bias)
 
 
 def ResidualBlock(in_channels, out_channels, num_blocks, stride, dropout=None):

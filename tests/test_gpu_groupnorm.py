@@ -25,7 +25,8 @@ def _reference(y1, y2, scale2, gamma, beta, dz):
         v = y1 + y2 * scale2.double()[:, :, None, None]
     z = F.elu(F.group_norm(v, 16, gamma, beta, eps=1e-5))
     z.backward(dz.double())
-    return (z.detach(), y1.grad, None if y2 is None else y2.grad, gamma.grad, beta.grad, y1.grad.sum(dim=(0, 2, 3)))
+    # bias gradient of the conv in front of the norm: column sums of d1 -- with a second input, of d2 (the shortcut conv's bias)
+    return (z.detach(), y1.grad, None if y2 is None else y2.grad, gamma.grad, beta.grad, (y1.grad if y2 is None else y2.grad).sum(dim=(0, 2, 3)))
 
 
 def _run(dtype, B, C, H, W, has2, slab):
@@ -50,10 +51,10 @@ def _run(dtype, B, C, H, W, has2, slab):
             gm, bt = gamma.to(dev), beta.to(dev)
             single = K.lib.mte_gn_fwd_is_single_pass(H * W, C, int(has2), K._dt(a1))
             z, stats = K._gn_forward(a1, a2, sc, gm, bt, 1e-5)
-            out = K._gn_backward(K.as_act(dz.to(dev), tdt), a1, a2, sc, stats, gm, bt, 1e-5, has2, want_dbias=not has2)
+            out = K._gn_backward(K.as_act(dz.to(dev), tdt), a1, a2, sc, stats, gm, bt, 1e-5, has2, want_dbias=True)
             torch.cuda.synchronize()
             d1, d2, dgamma, dbeta = out[:4]
-            dbias = out[4] if not has2 else None
+            dbias = out[4]
             got = (z.float().cpu(), d1.float().cpu(), None if d2 is None else d2.float().cpu(), dgamma.cpu(), dbeta.cpu(),
                    None if dbias is None else dbias.cpu())
             return got, want, single

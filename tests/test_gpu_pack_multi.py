@@ -50,7 +50,7 @@ def test_multi_tensor_pack_equals_per_layer_packs(dtype):
 
 def test_network_step_uses_the_multi_tensor_pack():
     """a training step of the real network: after FusedAdam.step() every pack the next forward needs carries a prefetch event and
-    the next step's loss equals the loss of a run that packs lazily layer by layer (side stream off = no prefetch)"""
+    the next step's loss equals the loss of a run with the side stream off (the same launches on the main stream, no events)"""
     from mindtheedge_amd import kernels as K
     from mindtheedge_amd.networks.depth.PackNetSAN01 import PackNetSAN01
     from mindtheedge_amd.models.SemiSupEdgeModel import SemiSupEdgeModel

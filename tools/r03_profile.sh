@@ -1,4 +1,5 @@
 #!/bin/bash
+# (bench.py runs warm-up + timed + 3 unthrottled steps: 1 + 3 + 3 = 7 steps in a trace, 1 + 2 + 3 = 6 in a PMC pass)
 # Round-3 evidence in ONE gpurun call (program directly after `--`; --pmc passes separate from --kernel-trace):
 #   1. overlapped (default two-stream schedule) kernel trace + stats     -> gpurun_out/r03_<tag>_train_T8_kernel_stats.csv / _trace_summary.txt
 #   2. SERIAL kernel trace + stats (MTE_NO_SIDE_STREAM=1 in the environment) -> ..._serial_kernel_stats.csv  (bench.py's roofline.frac is the serial figure)
@@ -19,8 +20,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -- python3 $GRAFT_RE
 cd $GRAFT_REPO_ROOT
 cp "$(find /tmp/trO -name '*kernel_stats.csv' | head -1)" $out/r03_${tag}_train_T8_kernel_stats.csv
 cp "$(find /tmp/trS -name '*kernel_stats.csv' | head -1)" $out/r03_${tag}_train_T8_serial_kernel_stats.csv
-python tools/trace_summary.py "$(find /tmp/trO -name '*kernel_trace.csv' | head -1)" 4 90 > $out/r03_${tag}_train_T8_trace_summary.txt
-python tools/trace_summary.py "$(find /tmp/trS -name '*kernel_trace.csv' | head -1)" 4 60 > $out/r03_${tag}_train_T8_serial_trace_summary.txt
-python3 tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW 3 > $out/r03_${tag}_pmc_traffic_T8.txt
+python tools/trace_summary.py "$(find /tmp/trO -name '*kernel_trace.csv' | head -1)" 7 90 > $out/r03_${tag}_train_T8_trace_summary.txt
+python tools/trace_summary.py "$(find /tmp/trS -name '*kernel_trace.csv' | head -1)" 7 60 > $out/r03_${tag}_train_T8_serial_trace_summary.txt
+python3 tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW 6 > $out/r03_${tag}_pmc_traffic_T8.txt
 python bench.py --steps 20 --warmup 5 --dump-conv $out/r03_${tag}_conv_table.txt > $out/r03_${tag}_train_T8_bench.json 2> $out/r03_${tag}_bench.err
 head -3 $out/r03_${tag}_train_T8_serial_trace_summary.txt; tail -c 600 $out/r03_${tag}_train_T8_bench.json
