@@ -289,6 +289,17 @@ int mte_canny_finish(const unsigned char* state, float* edges, int maps, int H, 
  * mte_sparse_bn_relu: out = mask ? relu(batchnorm_eval(a [+ b] [+ c])) : 0   (b, c nullable)
  * mte_san_fuse: out = skip * w[0] + sparse + bias[0]   (networks/depth/PackNetSAN01.py:254-258) */
 int mte_sparsify_depth(const float* depth, void* feat, long ldf, unsigned char* mask, int B, int H, int W, int dtype, mte_stream_t stream);
+/* Round 3: the sparse convolutions as gather-GEMM-scatter over the ACTIVE sites.  mte_sparse_site_list: sites[0 .. *count) = raster-ordered
+ * pixel indices of the active set (three small launches, no atomics; `count` stays in device memory).  mte_conv2d_igemm_sparse: the
+ * implicit GEMM of mte_conv2d_igemm with GEMM row m = pixel sites[m]: the k x k taps of a site are gathered from the zero-filled dense
+ * map (inactive neighbours contribute zeros = MinkowskiConvolution's sum over active neighbours), the result is scattered to the same
+ * sites and nothing else is written; tiles beyond *count return at once, so the work is proportional to the active count (LiDAR: ~5 % at
+ * the first level) without the count ever visiting the host.  Also the data gradient (backward pack, x := dy). */
+long mte_sparse_site_list_workspace_elems(long npix);
+int mte_sparse_site_list(const unsigned char* mask, long npix, int* sites, int* count, int* ws, mte_stream_t stream);
+int mte_conv2d_igemm_sparse(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy,
+                            int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
+                            const int* sites, const int* count, int accumulate, mte_stream_t stream);
 int mte_sparse_maxpool3s2(const void* in, long ldi, const unsigned char* mask_in, void* out, long ldo, unsigned char* mask_out,
                           int B, int H, int W, int C, int dtype, mte_stream_t stream);
 int mte_sparse_bn_relu(const void* a, long lda, const void* b, long ldb, const void* c, long ldc, const unsigned char* mask,

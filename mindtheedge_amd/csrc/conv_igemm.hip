@@ -35,6 +35,11 @@ struct ConvArgs {
                                     // the slabs in order -- no floating-point atomics, the result does not depend on the arrival order
     int accum;                      // 1: y += conv (sum formed in fp32, rounded once) -- second gradient of a two-consumer activation
     int solo;                       // host-side hint (MTE_CONV_SOLO): nothing runs beside this launch on another stream
+    // Sparse form (SAN branch, round 3): GEMM row m is pixel rows[m] of the dense NHWC maps, for m < *nrows (device-side count).  The
+    // input map is zero-filled off the active set, so gathering a row's taps from it IS the sparse convolution's sum over active
+    // neighbours; outputs are scattered to the same sites, nothing is written elsewhere.  Work scales with the active count: tiles past
+    // *nrows return at once (the grid is sized for the dense capacity M, the count never visits the host).
+    const int* rows; const int* nrows;
 };
 
 template <typename T> struct Mma;
@@ -124,6 +129,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
     const int id = xcd_remap(blockIdx.x - split * ntiles, ntiles);
     const int tile_n = id % tiles_n, tile_m = id / tiles_n;
     const long m0 = (long)tile_m * BM;
+    const long Mrows = a.rows ? (long)*a.nrows : a.M;          // GEMM rows that exist
+    if (m0 >= Mrows) return;                                    // (wave-uniform, before any barrier)
     const int n0 = tile_n * BN;
 
     const int taps = a.KH * a.KW, pad_h = a.KH >> 1, pad_w = a.KW >> 1;
@@ -152,8 +159,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
     for (int i = 0; i < A_CH; ++i) {
         const int row = (tid + i * NTHR) >> 2;
         const long m = m0 + row;
-        a_ok[i] = m < a.M;
-        const long mm = a_ok[i] ? m : 0;
+        a_ok[i] = m < Mrows;
+        const long mm = a_ok[i] ? (a.rows ? (long)a.rows[m] : m) : 0;
         const int hw = a.H * a.W;
         const int b = (int)(mm / hw), rem = (int)(mm - (long)b * hw);
         a_oy[i] = rem / a.W; a_ox[i] = rem - a_oy[i] * a.W;
@@ -419,17 +426,18 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             for (int it = 0; it < BM * CPR / NTHR; ++it) {
                 const int row = tid / CPR + it * (NTHR / CPR);
                 const long m = m0 + row;
-                if (m < a.M && cc < cvalid) {
+                if (m < Mrows && cc < cvalid) {
+                    const long pm = a.rows ? (long)a.rows[m] : m;      // output pixel of this tile row
                     u32x4_t c = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
                     if (a.accum) {
                         float vn[PER16], vo[PER16];
                         unpack16<T>(c, vn);
-                        unpack16<T>(*(const u32x4_t*)((const T*)a.y + m * a.ldy + n0 + cc * PER16), vo);
+                        unpack16<T>(*(const u32x4_t*)((const T*)a.y + pm * a.ldy + n0 + cc * PER16), vo);
 #pragma unroll
                         for (int k = 0; k < PER16; ++k) vn[k] += vo[k];
                         c = pack16<T>(vn);
                     }
-                    *(u32x4_t*)((T*)a.y + m * a.ldy + n0 + cc * PER16) = c;
+                    *(u32x4_t*)((T*)a.y + pm * a.ldy + n0 + cc * PER16) = c;
                 }
             }
             return;
@@ -447,11 +455,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 #pragma unroll
             for (int e = 0; e < AE; ++e) {
                 const long m = m0 + acc_row(i, e);
-                if (m < a.M) {
+                if (m < Mrows) {
                     const float v = acc[i][j][e] + bv;
+                    const long pm = a.rows ? (long)a.rows[m] : m;
                     if (a.splits > 1) a.ws[((long)split * a.M + m) * a.N + n] = acc[i][j][e];
-                    else if (a.out_f32) ((float*)a.y)[m * a.ldy + n] = a.accum ? v + ((float*)a.y)[m * a.ldy + n] : v;
-                    else Elem<T>::st((T*)a.y + m * a.ldy + n, a.accum ? v + Elem<T>::ld((const T*)a.y + m * a.ldy + n) : v);
+                    else if (a.out_f32) ((float*)a.y)[pm * a.ldy + n] = a.accum ? v + ((float*)a.y)[pm * a.ldy + n] : v;
+                    else Elem<T>::st((T*)a.y + pm * a.ldy + n, a.accum ? v + Elem<T>::ld((const T*)a.y + pm * a.ldy + n) : v);
                 }
             }
         }
@@ -495,7 +504,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
-    a.splits = (a.ws && !a.out_f32) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems, NTHR) : 1;
+    a.splits = (a.ws && !a.out_f32 && !a.rows) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems, NTHR) : 1;
     if constexpr ((BN * 4) % NTHR == 0) {
         if (g_igemm_dma) {
             const size_t lds4 = 4 * (BM + BN) * 64;
@@ -1422,9 +1431,27 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
     if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
-    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, accumulate & 1, (accumulate >> 1) & 1};
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, workspace, accumulate & 1, (accumulate >> 1) & 1,
+               nullptr, nullptr};
     if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream);
     if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream);
+    return MTE_ERR_UNSUPPORTED;
+}
+
+// The same convolution over the ACTIVE SITES of a sparse map only (SAN branch): x / y are the dense zero-filled NHWC maps, `sites` the
+// pixel indices of the active set (mte_sparse_site_list), `count` their number in DEVICE memory.  y is written at the active sites and
+// nowhere else.  The grid covers the dense capacity and tiles past *count return at once, so no count crosses to the host.
+int mte_conv2d_igemm_sparse(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy,
+                            int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
+                            const int* sites, const int* count, int accumulate, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpack || !y || !sites || !count || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (long)B * H * W > 0x7fffffffL) return MTE_ERR_ARG;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    if (Cin_p % 8 != 0 || ldx % per16 != 0 || (KH & 1) == 0 || (KW & 1) == 0) return MTE_ERR_ARG;
+    ConvArgs a{x, ldx, wpack, bias, y, ldy, 0, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, nullptr, accumulate & 1, (accumulate >> 1) & 1,
+               sites, count};
+    if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, 0, stream);
+    if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, 0, stream);
     return MTE_ERR_UNSUPPORTED;
 }
 

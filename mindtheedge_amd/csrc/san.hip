@@ -321,6 +321,67 @@ __global__ __launch_bounds__(256) void feat_l2_kernel(const T* __restrict__ a, l
 
 inline unsigned grid_for(long total) { long g = (total + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g; }
 
+
+// ---- site list of the active set (round 3: the sparse convolutions run over the ACTIVE pixels only, mte_conv2d_igemm_sparse) ----------
+// sites[0 .. count) = linear pixel indices (b*H*W + y*W + x) of the pixels with mask != 0, in raster order.  Three small kernels, no
+// atomics: per-block counts (a block = 1024 pixels), an exclusive scan of the counts by one block, the ordered write.
+__device__ __forceinline__ int block_excl_scan_256(int v, int* s_w, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return base + inc - v;
+}
+__device__ __forceinline__ unsigned load_mask4(const unsigned char* mask, long p, long npix) {
+    if (p + 4 <= npix && ((p & 3) == 0)) return *(const unsigned*)(mask + p);
+    unsigned r = 0;
+    for (int k = 0; k < 4; ++k) if (p + k < npix) r |= (unsigned)mask[p + k] << (8 * k);
+    return r;
+}
+__global__ __launch_bounds__(256) void site_count_kernel(const unsigned char* __restrict__ mask, long npix, int* __restrict__ counts) {
+    __shared__ int s_w[4];
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const unsigned m = p < npix ? load_mask4(mask, p, npix) : 0u;
+    const int c = ((m & 0xffu) != 0) + ((m & 0xff00u) != 0) + ((m & 0xff0000u) != 0) + ((m & 0xff000000u) != 0);
+    int total;
+    (void)block_excl_scan_256(c, s_w, total);
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void site_scan_kernel(int* __restrict__ counts, int nb, int* __restrict__ count) {
+    __shared__ int s_w[4];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb ? counts[i] : 0;
+        int total;
+        const int ex = block_excl_scan_256(v, s_w, total);
+        const int carry = s_carry;
+        if (i < nb) counts[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = s_carry;
+}
+__global__ __launch_bounds__(256) void site_write_kernel(const unsigned char* __restrict__ mask, long npix, const int* __restrict__ offsets, int* __restrict__ sites) {
+    __shared__ int s_w[4];
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const unsigned m = p < npix ? load_mask4(mask, p, npix) : 0u;
+    const int c = ((m & 0xffu) != 0) + ((m & 0xff00u) != 0) + ((m & 0xff0000u) != 0) + ((m & 0xff000000u) != 0);
+    int total;
+    int o = offsets[blockIdx.x] + block_excl_scan_256(c, s_w, total);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((m >> (8 * k)) & 0xffu) sites[o++] = (int)(p + k);
+}
+
 }  // namespace
 
 extern "C" {
@@ -330,6 +391,19 @@ int mte_sparsify_depth(const float* depth, void* feat, long ldf, unsigned char* 
     const long npix = (long)B * H * W;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(sparsify_depth_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, stream, depth, (bf16_t*)feat, ldf, mask, npix);
     else hipLaunchKernelGGL(sparsify_depth_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, stream, depth, (float*)feat, ldf, mask, npix);
+    return mte_check_launch();
+}
+
+// sites[0 .. *count) = raster-ordered pixel indices of the active set (mask != 0) of npix = B*H*W pixels; `count` (1 int) and `sites`
+// (npix ints) in device memory; ws: mte_sparse_site_list_workspace_elems(npix) ints of scratch
+long mte_sparse_site_list_workspace_elems(long npix) { return npix > 0 ? (npix + 1023) / 1024 : 0; }
+int mte_sparse_site_list(const unsigned char* mask, long npix, int* sites, int* count, int* ws, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!mask || !sites || !count || !ws || npix <= 0 || npix > 0x7fffffffL) return MTE_ERR_ARG;
+    const int nb = (int)((npix + 1023) / 1024);
+    hipLaunchKernelGGL(site_count_kernel, dim3(nb), dim3(256), 0, stream, mask, npix, ws);
+    hipLaunchKernelGGL(site_scan_kernel, dim3(1), dim3(256), 0, stream, ws, nb, count);
+    hipLaunchKernelGGL(site_write_kernel, dim3(nb), dim3(256), 0, stream, mask, npix, (const int*)ws, sites);
     return mte_check_launch();
 }
 

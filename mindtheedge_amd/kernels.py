@@ -519,13 +519,36 @@ def _patch_ok(W, cin_p, n, kh, kw, dtype):
     return _cfg["patch_kernels"] and dtype == torch.bfloat16 and lib.mte_conv2d_patch_supported(W, cin_p, n, kh, kw, DT_BF16) == 1
 
 
-def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumulate=False):
-    """y = conv_k(zero_pad(x)) + bias -> NHWC activation (written into `out` when given)"""
+class SiteList:
+    """Active set of a sparse NHWC map as a list of pixel indices (SAN branch): `rows` int32 [B*H*W] (the first `count[0]` entries are
+    valid, raster order), `count` int32 [1] -- both on the device; the count never visits the host (mte_sparse_site_list)."""
+
+    def __init__(self, mask):
+        _require_gpu(mask)
+        if mask.dtype != torch.uint8 or not mask.is_contiguous():
+            raise MteError("site list: expected a contiguous uint8 mask [B,H,W]")
+        n = mask.numel()
+        self.rows = torch.empty((n,), dtype=torch.int32, device=mask.device)
+        self.count = torch.empty((1,), dtype=torch.int32, device=mask.device)
+        ws = torch.empty((int(lib.mte_sparse_site_list_workspace_elems(n)),), dtype=torch.int32, device=mask.device)
+        lib.mte_sparse_site_list(mask.data_ptr(), n, self.rows.data_ptr(), self.count.data_ptr(), ws.data_ptr(), _stream())
+        self.shape = tuple(mask.shape)
+
+
+def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumulate=False, sites=None):
+    """y = conv_k(zero_pad(x)) + bias -> NHWC activation (written into `out` when given).
+    sites (SiteList): the sparse form -- only the active sites are computed and written (mte_conv2d_igemm_sparse)."""
     B, Cp, H, W = x.shape
     if out is None:
         out = new_act(B, cout, H, W, x.dtype, x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(out)
+    if sites is not None:
+        if sites.shape != (B, H, W):
+            raise MteError("site list of a %s mask used on a %s map" % (sites.shape, (B, H, W)))
+        lib.mte_conv2d_igemm_sparse(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw, _dt(x),
+                                    sites.rows.data_ptr(), sites.count.data_ptr(), 1 if accumulate else 0, _stream())
+        return out
     if not accumulate and _stem_ok(W, Cp, cout, kh, kw, x.dtype):
         lib.mte_conv2d_stem_fwd(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, B, H, W, cout, kh, kw, _stream())
         return out
@@ -641,7 +664,7 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     return dw, dbias
 
 
-def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None, sunk=False):
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None, sunk=False, sites=None):
     """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations; sunk: they are views
     of the gradient sink (nothing on the backward chain reads them: the weight-gradient kernels may run on the side stream);
     fork_slot: see ForkFn -- the data gradient is accumulated into the gradient another consumer of x already produced"""
@@ -665,7 +688,11 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
         dx = target if target is not None else new_act(B, Cp, H, W, x.dtype, x.device)
         acc = 1 if target is not None else 0
         dxp, lddx = _pl(dx)
-        if _patch_ok(W, cout, Cp, kh, kw, x.dtype):
+        if sites is not None:                              # sparse data gradient: the same gather-GEMM-scatter with the backward pack
+            _, wb = pack.get(w, x.dtype, True)
+            lib.mte_conv2d_igemm_sparse(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, _dt(x),
+                                        sites.rows.data_ptr(), sites.count.data_ptr(), acc, st)
+        elif _patch_ok(W, cout, Cp, kh, kw, x.dtype):
             lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
         else:
             _, wb = pack.get(w, x.dtype, True)

@@ -3,7 +3,8 @@
 Mirror of packnet_sfm/networks/layers/minkowski_encoder.py (``MinkConv2D`` :11-86, ``MinkowskiEncoder`` :89-132) and of
 ``sparsify_depth`` / ``densify_features`` (networks/layers/minkowski.py:33-79) WITHOUT MinkowskiEngine: the sparse
 operators are evaluated in their dense-equivalent form on zero-filled NHWC maps plus a byte mask of the active set
-(csrc/san.hip), and the convolutions run on the library's dense MFMA kernels.  MinkowskiEngine is a third-party CUDA
+(csrc/san.hip), and the convolutions run on the library's dense MFMA kernels (a gather-GEMM-scatter form over the active sites exists
+too, round 3: see SPARSE_GATHER below for why it is not the default).  MinkowskiEngine is a third-party CUDA
 dependency of the reference that is not available where this was written, so the operator semantics follow its published
 documentation as restated in oracle/san_oracle.py and cannot be checked against the real thing here:
 
@@ -28,28 +29,42 @@ import torch.nn as nn
 from ... import kernels as K
 
 
+# Form of the branch's convolutions.  False (default): dense convolution of the zero-filled map, result kept on the mask.  True: gather-GEMM-
+# scatter over the active sites (round 3, mte_conv2d_igemm_sparse).  Both are tested against the same statement and against each other
+# (bit-identical on the active sites); the dense form is the default because it is FASTER on this workload -- measured on MI355X, B 4,
+# 384x1280, 5 % LiDAR density (tools/san_bench.py, profiles/r03_san_dense_vs_gather.txt): branch 2.30 ms dense vs 2.89 ms gather.  Only the
+# INPUT is 5 % active: the stride-2 3x3 pooling in front of every level leaves 18.5 % of the cells active at the first level, 55.7 % at
+# the second and >= 96 % from the third on, and a gathered 5x5 site re-reads 25 scattered taps where the dense kernel streams every pixel once.
+SPARSE_GATHER = False
+
+
 class _SparseConvFn(torch.autograd.Function):
-    """dense convolution of the zero-filled map with the [k*k, C_in, C_out] kernel parameter (the caller masks the result)"""
+    """MinkowskiConvolution(k, stride 1) of the zero-filled map with the [k*k, C_in, C_out] kernel parameter.
+    Round 3: gather-GEMM-scatter over the ACTIVE sites (`sites`: kernels.SiteList of the level's mask) on the implicit-GEMM MFMA kernel --
+    a site's k x k taps are gathered from the zero-filled dense map, the result is scattered to the same sites and nothing else is
+    written (every consumer selects by the mask), so the work follows the active count (~5 % of the pixels at the first level) instead
+    of the dense map; forward and data gradient.  The weight gradient stays the dense reduction (inactive sites contribute exact zeros).
+    sites = None: the dense-equivalent form of round 2 (the caller masks the result)."""
 
     @staticmethod
-    def forward(ctx, feat, kernel, k, pack):
+    def forward(ctx, feat, kernel, k, pack, sites=None):
         cin, cout = kernel.shape[1], kernel.shape[2]
         w = kernel.detach().view(k, k, cin, cout).permute(3, 2, 0, 1).contiguous()
         pack.key = None
         wf, _ = pack.get(w, feat.dtype, bool(ctx.needs_input_grad[0]))
-        y = K.conv_forward(feat, wf, None, cout, k, k, pack=pack, w=w)
+        y = K.conv_forward(feat, wf, None, cout, k, k, pack=pack, w=w, sites=sites)
         ctx.save_for_backward(feat, w)
-        ctx.pack, ctx.k = pack, k
+        ctx.pack, ctx.k, ctx.sites = pack, k, sites
         return y
 
     @staticmethod
     def backward(ctx, dy):
         feat, w = ctx.saved_tensors
         dy = K.as_act(dy, feat.dtype)
-        dx, dw, _ = K.conv_backward(feat, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False)
+        dx, dw, _ = K.conv_backward(feat, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, sites=ctx.sites)
         k = ctx.k
         dkernel = None if dw is None else dw.permute(2, 3, 1, 0).reshape(k * k, w.shape[1], w.shape[0])
-        return dx, dkernel, None, None
+        return dx, dkernel, None, None, None
 
 
 class _SparseConv(nn.Module):
@@ -61,8 +76,8 @@ class _SparseConv(nn.Module):
         self.kernel = nn.Parameter(kernel)
         self._pack = K.WeightPack()
 
-    def forward(self, feat):
-        return _SparseConvFn.apply(feat, self.kernel, self.k, self._pack)
+    def forward(self, feat, sites=None):
+        return _SparseConvFn.apply(feat, self.kernel, self.k, self._pack, sites)
 
 
 class _SparseBatchNorm(nn.Module):
@@ -177,9 +192,10 @@ class MinkConv2D(nn.Module):
         if self.stride != 1:
             feat, mask = _SparseMaxPoolFn.apply(feat, mask)
         l3, l2 = self.layer3, self.layer2
-        x1 = self.layer1[0](feat)
-        x2 = l2[3](_bn_relu(l2[0](feat), mask, l2[1]))
-        x3 = l3[6](_bn_relu(l3[3](_bn_relu(l3[0](feat), mask, l3[1])), mask, l3[4]))
+        sites = K.SiteList(mask) if SPARSE_GATHER else None          # one site list per level, shared by its six convolutions
+        x1 = self.layer1[0](feat, sites)
+        x2 = l2[3](_bn_relu(l2[0](feat, sites), mask, l2[1]), sites)
+        x3 = l3[6](_bn_relu(l3[3](_bn_relu(l3[0](feat, sites), mask, l3[1]), sites), mask, l3[4]), sites)
         return None, (_bn_relu(x1, mask, self.layer_final[0], x2, x3), mask)
 
 

@@ -51,10 +51,73 @@ def test_glue_kernels_against_dense_statement():
     assert float(wf.min()) < 0.0                                  # the case that distinguishes it from zero-filled pooling
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
-def test_encoder_levels_match_dense_statement(dtype, tol):
+@pytest.mark.parametrize("density", [0.0, 0.05, 0.5, 1.0])
+def test_site_list_is_the_raster_ordered_active_set(density):
+    """mte_sparse_site_list: three small launches, no atomics -> exactly torch.nonzero's order; the count stays on the device"""
     from mindtheedge_amd import kernels as K
+    g = torch.Generator().manual_seed(int(density * 100))
+    for shape in ((2, 24, 40), (1, 192, 640), (3, 7, 13)):
+        mask = (torch.rand(shape, generator=g) < density).to(torch.uint8).cuda()
+        sl = K.SiteList(mask)
+        torch.cuda.synchronize()
+        n = int(sl.count[0])
+        want = torch.nonzero(mask.flatten()).flatten().int()
+        assert n == want.numel()
+        assert torch.equal(sl.rows[:n], want)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape,density", [((64, 64, 3, 2, 24, 40), 0.05), ((8, 64, 5, 1, 48, 64), 0.06), ((128, 256, 3, 2, 12, 20), 0.5),
+                                           ((32, 32, 3, 1, 16, 32), 1.0), ((64, 128, 3, 1, 16, 32), 0.0)])
+def test_sparse_convolution_equals_the_dense_form_on_the_active_sites(shape, density, dtype):
+    """gather-GEMM-scatter over the site list (mte_conv2d_igemm_sparse) against the dense convolution of the same zero-filled map:
+    the same products in the same order per output, so forward and data gradient are BIT-identical on the active sites, and
+    nothing is written off them"""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W = shape
+    K.set_compute_dtype(dtype)
+    try:
+        g = torch.Generator().manual_seed(cin + cout + k)
+        mask = (torch.rand(B, H, W, generator=g) < density)
+        x = (torch.rand(B, cin, H, W, generator=g) * 2 - 1) * mask[:, None]
+        dy = (torch.rand(B, cout, H, W, generator=g) * 2 - 1) * mask[:, None]
+        w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+        xa, dya = K.as_act(x.cuda(), K.compute_dtype()), K.as_act(dy.cuda(), K.compute_dtype())
+        sites = K.SiteList(mask.to(torch.uint8).cuda())
+        pack = K.WeightPack()
+        wf, wb = pack.get(w, xa.dtype, True)
+        K.use_patch_kernels(False)                                    # (the dense side on the implicit GEMM too, un-split: same accumulation order)
+        orig, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)
+        try:
+            dense = K.conv_forward(xa, wf, None, cout, k, k).float()
+            ddx, _, _ = K.conv_backward(xa, dya, w, pack, True, need_dw=False)
+        finally:
+            K._splitk_workspace = orig
+            K.use_patch_kernels(True)
+        out = torch.full_like(K.new_act(B, cout, H, W), 7.0)
+        got = K.conv_forward(xa, wf, None, cout, k, k, out=out, sites=sites).float()
+        sdx, _, _ = K.conv_backward(xa, dya, w, pack, True, need_dw=False, sites=sites)
+        torch.cuda.synchronize()
+        m = mask.cuda()[:, None]
+        assert torch.equal(torch.where(m, got, torch.zeros_like(got)), torch.where(m, dense, torch.zeros_like(dense)))
+        assert bool((got[(~m).expand_as(got)] == 7.0).all())         # untouched off the active set
+        mi = m.expand(B, K.round8(cin), H, W)
+        assert torch.equal(torch.where(mi, sdx.float(), torch.zeros_like(sdx.float())), torch.where(mi, ddx.float(), torch.zeros_like(ddx.float())))
+        if density > 0:
+            assert float(dense.abs().max()) > 0
+    finally:
+        K.use_patch_kernels(True)
+        K.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("gather", [True, False])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_encoder_levels_match_dense_statement(dtype, tol, gather, monkeypatch):
+    """gather = True: the convolutions run over the active sites (round 3); False: the dense-equivalent form of round 2"""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.layers import minkowski_encoder as me
     from mindtheedge_amd.networks.layers.minkowski_encoder import MinkowskiEncoder
+    monkeypatch.setattr(me, "SPARSE_GATHER", gather)
     K.set_compute_dtype(dtype)
     enc = MinkowskiEncoder([32, 64, 128, 256, 512]).eval()
     _randomise(enc, seed=4)
@@ -166,7 +229,14 @@ def _oracle_params(enc):
     return P
 
 
-def test_training_features_gradients_and_running_statistics_match_autograd():
+@pytest.mark.parametrize("gather", [True, False])
+def test_training_features_gradients_and_running_statistics_match_autograd(gather, monkeypatch):
+    from mindtheedge_amd.networks.layers import minkowski_encoder as me
+    monkeypatch.setattr(me, "SPARSE_GATHER", gather)
+    _training_features_gradients_and_running_statistics()
+
+
+def _training_features_gradients_and_running_statistics():
     from mindtheedge_amd import kernels as K
     from mindtheedge_amd.networks.layers.minkowski_encoder import MinkowskiEncoder
     K.set_compute_dtype("fp32")

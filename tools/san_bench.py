@@ -30,8 +30,22 @@ def timed(fn, n=10):
     return (time.perf_counter() - t0) * 1e3 / n
 
 
+from mindtheedge_amd.networks.layers import minkowski_encoder as me  # noqa: E402
+
 with torch.no_grad():
     rgb_ms = timed(lambda: net(rgb))
-    san_ms = timed(lambda: net(rgb, input_depth=lidar))
-print(json.dumps({"B": B, "rgb_only_ms": round(rgb_ms, 3), "rgb_plus_lidar_ms": round(san_ms, 3), "san_branch_ms": round(san_ms - rgb_ms, 3),
-                  "images_per_s_with_lidar": round(B / (san_ms * 1e-3), 1), "san_params": sum(p.numel() for p in net.mconvs.parameters())}))
+    out = {"B": B, "rgb_only_ms": round(rgb_ms, 3), "san_params": sum(p.numel() for p in net.mconvs.parameters())}
+    for gather in (False, True):                 # dense-equivalent convolutions of the zero-filled maps | gather-GEMM-scatter over the site lists
+        me.SPARSE_GATHER = gather
+        san_ms = timed(lambda: net(rgb, input_depth=lidar))
+        tag = "gather" if gather else "dense"
+        out.update({"rgb_plus_lidar_ms_" + tag: round(san_ms, 3), "san_branch_ms_" + tag: round(san_ms - rgb_ms, 3),
+                    "images_per_s_with_lidar_" + tag: round(B / (san_ms * 1e-3), 1)})
+    # active share per pyramid level (what the gather form's work scales with)
+    net.mconvs.prep(lidar)
+    dens = []
+    for _ in range(5):
+        net.mconvs()
+        dens.append(round(float(net.mconvs.d[1].float().mean()), 3))
+    out["active_share_per_level"] = dens
+print(json.dumps(out))
