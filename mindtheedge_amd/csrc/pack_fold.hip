@@ -51,17 +51,32 @@ __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __
             }
         Wf[i] = acc;
     }
-    // b' (one wave per co; first blocks only)
-    const int lane = threadIdx.x & 63;
-    for (int co = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); co < Co; co += gridDim.x * (blockDim.x >> 6)) {
-        float sum = 0.f;
+    // b'[co] = b[co] + sum_f b3[f] * sum_{d,t} W[co][f][d][t]: one block per co (a wave per co walked the 4 * D * k * k weights in 64-wide
+    // steps, one dependent load after the other: 80 us of a 90 us launch at D = 512); fixed summation order
+    __shared__ float s_w[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int co = blockIdx.x; co < Co; co += gridDim.x) {
+        float sf[4];
+#pragma unroll
         for (int f = 0; f < 4; ++f) {
-            float sf = 0.f;
             const float* wr = W + ((long)co * 4 * D + (long)f * D) * kk;
-            for (long j = lane; j < (long)D * kk; j += 64) sf += wr[j];
-            sum = fmaf(wave_sum(sf), b3[f], sum);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const long n = (long)D * kk;
+            long j = threadIdx.x;
+            for (; j + 768 < n; j += 1024) { a0 += wr[j]; a1 += wr[j + 256]; a2 += wr[j + 512]; a3 += wr[j + 768]; }
+            for (; j < n; j += 256) a0 += wr[j];
+            sf[f] = wave_sum((a0 + a1) + (a2 + a3));
         }
-        if (lane == 0) bf[co] = b[co] + sum;
+        __syncthreads();                                      // s_w free again
+        if (lane == 0)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) s_w[f][wave] = sf[f];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float sum = 0.f;
+            for (int f = 0; f < 4; ++f) sum = fmaf((s_w[f][0] + s_w[f][1]) + (s_w[f][2] + s_w[f][3]), b3[f], sum);
+            bf[co] = b[co] + sum;
+        }
     }
 }
 
@@ -94,7 +109,7 @@ __global__ void unfold_dw_kernel(const float* __restrict__ dWf, const float* __r
 }
 
 // dK3[f][kd][dh][dw] += sum_{co,d,t} dWf[co][d+kd-1][t+(dh,dw)] * W[co][f*D+d][t];  db3[f] += sum_co dbf[co] * sum_{d,t} W[co][fD+d][t]
-// grid.x strides over (co, d); out[112] = dK3[108] then db3[4], atomically accumulated
+// grid.x strides over (co, d, tap); out[112] = dK3[108] then db3[4], atomically accumulated
 __global__ __launch_bounds__(256) void unfold_dk3_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf,
                                                          const float* __restrict__ W, float* __restrict__ out, int Co, int D, int k) {
     __shared__ float sred[4 * 112];
@@ -102,11 +117,14 @@ __global__ __launch_bounds__(256) void unfold_dk3_kernel(const float* __restrict
     float acc[112];
 #pragma unroll
     for (int i = 0; i < 112; ++i) acc[i] = 0.f;
-    const long rows = (long)Co * D;                        // (co, d) pairs; thread handles whole rows
-    for (long rix = blockIdx.x * (long)blockDim.x + threadIdx.x; rix < rows; rix += (long)gridDim.x * blockDim.x) {
+    // a thread takes (co, d, tap) items (with whole (co, d) rows per thread the 32 x 128 rows of pack1 were 16 workgroups walking 25 taps x 31
+    // dependent loads each: 100 us for 0.4 MB)
+    const long items = (long)Co * D * kk;
+    for (long ix = blockIdx.x * (long)blockDim.x + threadIdx.x; ix < items; ix += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(ix % kk); const long rix = ix / kk;
         const int d = (int)(rix % D); const int co = (int)(rix / D);
         const float dbv = dbf[co];
-        for (int t = 0; t < kk; ++t) {
+        {
             const int ty = t / k, tx = t - ty * k;
             float wv[4];
 #pragma unroll
@@ -262,8 +280,8 @@ int mte_unfold_pack_wgrad(const float* dWf, const float* dbf, const float* W, co
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dWf || !dbf || !W || !K3 || !b3 || !dW || !dk3b) return MTE_ERR_ARG;
     hipLaunchKernelGGL(unfold_dw_kernel, dim3(sgrid((long)Co * 4 * D * k * k)), dim3(256), 0, stream, dWf, dbf, K3, b3, dW, Co, D, k, accumulate);
-    long rows = (long)Co * D;
-    long g = (rows + 255) / 256; if (g > 512) g = 512; if (g < 1) g = 1;
+    long items = (long)Co * D * k * k;
+    long g = (items + 255) / 256; if (g > 512) g = 512; if (g < 1) g = 1;
     hipLaunchKernelGGL(unfold_dk3_kernel, dim3((unsigned)g), dim3(256), 0, stream, dWf, dbf, W, dk3b, Co, D, k);
     return mte_check_launch();
 }

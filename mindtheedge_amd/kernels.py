@@ -306,10 +306,13 @@ class WeightPack:
 
     def _sync_prefetch(self):
         if self._event is not None:
-            if self._event is not _side.get("last_waited"):   # packs are prefetched in groups that share one event
-                torch.cuda.current_stream().wait_event(self._event)
-                _side["last_waited"] = self._event
-            self._event = None
+            cur = torch.cuda.current_stream()
+            waited = _side.setdefault("last_waited", {})      # packs are prefetched in groups that share one event: one wait per stream
+            if waited.get(cur.cuda_stream) is not self._event:
+                cur.wait_event(self._event)
+                waited[cur.cuda_stream] = self._event
+            if not _side.get("band_active"):                  # (a band chain runs beside the main chain, which may ask for this pack next)
+                self._event = None
 
     def _patch_pack(self, w, which):
         wf, wb = self.wf, self.wb
@@ -579,6 +582,54 @@ _SIDE_KEEP_LIMIT = 24 << 30          # bytes of (x, dy) kept alive for the side 
 
 def use_wgrad_side_stream(flag):
     _side["enabled"] = bool(flag)
+
+
+class _BandChain:
+    """The exact-border band chain of a folded pack layer (thin strips: 16 x 5 x 640 pixels and the like, launches that fill a
+    fraction of the chip) on a stream of its own, beside the layer's full-size kernels: `with chain:` forks from the current
+    stream, `chain.join()` makes the current stream wait for everything the block enqueued.  With the side streams switched
+    off (serial profiling) it does nothing and the chain stays on the current stream."""
+
+    def __init__(self):
+        self.stream = None
+        self.done = None
+        if _side["enabled"] and _BAND_STREAM:
+            if _side.get("band") is None:
+                _side["band"] = torch.cuda.Stream()
+            self.stream = _side["band"]
+
+    def __enter__(self):
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.stream.wait_event(ev)
+            self._ctx = torch.cuda.stream(self.stream)
+            self._ctx.__enter__()
+            _side["band_active"] = True
+        return self
+
+    def mark(self):
+        """event at this point of the chain (None when the chain runs on the current stream)"""
+        if self.stream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def __exit__(self, *exc):
+        if self.stream is not None:
+            self.done = self.mark()
+            _side["band_active"] = False
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, ev="done"):
+        ev = self.done if ev == "done" else ev
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
+_BAND_STREAM = not os.environ.get("MTE_NO_BAND_STREAM")    # development A/B: band chains on the main chain
 
 
 def join_side_stream():
@@ -1061,31 +1112,35 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         H2, W2 = H // 2, W // 2
         co, _, k, _ = w.shape
         pad, hb = k // 2, 2 * (k // 2) + 1
-        dt, dev, st = _dt(x), x.device, _stream()
+        dt, dev = _dt(x), x.device
         w3c, b3c = w3.detach().contiguous().float(), b3.detach().contiguous().float()
+        # exact border bands: group 1 = top/bottom rows, group 2 = left/right columns (rows pad .. H2-pad) -- a chain of small launches,
+        # on its own stream beside the interior path
+        bands = _BandChain()
+        with bands:
+            wu, _ = pack_unf.get(w, x.dtype, False)
+            xb1 = new_act(2 * B, C, 2 * hb, W, x.dtype, dev)
+            xb2 = new_act(2 * B, C, H, 2 * hb, x.dtype, dev)
+            _rects([(x, 0, 0, xb1[:B], 0, 0, 2 * hb, W, 0), (x, H - 2 * hb, 0, xb1[B:], 0, 0, 2 * hb, W, 0),
+                    (x, 0, 0, xb2[:B], 0, 0, H, 2 * hb, 0), (x, 0, W - 2 * hb, xb2[B:], 0, 0, H, 2 * hb, 0)])
+            Tb = []
+            for xb, (hh, ww) in ((xb1, (hb, W2)), (xb2, (H2, hb))):
+                T = new_act(2 * B, 16 * C, hh, ww, x.dtype, dev)
+                sp, lds_ = _pl(xb)
+                tp, ldt = _pl(T)
+                lib.mte_pack3d_fwd(sp, lds_, w3c.data_ptr(), b3c.data_ptr(), tp, ldt, 2 * B, xb.shape[2], xb.shape[3], C, dt, _stream())
+                Tb.append(T)
+            yb1 = conv_forward(Tb[0], wu, b, co, k, k, pack=pack_unf, w=w)
+            yb2 = conv_forward(Tb[1], wu, b, co, k, k, pack=pack_unf, w=w)
         # folded weights + interior result
         P = new_act(B, 4 * C, H2, W2, x.dtype, dev)
         xp, ldx = _pl(x)
         pp, ldp = _pl(P)
-        lib.mte_pixel_shuffle(xp, ldx, pp, ldp, B, H, W, C, 0, dt, st)
+        lib.mte_pixel_shuffle(xp, ldx, pp, ldp, B, H, W, C, 0, dt, _stream())
         Wf, bf = _folded_weights(pack_fold, w, w3, b, b3, co, C, k, dev)
         wfp, _ = pack_fold.get(Wf, x.dtype, False)
         y = conv_forward(P, wfp, bf, co, k + 2, k + 2, pack=pack_fold, w=Wf)
-        # exact border bands: group 1 = top/bottom rows, group 2 = left/right columns (rows pad .. H2-pad)
-        wu, _ = pack_unf.get(w, x.dtype, False)
-        xb1 = new_act(2 * B, C, 2 * hb, W, x.dtype, dev)
-        xb2 = new_act(2 * B, C, H, 2 * hb, x.dtype, dev)
-        _rects([(x, 0, 0, xb1[:B], 0, 0, 2 * hb, W, 0), (x, H - 2 * hb, 0, xb1[B:], 0, 0, 2 * hb, W, 0),
-                (x, 0, 0, xb2[:B], 0, 0, H, 2 * hb, 0), (x, 0, W - 2 * hb, xb2[B:], 0, 0, H, 2 * hb, 0)])
-        Tb = []
-        for xb, (hh, ww) in ((xb1, (hb, W2)), (xb2, (H2, hb))):
-            T = new_act(2 * B, 16 * C, hh, ww, x.dtype, dev)
-            sp, lds_ = _pl(xb)
-            tp, ldt = _pl(T)
-            lib.mte_pack3d_fwd(sp, lds_, w3c.data_ptr(), b3c.data_ptr(), tp, ldt, 2 * B, xb.shape[2], xb.shape[3], C, dt, st)
-            Tb.append(T)
-        yb1 = conv_forward(Tb[0], wu, b, co, k, k, pack=pack_unf, w=w)
-        yb2 = conv_forward(Tb[1], wu, b, co, k, k, pack=pack_unf, w=w)
+        bands.join()
         _rects([(yb1[:B], 0, 0, y, 0, 0, pad, W2, 0), (yb1[B:], hb - pad, 0, y, H2 - pad, 0, pad, W2, 0),
                 (yb2[:B], pad, 0, y, pad, 0, H2 - 2 * pad, pad, 0), (yb2[B:], pad, hb - pad, y, pad, W2 - pad, H2 - 2 * pad, pad, 0)])
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out))
@@ -1102,29 +1157,34 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         pack_unf, pack_fold = ctx.packs
         B, C, H, W, co, k = ctx.geom
         H2, W2, pad, hb = H // 2, W // 2, k // 2, 2 * (k // 2) + 1
-        dt, dev, st = _dt(P), P.device, _stream()
+        dt, dev = _dt(P), P.device
         dy, _, dgamma, dbeta = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False)
-        # ---- band paths (unfolded, exact)
-        dyb1 = torch.zeros((2 * B, hb, W2, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
-        dyb2 = torch.zeros((2 * B, H2, hb, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
-        _rects([(dy, 0, 0, dyb1[:B], 0, 0, pad, W2, 0), (dy, H2 - pad, 0, dyb1[B:], hb - pad, 0, pad, W2, 0),
-                (dy, pad, 0, dyb2[:B], pad, 0, H2 - 2 * pad, pad, 0), (dy, pad, W2 - pad, dyb2[B:], pad, hb - pad, H2 - 2 * pad, pad, 0)])
-        dTs, dxb = [], []
-        for xb, T, dyb in ((xb1, T1, dyb1), (xb2, T2, dyb2)):
-            dT, _, _ = conv_backward(T, dyb, w, pack_unf, True, need_dw=False)
-            Bb, _, hx, wx = xb.shape
-            tp, ldt = _pl(dT)
-            dxi = new_act(Bb, C, hx, wx, P.dtype, dev)
-            dp_, ldd = _pl(dxi)
-            lib.mte_pack3d_bwd_data(tp, ldt, w3c.data_ptr(), dp_, ldd, Bb, hx, wx, C, dt, st)
-            dTs.append(dT)
-            dxb.append(dxi)
+        # ---- band paths (unfolded, exact), beside the interior path
+        bands = _BandChain()
+        with bands:
+            dyb1 = torch.zeros((2 * B, hb, W2, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
+            dyb2 = torch.zeros((2 * B, H2, hb, co), dtype=P.dtype, device=dev).permute(0, 3, 1, 2)
+            _rects([(dy, 0, 0, dyb1[:B], 0, 0, pad, W2, 0), (dy, H2 - pad, 0, dyb1[B:], hb - pad, 0, pad, W2, 0),
+                    (dy, pad, 0, dyb2[:B], pad, 0, H2 - 2 * pad, pad, 0), (dy, pad, W2 - pad, dyb2[B:], pad, hb - pad, H2 - 2 * pad, pad, 0)])
+            gathered = bands.mark()                            # the band pixels of dy have been read (they are cleared below)
+            dTs, dxb = [], []
+            for xb, T, dyb in ((xb1, T1, dyb1), (xb2, T2, dyb2)):
+                dT, _, _ = conv_backward(T, dyb, w, pack_unf, True, need_dw=False)
+                Bb, _, hx, wx = xb.shape
+                tp, ldt = _pl(dT)
+                dxi = new_act(Bb, C, hx, wx, P.dtype, dev)
+                dp_, ldd = _pl(dxi)
+                lib.mte_pack3d_bwd_data(tp, ldt, w3c.data_ptr(), dp_, ldd, Bb, hx, wx, C, dt, _stream())
+                dTs.append(dT)
+                dxb.append(dxi)
         # ---- interior path (folded): band pixels carry no gradient here
+        bands.join(gathered)
         _rects([(None, 0, 0, dy, 0, 0, pad, W2, 2), (None, 0, 0, dy, H2 - pad, 0, pad, W2, 2),
                 (None, 0, 0, dy, pad, 0, H2 - 2 * pad, pad, 2), (None, 0, 0, dy, pad, W2 - pad, H2 - 2 * pad, pad, 2)])
 
         def weight_grads():
             """every parameter gradient of the layer except gamma/beta; nothing on the data-gradient chain needs them"""
+            bands.join()                                       # (on the stream that runs the weight gradients: they read dTs / dyb)
             sw = _stream()
             dw_band = db_band = None
             dk3b = torch.zeros((112,), dtype=torch.float32, device=dev)
@@ -1153,7 +1213,8 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         dx = new_act(B, C, H, W, P.dtype, dev)
         sp, lds_ = _pl(dP)
         dp_, ldd = _pl(dx)
-        lib.mte_pixel_shuffle(sp, lds_, dp_, ldd, B, H, W, C, 1, dt, st)
+        lib.mte_pixel_shuffle(sp, lds_, dp_, ldd, B, H, W, C, 1, dt, _stream())
+        bands.join()
         # (the four bands overlap in the corners: two launches so that no element is read-modified by two operations at once)
         _rects([(dxb[0][:B], 0, 0, dx, 0, 0, 2 * hb, W, 1), (dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, 1)])
         _rects([(dxb[1][:B], 0, 0, dx, 0, 0, H, 2 * hb, 1), (dxb[1][B:], 0, 0, dx, 0, W - 2 * hb, H, 2 * hb, 1)])
