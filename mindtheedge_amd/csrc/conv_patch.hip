@@ -16,6 +16,7 @@
 //
 // Reference ops replaced: nn.Conv2d + ConstantPad2d of Conv2D / ResidualConv (layers01.py:29-31,61) and their autograd.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -165,6 +166,232 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
         if (yy < a.H && c < cpp) {
             u32x4_t v16 = *(const u32x4_t*)(smem + pix * NB + c * 16);
+            if (a.accum) {
+                float vn[8], vo[8];
+                unpack16<bf16_t>(v16, vn);
+                unpack16<bf16_t>(*(const u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8), vo);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vn[k] += vo[k];
+                v16 = pack16<bf16_t>(vn);
+            }
+            *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
+        }
+    }
+}
+
+
+// ---- forward / dgrad, second form (round 3) ------------------------------------------------------------------------
+// In-kernel stamps of the first form (3 slices of a 3x3 filter, 16 x 32 tile, two workgroups per CU) put a tile at 21.8 us: 2.9 us of
+// cold prologue, 2.4 us of epilogue, and tap loops at ~55 % of the MFMA rate that take 6.1 / 4.9 / 4.0 us -- the first two longer because
+// vmcnt retires in order and every weight fragment requested after the next slice's patch loads waits out that whole HBM fetch.  Changes:
+//   * the patch travels global -> LDS by LDS-DMA (no staging registers, no ds_write): a wave instruction fills 1 KiB of the patch image,
+//     the XOR swizzle is applied to the SOURCE chunk a lane asks for, out-of-image chunks read a zero chunk (no branch, so every wait is
+//     counted exactly), and the 3x3 kernels request all nine taps' weight fragments BEFORE the DMA of the next slice is issued;
+//   * the A fragments slide down the patch: for a fixed tap column the wave keeps MM + 1 pixel rows in registers and each tap row reads
+//     ONE new row (2 ds_read_b128 instead of 2 MM), issued a whole tap ahead of its first MFMA;
+//   * the MFMA operands are swapped (D = W * X^T): a lane then owns 4 CONSECUTIVE output channels of one pixel per accumulator quad, so
+//     the tile is staged with 16 ds_write_b64 per thread instead of 64 two-byte writes that all fell on two LDS banks.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+template <int K, int NT, bool TALL>
+__global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
+    static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
+    constexpr int TH = TALL ? 16 : 8;
+    constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
+    constexpr int PCH = PH * PW * 4;                               // 16-B chunks of one patch slice
+    constexpr int NDMA = (PCH + 255) / 256;                        // DMA instructions per wave and slice
+    constexpr int PBYTES = NDMA * 256 * 16;                        // (whole instructions: the tail lanes deposit zero chunks behind the patch)
+    constexpr int NB = NT * 64, OSTR = NB + 16;                    // bytes per staged pixel, padded stride (b64 writes of 16 pixels: 2-way)
+    constexpr int OBYTES = TH * TW * OSTR;
+    constexpr int NBUF = (TALL && K > 3) ? 1 : 2;                  // tall 5x5 / 7x7 tiles: single-slice layers only
+    constexpr int LDS_BYTES = NBUF * PBYTES > OBYTES ? NBUF * PBYTES : OBYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = a.W / TW, tiles_y = (a.H + TH - 1) / TH;
+    int id = xcd_remap(blockIdx.x, tiles_x * tiles_y * a.B);
+    const int tx_ = id % tiles_x; id /= tiles_x;
+    const int ty_ = id % tiles_y; const int b = id / tiles_y;
+    const int x0 = tx_ * TW, y0 = ty_ * TH;
+    const int cpt = a.Cin_p >> 3;                                  // 16-B chunks per pixel
+    const int nslices = (a.Cin_p + 31) >> 5;
+
+    // ---- DMA plan of this thread: chunk idc = (i * 4 + wave) * 64 + lane of the patch image; LDS slot (idc & 3) of pixel p = idc >> 2 holds
+    // source chunk kc = slot ^ swz(p)
+    // (buffer-descriptor form of the DMA, as in conv_igemm.hip: the per-lane byte offset is fixed per tile, the slice advance is a wave-uniform
+    //  scalar offset, and a chunk outside the image asks for an offset beyond the descriptor's range, which returns zeros.  The compiler also
+    //  keeps LDS reads that follow a global_load_lds behind vmcnt(0) -- it cannot tell the two patch buffers apart -- but not these.)
+    constexpr unsigned OOB = 0xfffffff0u;
+    unsigned doff[NDMA];                                           // byte offset of the chunk for slice 0 (launcher: the tensor is < 2 GiB)
+    unsigned dkc = 0;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int idc = (i * 4 + wave) * 64 + lane;
+        const int p = idc >> 2, kc = (idc & 3) ^ ((p >> 2) & 3);
+        const int py = p / PW, px = p - py * PW;
+        const int iy = y0 + py - PAD, ix = x0 + px - PAD;
+        const bool ok = idc < PCH && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        doff[i] = ok ? (unsigned)(((((long)b * a.H + iy) * a.W + ix) * a.ldx + kc * 8) * 2) : OOB;
+        dkc |= (unsigned)kc << (2 * i);
+    }
+    auto dma_patch = [&](int s, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((((long)a.B * a.H * a.W - 1) * a.ldx + a.Cin_p) * 2), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int cc = s * 4 + (int)((dkc >> (2 * i)) & 3u);
+            const unsigned voff = cc < cpt ? doff[i] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + buf * PBYTES + (i * 4 + wave) * 1024), 16, voff, s * 64, 0, 0);
+        }
+#else
+        (void)s; (void)buf;
+#endif
+    };
+
+    constexpr int MM = (NT == 2 || TALL) ? 4 : 2;                  // pixel rows per wave
+    const int nsel = NT == 2 ? wave >> 1 : 0;
+    const int mrow0 = NT == 2 ? (wave & 1) * 4 : wave * MM;
+    f32x16_t acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    dma_patch(0, 0);
+    // weight fragments: block (slice, tap, kk, nt) of 64 lanes x 16 B, straight from L2
+    const u32x4_t* wl = (const u32x4_t*)a.wp + lane + nsel * 64;
+    auto wfrag = [&](int s, int t, int kk) { return wl[((long)(s * TAPS + t) * 2 + kk) * (NT * 64)]; };
+    // ring of fragments in VISITING order (tap column dx outer, tap row dy inner): the 3x3 / 1x1 kernels hold a whole slice (<= 72 VGPRs, all
+    // requested before the next slice's DMA), the 5x5 / 7x7 kernels one tap column (slot dy, refilled with the next column right after use)
+    constexpr bool WHOLE = TAPS <= 9;
+    constexpr int RS = WHOLE ? TAPS : K;
+    u32x4_t bq[RS][2];
+    if constexpr (!WHOLE) {
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bq[dy][kk] = wfrag(0, dy * K, kk);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WHOLE ? 0 : 2 * K) : "memory");     // the patch of slice 0 (the ring may still be in flight)
+    __syncthreads();
+
+    constexpr int WR = MM + 1;                                     // window rows in registers
+    u32x4_t win[WR][2];
+    // pixel row J of this wave's patch rows (tap column DX) -> window slot
+#define PF2_LDROW(J, SLOT, DX)                                                                                         \
+    {                                                                                                                  \
+        const int p_ = (mrow0 + (J)) * PW + (DX) + r;                                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) win[SLOT][kk] = *(const u32x4_t*)(P + swz_off(p_, 2 * kk + h)); \
+    }
+#define PF2_MFMAS(DY, BQ)                                                                                              \
+    _Pragma("unroll") for (int m = 0; m < MM; ++m)                                                                     \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                               \
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (BQ)[kk]),                   \
+                                                             __builtin_bit_cast(bf16x8_t, win[((DY) + m) % WR][kk]), acc[m], 0, 0, 0);
+    if constexpr (WHOLE) {
+        // The compiler does not count LDS-DMA in its s_waitcnt bookkeeping, and beside a DMA it drains vmcnt(0) in front of every use of an
+        // ordinary load: the fragment loads of these kernels are hidden from it in asm statements and waited for by hand.  Fragment pair Q of
+        // the visiting order has landed when at most the operations issued after it are outstanding: the later pairs and, when there is a
+        // next slice (MORE), its NDMA patch instructions.  ONE wait statement per pair, in straight-line code between the load and the MFMAs
+        // and naming the pair as read-write operands: with the wait in two arms of a branch the compiler copied the (not yet loaded)
+        // registers in front of one of them.
+#define PF2_TAP(DX, DY, MORE)                                                                                          \
+        if constexpr ((DX) < K && (DY) < K) {                                                                          \
+            constexpr int Q = ((DX) < K && (DY) < K) ? (DX) * K + (DY) : 0;                                            \
+            if ((DY) + 1 < K) PF2_LDROW((DY) + MM, ((DY) + MM) % WR, DX)                                               \
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq[Q][0]), "+v"(bq[Q][1]) : "n"(2 * (TAPS - 1 - Q) + ((MORE) ? NDMA : 0)) : "memory"); \
+            PF2_MFMAS(DY, bq[Q])                                                                                       \
+        }
+#define PF2_COLUMN(DX, MORE)                                                                                           \
+        if constexpr ((DX) < K) {                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < MM; ++j) PF2_LDROW(j, j, DX)                                         \
+            PF2_TAP(DX, 0, MORE) PF2_TAP(DX, 1, MORE) PF2_TAP(DX, 2, MORE)                                             \
+        }
+#define PF2_SLICE(S, MORE)                                                                                             \
+        {                                                                                                              \
+            const char* P = smem + (((S) & 1) * PBYTES);                                                               \
+            _Pragma("unroll") for (int dx = 0; dx < K; ++dx)                                                           \
+                _Pragma("unroll") for (int dy = 0; dy < K; ++dy)                                                       \
+                    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                 \
+                        const u32x4_t* src = wl + ((long)((S) * TAPS + dy * K + dx) * 2 + kk) * (NT * 64);             \
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[dx * K + dy][kk]) : "v"(src) : "memory"); \
+                    }                                                                                                  \
+            if (MORE) dma_patch((S) + 1, ((S) + 1) & 1);                                                               \
+            PF2_COLUMN(0, MORE) PF2_COLUMN(1, MORE) PF2_COLUMN(2, MORE)                                                \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* the next slice's patch has landed */            \
+            __syncthreads();                                                                                           \
+        }
+        static_assert(NBUF == 2, "the whole-slice kernels double-buffer the patch");
+        for (int s = 0; s + 1 < nslices; ++s) PF2_SLICE(s, true)
+        PF2_SLICE(nslices - 1, false)
+#undef PF2_SLICE
+#undef PF2_COLUMN
+#undef PF2_TAP
+    } else {
+        for (int s = 0; s < nslices; ++s) {
+            const char* P = smem + (NBUF == 2 ? (s & 1) * PBYTES : 0);
+            const bool more = s + 1 < nslices;                     // (wave-uniform)
+            if (more) dma_patch(s + 1, (s + 1) & 1);
+            auto taps_of_column = [&](int dx, bool last_column) {
+#pragma unroll
+                for (int j = 0; j < MM; ++j) PF2_LDROW(j, j, dx)
+#pragma unroll
+                for (int dy = 0; dy < K; ++dy) {
+                    if (dy + 1 < K) PF2_LDROW(dy + MM, (dy + MM) % WR, dx)     // next tap row's new pixel row, a tap ahead of its first MFMA
+                    PF2_MFMAS(dy, bq[dy])
+                    // refill: the same tap row of the next column, or of the next slice's first column
+                    if (!last_column) {
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) bq[dy][kk] = wfrag(s, dy * K + dx + 1, kk);
+                    } else if (more) {
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) bq[dy][kk] = wfrag(s + 1, dy * K, kk);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int dx = 0; dx < K - 1; ++dx) taps_of_column(dx, false);
+            taps_of_column(K - 1, true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next slice's patch has landed (and nothing else is outstanding)
+            __syncthreads();
+        }
+    }
+#undef PF2_MFMAS
+#undef PF2_LDROW
+
+    // ---- epilogue: lane (r, h) holds, for pixel r of row m, channels nsel*32 + 8g + 4h + (0..3) in acc[m][4g .. 4g+3]
+    {
+        float bv[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = nsel * 32 + 8 * g + 4 * h + j;
+                bv[g][j] = (a.bias && ch < a.N) ? a.bias[ch] : 0.f;
+            }
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t v;
+                v[0] = pack2bf(acc[m][4 * g] + bv[g][0], acc[m][4 * g + 1] + bv[g][1]);
+                v[1] = pack2bf(acc[m][4 * g + 2] + bv[g][2], acc[m][4 * g + 3] + bv[g][3]);
+                *(u32x2_t*)(smem + ((mrow0 + m) * TW + r) * OSTR + (nsel * 32 + 8 * g + 4 * h) * 2) = v;
+            }
+    }
+    __syncthreads();
+    constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
+    const int cpp = a.N >> 3;                                      // valid chunks per pixel
+    const int c = tid % (NT * 4);
+#pragma unroll
+    for (int i = 0; i < OCH / 256; ++i) {
+        const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
+        const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
+        if (yy < a.H && c < cpp) {
+            u32x4_t v16 = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
             if (a.accum) {
                 float vn[8], vo[8];
                 unpack16<bf16_t>(v16, vn);
@@ -359,16 +586,26 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
 int g_patch_wgrad_wgs = 512;                         // development knob (mte_debug_set(12, v))
 int g_patch_tall = 1;                                // development knob (mte_debug_set(11, v))
 
+int g_patch_fwd2 = 1;                                // development knob (mte_debug_set(11, 400 + v)): 0 = the first form of the forward kernel
+
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
+    // the second form addresses the input through a buffer descriptor (< 2 GiB)
+    // Same-box A/B over the network's shapes (tools/conv_shape_bench.py): 7x7 -12..-15 %, 5x5 -8..-12 %, 3x3 with 32 outputs -4..-12 %, 3x3
+    // with 64 outputs -8 % from three slices on; with one or two slices the first form wins by 8-15 % (167 VGPRs, three workgroups per CU,
+    // against 244), and the 1x1 layers are HBM-bound either way
+    const bool v2 = g_patch_fwd2 && (K >= 5 || (K == 3 && (NT == 1 || a.Cin_p > 64))) &&
+                    (((long)a.B * a.H * a.W - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L;
     if constexpr (NT == 1) {
         if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
-            hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             return mte_check_launch();
         }
     }
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
-    hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     return mte_check_launch();
 }
 template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
@@ -457,7 +694,7 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 }  // namespace
 
 #ifdef MTE_DEV
-extern "C" int mtei_set_patch_tall(int v) { if (v >= 300 && v < 310) { g_patch_wgrad_wide = v - 300; return MTE_OK; } if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
+extern "C" int mtei_set_patch_tall(int v) { if (v >= 400 && v < 410) { g_patch_fwd2 = v - 400; return MTE_OK; } if (v >= 300 && v < 310) { g_patch_wgrad_wide = v - 300; return MTE_OK; } if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
 #endif
 
 extern "C" {

@@ -158,7 +158,7 @@ def round8(c):
 
 def new_act(B, C, H, W, dtype=None, device="cuda"):
     """Uninitialised NHWC activation with logical shape [B,C,H,W]."""
-    return torch.empty((B, H, W, C), dtype=dtype or compute_dtype(), device=device).permute(0, 3, 1, 2)
+    return torch.empty_strided((B, C, H, W), (H * W * C, 1, W * C, C), dtype=dtype or compute_dtype(), device=device)   # (one operator, not empty + permute)
 
 
 def alias_of(t):
@@ -252,8 +252,15 @@ class _ZeroArena:
             if c is not None and c[2] is not None:
                 self.captured.append(c[0])                   # a captured graph keeps replaying into this chunk: never hand it back
             c = self.chunks[key] = [torch.zeros((self.CHUNK,), dtype=torch.uint8, device=device), 0,
-                                    self.capture_id if capturing else None]
-        out = c[0][c[1]:c[1] + nbytes].view(dtype)[:n].view(shape)
+                                    self.capture_id if capturing else None, {}]
+        typed = c[3].get(dtype)
+        if typed is None:
+            typed = c[3][dtype] = c[0].view(dtype)
+        strides, acc = [], 1
+        for d in reversed(shape):
+            strides.append(acc)
+            acc *= d
+        out = typed.as_strided(shape, strides[::-1], c[1] // _ELEM_SIZE[dtype])     # (one operator per buffer: ~190 of them per training step)
         c[1] += nbytes
         return out
 
