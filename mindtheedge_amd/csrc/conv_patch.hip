@@ -18,6 +18,24 @@
 #include "common.hpp"
 #include <type_traits>
 
+// In-kernel phase stamps of the forward kernels: a separate diagnostic build only (-DMTE_STAMPS, tools/patch_stamps.py); no stamp executes in
+// the product or the development library.  Thread 0 of a workgroup stores s_memrealtime (100 MHz) at each phase boundary.
+#ifdef MTE_STAMPS
+__device__ unsigned long long g_patch_stamps[16384 * 16];
+extern "C" int mtei_patch_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_patch_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#define PATCH_STAMP_DECL int stamp_i_ = 0
+#define PATCH_STAMP()                                                                                                              \
+    {                                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 16384 && stamp_i_ < 16) g_patch_stamps[blockIdx.x * 16 + stamp_i_] = __builtin_amdgcn_s_memrealtime(); \
+        ++stamp_i_;                                                                                                                 \
+    }
+#else
+#define PATCH_STAMP_DECL
+#define PATCH_STAMP()
+#endif
+
 namespace {
 
 constexpr int TH = 8, TW = 32;                     // output tile (pixels)
@@ -98,9 +116,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
+    PATCH_STAMP_DECL;
+    PATCH_STAMP();
     load_patch(0);
     store_patch(0);
     __syncthreads();
+    PATCH_STAMP();
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane;               // fragment block = 64 lanes x 16 B
     for (int s = 0; s < nslices; ++s) {
         const char* P = smem + (s & 1) * PBYTES;
@@ -140,8 +161,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
                 }
             }
         }
+        PATCH_STAMP();
         if (s + 1 < nslices) store_patch((s + 1) & 1);
         __syncthreads();
+        PATCH_STAMP();
     }
     // ---- epilogue: stage the tile as bf16 [pixel][N] in LDS, then 16-byte coalesced stores
     constexpr int NB = NT * 64;                                    // bytes per pixel
@@ -177,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
             *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
         }
     }
+    PATCH_STAMP();
 }
-
 
 // ---- forward / dgrad, second form (round 3) ------------------------------------------------------------------------
 // In-kernel stamps of the first form (3 slices of a 3x3 filter, 16 x 32 tile, two workgroups per CU) put a tile at 21.8 us: 2.9 us of
@@ -260,9 +283,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
+    PATCH_STAMP_DECL;
+    PATCH_STAMP();
     dma_patch(0, 0);
     // weight fragments: block (slice, tap, kk, nt) of 64 lanes x 16 B, straight from L2
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane + nsel * 64;
+    const unsigned wlane = (unsigned)(lane + nsel * 64) * 16u;      // this lane's byte offset inside a fragment block
     auto wfrag = [&](int s, int t, int kk) { return wl[((long)(s * TAPS + t) * 2 + kk) * (NT * 64)]; };
     // ring of fragments in VISITING order (tap column dx outer, tap row dy inner): the 3x3 / 1x1 kernels hold a whole slice (<= 72 VGPRs, all
     // requested before the next slice's DMA), the 5x5 / 7x7 kernels one tap column (slot dy, refilled with the next column right after use)
@@ -277,9 +303,21 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WHOLE ? 0 : 2 * K) : "memory");     // the patch of slice 0 (the ring may still be in flight)
     __syncthreads();
+    PATCH_STAMP();
 
     constexpr int WR = MM + 1;                                     // window rows in registers
     u32x4_t win[WR][2];
+    // bias of the 16 channels this lane owns, as four 16-byte loads issued behind the last slice's MFMAs (its wait + barrier cover them; as 16
+    // guarded scalar loads at the top of the epilogue they cost the tile 1.3-2 us)
+    f32x4_t bv4[4];
+    auto load_bias = [&]() {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch0 = nsel * 32 + 8 * g + 4 * h;             // (N % 8 == 0: a group of four is inside or outside as a whole)
+            const f32x4_t v = *(const f32x4_t*)((a.bias ? a.bias : (const float*)a.wp) + (ch0 < a.N ? ch0 : 0));
+            bv4[g] = (a.bias && ch0 < a.N) ? v : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     // pixel row J of this wave's patch rows (tap column DX) -> window slot
 #define PF2_LDROW(J, SLOT, DX)                                                                                         \
     {                                                                                                                  \
@@ -316,13 +354,17 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
             _Pragma("unroll") for (int dx = 0; dx < K; ++dx)                                                           \
                 _Pragma("unroll") for (int dy = 0; dy < K; ++dy)                                                       \
                     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                 \
-                        const u32x4_t* src = wl + ((long)((S) * TAPS + dy * K + dx) * 2 + kk) * (NT * 64);             \
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[dx * K + dy][kk]) : "v"(src) : "memory"); \
+                        /* scalar base of the fragment block + one per-lane byte offset for all of them (18 VGPR pointer pairs otherwise) */ \
+                        const char* blk = (const char*)a.wp + (((long)((S) * TAPS + dy * K + dx) * 2 + kk) * NT) * 1024;   \
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[dx * K + dy][kk]) : "v"(wlane), "s"(blk) : "memory"); \
                     }                                                                                                  \
             if (MORE) dma_patch((S) + 1, ((S) + 1) & 1);                                                               \
             PF2_COLUMN(0, MORE) PF2_COLUMN(1, MORE) PF2_COLUMN(2, MORE)                                                \
+            if (!(MORE)) load_bias();                                                                                  \
+            PATCH_STAMP();                                                                                             \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* the next slice's patch has landed */            \
             __syncthreads();                                                                                           \
+            PATCH_STAMP();                                                                                             \
         }
         static_assert(NBUF == 2, "the whole-slice kernels double-buffer the patch");
         for (int s = 0; s + 1 < nslices; ++s) PF2_SLICE(s, true)
@@ -355,8 +397,11 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 #pragma unroll 1
             for (int dx = 0; dx < K - 1; ++dx) taps_of_column(dx, false);
             taps_of_column(K - 1, true);
+            if (!more) load_bias();
+            PATCH_STAMP();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next slice's patch has landed (and nothing else is outstanding)
             __syncthreads();
+            PATCH_STAMP();
         }
     }
 #undef PF2_MFMAS
@@ -364,21 +409,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 
     // ---- epilogue: lane (r, h) holds, for pixel r of row m, channels nsel*32 + 8g + 4h + (0..3) in acc[m][4g .. 4g+3]
     {
-        float bv[4][4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ch = nsel * 32 + 8 * g + 4 * h + j;
-                bv[g][j] = (a.bias && ch < a.N) ? a.bias[ch] : 0.f;
-            }
 #pragma unroll
         for (int m = 0; m < MM; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2_t v;
-                v[0] = pack2bf(acc[m][4 * g] + bv[g][0], acc[m][4 * g + 1] + bv[g][1]);
-                v[1] = pack2bf(acc[m][4 * g + 2] + bv[g][2], acc[m][4 * g + 3] + bv[g][3]);
+                v[0] = pack2bf(acc[m][4 * g] + bv4[g][0], acc[m][4 * g + 1] + bv4[g][1]);
+                v[1] = pack2bf(acc[m][4 * g + 2] + bv4[g][2], acc[m][4 * g + 3] + bv4[g][3]);
                 *(u32x2_t*)(smem + ((mrow0 + m) * TW + r) * OSTR + (nsel * 32 + 8 * g + 4 * h) * 2) = v;
             }
     }
@@ -403,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
             *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
         }
     }
+    PATCH_STAMP();
 }
 
 // generic pack [N][taps][Cin_p] -> fragment blocks [slice][tap][kk][nt][lane = h*32 + r][8]
@@ -586,7 +624,12 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
 int g_patch_wgrad_wgs = 512;                         // development knob (mte_debug_set(12, v))
 int g_patch_tall = 1;                                // development knob (mte_debug_set(11, v))
 
-int g_patch_fwd2 = 1;                                // development knob (mte_debug_set(11, 400 + v)): 0 = the first form of the forward kernel
+#ifdef MTE_PATCH_FWD1
+int g_patch_fwd2 = 0;                                // (diagnostic builds: tools/patch_stamps.py v1)
+#else
+int g_patch_fwd2 = 1;
+#endif
+//                               // development knob (mte_debug_set(11, 400 + v)): 0 = the first form of the forward kernel
 
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
     // the second form addresses the input through a buffer descriptor (< 2 GiB)
@@ -594,7 +637,7 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
     // with 64 outputs -8 % from three slices on; with one or two slices the first form wins by 8-15 % (167 VGPRs, three workgroups per CU,
     // against 244), and the 1x1 layers are HBM-bound either way
     const bool v2 = g_patch_fwd2 && (K >= 5 || (K == 3 && (NT == 1 || a.Cin_p > 64))) &&
-                    (((long)a.B * a.H * a.W - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L;
+                    (((long)a.B * a.H * a.W - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((uintptr_t)a.bias & 15) == 0;   // (it reads the bias in 16-byte groups)
     if constexpr (NT == 1) {
         if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
