@@ -22,6 +22,17 @@
 // slot c ^ ((r>>2)&3), which makes every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
 #include "common.hpp"
 
+// In-loop s_memtime sums of the DMA main loop (diagnostic build only: -DMTE_STAMPS, tools/igemm_stamps.py).  Round-3 reading, cycles per K-step
+// and wave: 256 x 128 tile (512 -> 512 @24x80) stage wait 57 | barrier 314 | DMA issue 267 | fragment reads + MFMA issue 468 | total 1192
+// (MFMA pipe busy 512); 256 x 256 tile (256 -> 256 @48x160) 68 | 861 | 207 | 484 | 1707 (pipe busy 1024).  Issuing the DMA behind the MFMAs
+// instead of in front of the fragment reads was tried on that evidence and lost 1.7 % (same-box A/B), s_setprio around the MFMAs 0.7 %.
+#ifdef MTE_STAMPS
+__device__ unsigned long long g_igemm_stamps[16384 * 8];
+extern "C" int mtei_igemm_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -366,7 +377,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p)
             if (p < nst) { if constexpr (LD == 2) dma_fast(s_begin + p, p); else dma_step(s_begin + p, p); }
+#ifdef MTE_STAMPS
+        unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_cmp = 0, t_a, t_b;
+        const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
         for (int i = 0; i < nst; ++i) {
+#ifdef MTE_STAMPS
+            t_a = __builtin_amdgcn_s_memtime();
+#endif
             const int rem = nst - 1 - i;                   // stages issued after stage i and possibly still in flight: min(rem, AHEAD - 1)
             if constexpr (ST == 6) {
                 if (rem >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPS) : "memory");
@@ -382,11 +400,32 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
                 if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+#ifdef MTE_STAMPS
+            t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; t_a = t_b;
+#endif
             __builtin_amdgcn_s_barrier();
+#ifdef MTE_STAMPS
+            t_b = __builtin_amdgcn_s_memtime(); t_bar += t_b - t_a; t_a = t_b;
+#endif
             if constexpr (!(ABL & 2))
             if (i + AHEAD < nst) { if constexpr (LD == 2) dma_fast(s_begin + i + AHEAD, (i + AHEAD) % ST); else dma_step(s_begin + i + AHEAD, (i + AHEAD) % ST); }
+#ifdef MTE_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            t_b = __builtin_amdgcn_s_memtime(); t_dma += t_b - t_a; t_a = t_b;
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             compute(i % ST);
+#ifdef MTE_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            t_b = __builtin_amdgcn_s_memtime(); t_cmp += t_b - t_a;
+#endif
         }
+#ifdef MTE_STAMPS
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
+            unsigned long long* o = g_igemm_stamps + ((long)blockIdx.x * 4 + (threadIdx.x >> 6) % 4) * 8;   // first four waves of a workgroup
+            if ((threadIdx.x >> 6) < 4) { o[0] = t_wait; o[1] = t_bar; o[2] = t_dma; o[3] = t_cmp; o[4] = __builtin_amdgcn_s_memtime() - t_start; o[5] = nst; }
+        }
+#endif
     } else {
         if (s_begin < s_end) {
             load_step(s_begin); store_step(0);
