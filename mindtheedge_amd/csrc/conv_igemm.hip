@@ -302,19 +302,22 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 #pragma unroll
         for (int j = 0; j < AN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, q16 = lane >> 4;
-    auto compute = [&](int slot) {
+    u32x4_t fa[AM], fb[AN];
+    auto read_frags = [&](int slot) {
         const char* pA = sA + slot * BM * 64;
         const char* pB = sB + slot * BN * 64;
-        u32x4_t fa[AM], fb[AN];
 #pragma unroll
         for (int i = 0; i < AM; ++i) fa[i] = *(const u32x4_t*)(pA + lds_chunk_off((wm * AM + i) * 16 + r16, q16));
 #pragma unroll
         for (int j = 0; j < AN; ++j) fb[j] = *(const u32x4_t*)(pB + lds_chunk_off((wn * AN + j) * 16 + r16, q16));
+    };
+    auto mfmas = [&]() {
 #pragma unroll
         for (int i = 0; i < AM; ++i)
 #pragma unroll
             for (int j = 0; j < AN; ++j) Mma16<T>::run(fa[i], fb[j], acc[i][j]);
     };
+    auto compute = [&](int slot) { read_frags(slot); mfmas(); };
     // element e of block (i, j): tile row / column
     auto acc_row = [&](int i, int e) { return (wm * AM + i) * 16 + 4 * q16 + e; };
     auto acc_col = [&](int j) { return (wn * AN + j) * 16 + r16; };
@@ -377,6 +380,47 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p)
             if (p < nst) { if constexpr (LD == 2) dma_fast(s_begin + p, p); else dma_step(s_begin + p, p); }
+#if MTE_IGEMM_MFMA16
+        // PING-PONG form (round 3; the 8-wave 256 x 256 tile: two wave groups = the two M halves, waves g and g + 4 share a SIMD).  In-loop
+        // stamps of the one-barrier loop showed every wave of a workgroup issuing its DMA (207-267 cycles) and its fragment reads together
+        // with the MFMA pipe idle, then all queueing on it (pipe busy 43-60 % of a K-step).  Here a K-step is two half-steps separated by a
+        // barrier: group 0 reads the fragments of K-step k and issues its part of stage k + 3 while group 1 runs the MFMAs of K-step
+        // k - 1, then they swap -- one group's loads always sit under the other group's MFMAs.  Hazards: a wave finishes its fragment
+        // reads (lgkmcnt(0)) BEFORE the barrier that ends its load phase, so the slot of K-step k - 1 is free for the DMA of stage k + 3
+        // from the next half-step on; every wave waits for its parts of stage k + 1 before the barrier that ends the half-step in which
+        // it handled K-step k, which is at least one barrier before anyone reads that stage.
+        constexpr bool PP = LD == 2 && WM == 2 && WN == 4 && TM == 4 && TN == 2 && ST == 4;
+        if constexpr (PP) {
+            const int grp = __builtin_amdgcn_readfirstlane(wm);
+            {   // stage 0 has landed
+                if (nst >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+                else if (nst == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            // both groups run the same body -- load phase, barrier, MFMA phase, barrier -- group 1 one barrier behind group 0.
+            // (Issuing half of the stage's DMA behind the MFMAs instead -- the load phase is the longer one -- was tried: 66 -> 73 us on the
+            //  256 -> 256 layer; a DMA instruction behind the wave's own MFMAs is slower still.)
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            for (int k = 0; k < nst; ++k) {
+                const int rem = nst - 2 - k;                   // stages this wave has issued behind stage k + 1: min(rem, 2)
+                read_frags(k % ST);
+                if (k + AHEAD < nst) dma_fast(s_begin + k + AHEAD, (k + AHEAD) % ST);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (group 1 ends its load phase right before group 0 reads stage k + 1: its parts of that stage must be in)
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                mfmas();
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();
+        } else {
+#endif
 #ifdef MTE_STAMPS
         unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_cmp = 0, t_a, t_b;
         const unsigned long long t_start = __builtin_amdgcn_s_memtime();
@@ -425,6 +469,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             unsigned long long* o = g_igemm_stamps + ((long)blockIdx.x * 4 + (threadIdx.x >> 6) % 4) * 8;   // first four waves of a workgroup
             if ((threadIdx.x >> 6) < 4) { o[0] = t_wait; o[1] = t_bar; o[2] = t_dma; o[3] = t_cmp; o[4] = __builtin_amdgcn_s_memtime() - t_start; o[5] = nst; }
         }
+#endif
+#if MTE_IGEMM_MFMA16
+        }   // !PP
 #endif
     } else {
         if (s_begin < s_end) {
@@ -610,6 +657,7 @@ launched:
 }
 
 int g_igemm_big_min_tiles = 224;
+int g_igemm_pp = 1;                                  // development knob (mte_debug_set(21, v)): 0 = the 16-wave one-barrier loop on the 256 x 256 tile
 int g_igemm_big = 3;                                 // development knob (mte_debug_set(6, v)): 0 128x128 only, 1 + 256x128, 2 + 256x256, 3 + 192x96
 
 template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipStream_t st) {
@@ -634,6 +682,10 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         const long reach256 = t256 * (can_split ? (ksteps / 16 < smax ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : smax) : 1);
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
             (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160)))   // (96: below it choose_splits does split)
+            // enough tiles without a K split: 8 waves of 128 x 64 in the ping-pong loop (same-box A/B per layer: 256 -> 256 3x3 @48x160
+            // 70.2 -> 66 us, 384 -> 256 106 -> 95-101, 5x5 64 -> 256 @96x320 226 -> 212, 128 -> 512 @48x160 203 -> 189); the split-K
+            // launches (few tiles, short per-split reductions) lose with it and keep the 16-wave one-barrier loop
+            if (g_igemm_pp && t256 >= g_igemm_big_min_tiles) return launch_igemm<T, 2, 4, 4, 2>(a, 0, st);
             return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st);   // 256 x 256, 16 waves (8 waves of 128 x 64: 7.82 vs 7.65 ms / step, not kept)
         // 65..96 columns (the 72-channel decoder concat as data-gradient N): a 192 x 96 tile of 6 waves wastes a quarter of
         // the MFMA work instead of the 44 % a 128-wide tile does
@@ -1449,6 +1501,7 @@ int mte_debug_set(int key, int value) {
     if (key == 15) { g_igemm_ring6 = value; return MTE_OK; }
     if (key == 17) { g_igemm_ablate = value; return MTE_OK; }
     if (key == 19) { g_igemm_pair_ksteps = value; return MTE_OK; }
+    if (key == 21) { g_igemm_pp = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }

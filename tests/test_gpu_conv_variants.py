@@ -142,6 +142,42 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape, devlib):
         K.use_patch_kernels(True)
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 3, 8, 48, 160), (64, 256, 5, 2, 96, 320), (96, 512, 3, 3, 10, 52), (128, 256, 1, 8, 48, 160)])
+def test_igemm_pingpong_loop_matches_one_barrier_loop(shape, devlib):
+    """The 8-wave ping-pong form of the 256x256 tile (two wave groups half a K-step apart, round 3) against the 16-wave one-barrier form and
+    the 4-wave 128x128 tiles: same K order and fp32 accumulation chain per output, so all three are bit-identical -- repeated, because a
+    stale ring slot or a fragment read that overtakes its DMA would show on some launches only (tools/igemm_race_stress.py screens longer)."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W = shape
+    g = torch.Generator().manual_seed(11 + cin + cout)
+    w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+    b = (torch.rand(cout, generator=g) - 0.5).cuda()
+    xa = K.image_to_act(torch.rand(B, cin, H, W, generator=g).cuda() * 2 - 1)
+    pack = K.WeightPack()
+    wf, _ = pack.get(w, xa.dtype, False)
+    orig, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)
+    K.use_patch_kernels(False)
+
+    def run(big, pp):
+        K.lib.mte_debug_set(6, big)
+        K.lib.mte_debug_set(7, 1)
+        K.lib.mte_debug_set(21, pp)
+        y = K.conv_forward(xa, wf, b, cout, k, k)
+        torch.cuda.synchronize()
+        return y
+    try:
+        ref = run(0, 0).clone()
+        for rep in range(6):
+            assert torch.equal(run(2, 1), ref), "ping-pong loop, repetition %d" % rep
+            assert torch.equal(run(2, 0), ref), "16-wave loop, repetition %d" % rep
+    finally:
+        K._splitk_workspace = orig
+        K.use_patch_kernels(True)
+        K.lib.mte_debug_set(6, 3)
+        K.lib.mte_debug_set(7, 224)
+        K.lib.mte_debug_set(21, 1)
+
+
 @pytest.mark.parametrize("shape", [(512, 256, 3, 4, 32, 40), (1024, 512, 3, 2, 40, 64)])
 def test_big_tile_split_k_matches_small_tiles(shape, devlib):
     """Few output tiles + a long reduction (the pack4/pack5.conv regime): 256x256 tiles with the K range split over

@@ -95,3 +95,18 @@ for ev in prof.events():
 print("device activities:", sum(kern.values()))
 for n, c in kern.most_common(25):
     print("%4d  %s" % (c, n))
+
+# ---- host profile of three steps (cProfile, cumulative time per function of this package)
+import cProfile  # noqa: E402
+import pstats  # noqa: E402
+import io  # noqa: E402
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+sio = io.StringIO()
+pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(45)
+print("\n".join(l for l in sio.getvalue().splitlines() if l.strip())[:9000])
