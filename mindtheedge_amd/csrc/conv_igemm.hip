@@ -681,12 +681,13 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         if (smax > 8) smax = 8;
         const long reach256 = t256 * (can_split ? (ksteps / 16 < smax ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : smax) : 1);
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
-            (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160)))   // (96: below it choose_splits does split)
+            (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160))) {   // (96: below it choose_splits does split)
             // enough tiles without a K split: 8 waves of 128 x 64 in the ping-pong loop (same-box A/B per layer: 256 -> 256 3x3 @48x160
             // 70.2 -> 66 us, 384 -> 256 106 -> 95-101, 5x5 64 -> 256 @96x320 226 -> 212, 128 -> 512 @48x160 203 -> 189); the split-K
             // launches (few tiles, short per-split reductions) lose with it and keep the 16-wave one-barrier loop
             if (g_igemm_pp && t256 >= g_igemm_big_min_tiles) return launch_igemm<T, 2, 4, 4, 2>(a, 0, st);
-            return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st);   // 256 x 256, 16 waves (8 waves of 128 x 64: 7.82 vs 7.65 ms / step, not kept)
+            return launch_igemm<T, 4, 4, 2, 2>(a, t256 >= g_igemm_big_min_tiles ? 0 : ws_elems, st);   // 256 x 256, 16 waves
+        }
         // 65..96 columns (the 72-channel decoder concat as data-gradient N): a 192 x 96 tile of 6 waves wastes a quarter of
         // the MFMA work instead of the 44 % a 128-wide tile does
         if (g_igemm_big >= 3 && dma_ok && !a.out_f32 && a.N > 64 && a.N <= 96 && ((a.M + 191) / 192) >= g_igemm_big_min_tiles)
