@@ -25,6 +25,7 @@ raw = ctypes.CDLL(so)
 B = 8
 K.use_patch_kernels(False)
 shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(512, 512, 3, 24, 80), (256, 256, 3, 48, 160), (128, 128, 3, 96, 320), (64, 256, 5, 96, 320), (4096, 256, 3, 24, 80)]
+prev = None
 for shp in shapes:
     cin, cout, k, H, W = shp[:5]
     cp = K.round8(cin)
@@ -45,9 +46,13 @@ for shp in shapes:
     arr = (ctypes.c_ulonglong * n)()
     assert raw.mtei_igemm_stamps(arr, n) == 0
     a = np.frombuffer(arr, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
+    if prev is not None and np.array_equal(a, prev):
+        print("%d -> %d k%d @%dx%d: not stamped (this launch took the ping-pong loop or a split-K / fp32 path)" % (cin, cout, k, H, W))
+        continue
+    prev = a.copy()
     a = a[a[:, 5] > 0]
     ks = a[:, 5]
     per = a[:, :5] / ks[:, None]
     m = np.median(per, axis=0)
-    print("%d -> %d k%d @%dx%d: %d waves stamped, %d K-steps; cycles per K-step (median, 100 MHz s_memtime ticks x ~21 = shader clocks): "
-          "stage wait %.1f | barrier %.1f | DMA issue %.1f | reads+MFMA issue %.1f | total %.1f  (ticks)" % (cin, cout, k, H, W, len(a), int(np.median(ks)), m[0], m[1], m[2], m[3], m[4]))
+    print("%d -> %d k%d @%dx%d: %d waves stamped, %d K-steps; s_memtime cycles per K-step and wave (median): "
+          "stage wait %.1f | barrier %.1f | DMA issue %.1f | fragment reads + MFMA issue %.1f | total %.1f" % (cin, cout, k, H, W, len(a), int(np.median(ks)), m[0], m[1], m[2], m[3], m[4]))
