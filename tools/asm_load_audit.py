@@ -1,45 +1,81 @@
 #!/usr/bin/env python3
-"""development aid: audit of the hand-waited asm loads of conv_patch_fwd2_kernel (3x3 / 1x1 forms) in the compiler's .s output.
+"""Audit of the hand-waited asm loads of conv_patch_fwd2_kernel (3x3 / 1x1 forms) in the compiler's .s output.
 
-hipcc does not model an asm load: the destination counts as written at the end of the statement, so the register allocator may copy or
-read it before the data lands.  For every `global_load_dwordx4 v[a:b]` inside an ASMSTART/ASMEND pair this walks forward to the first asm
-`s_waitcnt vmcnt` statement whose tied operands... (the .s does not name them) -- conservatively: to the next asm s_waitcnt that follows at
-least one MFMA-free stretch -- and reports any instruction in between that READS v[a:b].  usage: asm_load_audit.py file.s"""
+hipcc does not model an `asm volatile` load: its destination counts as written at the end of the statement, so the register allocator may
+copy or read it before the data lands, and the wait that covers it is ours to count.  This walks each kernel's instruction stream in text
+order (the tap code of a slice is straight-line; every slice ends with s_waitcnt vmcnt(0), so nothing is outstanding across the loop's back
+edge) and keeps the queue of outstanding vector-memory operations exactly as the hardware does -- loads, LDS-DMA and stores retire in issue
+order, `s_waitcnt vmcnt(N)` leaves at most the N youngest outstanding -- and reports every instruction that READS the destination of an asm
+load still in the queue.  usage: asm_load_audit.py file.s   (exit code 1 on a finding; tests/test_asm_audit.py runs it on a fresh compile)"""
 import re
 import sys
 
-txt = open(sys.argv[1]).read()
-bad = 0
-for m in re.finditer(r"^(_ZN\S*conv_patch_fwd2_kernelILi([13])\S*):.*?s_endpgm", txt, re.S | re.M):
-    name, body = m.group(1), m.group(0).splitlines()
-    in_asm, loads = False, []                      # (line index, lo, hi)
-    for i, l in enumerate(body):
-        if "#ASMSTART" in l:
-            in_asm = True
-        elif "#ASMEND" in l:
-            in_asm = False
-        elif in_asm:
-            g = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
-            if g:
-                loads.append((i, int(g.group(1)), int(g.group(2))))
-    checked = 0
-    for i, lo, hi in loads:
-        # the wait for this pair is the first asm s_waitcnt AFTER which an MFMA reads the register; until that MFMA nothing may read it
-        j = i + 1
-        waited = False
-        while j < len(body):
-            l = body[j]
-            if "s_waitcnt vmcnt" in l and "#ASM" in body[j - 1]:
-                waited = True
-            regs = [(int(a), int(b)) for a, b in re.findall(r"v\[(\d+):(\d+)\]", l)] + [(int(a), int(a)) for a in re.findall(r"\bv(\d+)\b", l)]
-            reads = any(not (b < lo or a > hi) for a, b in regs)
-            if reads and "global_load_dwordx4 v[%d:%d]" % (lo, hi) not in l:
-                if not waited:
-                    print("%s: line %d reads v[%d:%d] before any asm wait: %s" % (name[:60], j, lo, hi, l.strip()))
-                    bad += 1
-                break
-            j += 1
-        checked += 1
-    print("%s: %d asm loads checked" % (name[-40:], checked))
-print("PROBLEMS: %d" % bad)
-sys.exit(1 if bad else 0)
+VMEM = re.compile(r"^\s*(global_load|global_store|buffer_load|buffer_store|global_atomic|buffer_atomic|scratch_load|scratch_store|flat_load|flat_store)")
+WAIT = re.compile(r"s_waitcnt.*vmcnt\((\d+)\)")
+REG = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs_of(text):
+    out = []
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.append((int(m.group(1)), int(m.group(2))))
+        else:
+            out.append((int(m.group(3)), int(m.group(3))))
+    return out
+
+
+def audit(txt, pattern=r"conv_patch_fwd2_kernelILi[13]"):
+    findings, checked = [], 0
+    for m in re.finditer(r"^(_ZN\S*" + pattern + r"\S*):.*?s_endpgm", txt, re.S | re.M):
+        name, body = m.group(1), m.group(0).splitlines()
+        queue = []                                     # outstanding vmem operations, oldest first: (lo, hi) of an asm load's destination or None
+        in_asm = False
+        for ln, l in enumerate(body):
+            code = l.split(";")[0]
+            if "#ASMSTART" in l:
+                in_asm = True
+                continue
+            if "#ASMEND" in l:
+                in_asm = False
+                continue
+            w = WAIT.search(code)
+            if w:
+                n = int(w.group(1))
+                while len(queue) > n:
+                    queue.pop(0)
+                continue
+            if "s_waitcnt" in code and "vmcnt" not in code:
+                continue
+            if VMEM.match(code):
+                dst = None
+                g = re.match(r"\s*global_load_dwordx4 v\[(\d+):(\d+)\]", code)
+                if in_asm and g:
+                    dst = (int(g.group(1)), int(g.group(2)))
+                    checked += 1
+                # an instruction's own address / data registers are read at issue: check them against the pending asm destinations
+                srcs = regs_of(code.split(",", 1)[1]) if "," in code else []
+                if dst is None and not in_asm and re.match(r"\s*(global_load|buffer_load|scratch_load|flat_load)", code) and "lds" not in code:
+                    srcs = regs_of(code.split(",", 1)[1]) if "," in code else []
+                for lo, hi in srcs:
+                    for q in queue:
+                        if q is not None and not (hi < q[0] or lo > q[1]):
+                            findings.append("%s: line %d reads v[%d:%d] (asm load still outstanding): %s" % (name[-44:], ln, q[0], q[1], code.strip()))
+                queue.append(dst)
+                continue
+            if not code.strip() or code.strip().startswith(".") or code.strip().endswith(":"):
+                continue
+            # any other instruction: every VGPR it names is read or written -- neither is allowed while the asm load that owns it is in flight
+            for lo, hi in regs_of(code):
+                for q in queue:
+                    if q is not None and not (hi < q[0] or lo > q[1]):
+                        findings.append("%s: line %d touches v[%d:%d] before its wait: %s" % (name[-44:], ln, q[0], q[1], code.strip()))
+    return checked, findings
+
+
+if __name__ == "__main__":
+    checked, findings = audit(open(sys.argv[1]).read())
+    for f in findings[:40]:
+        print(f)
+    print("asm loads checked: %d, findings: %d" % (checked, len(findings)))
+    sys.exit(1 if findings or not checked else 0)
