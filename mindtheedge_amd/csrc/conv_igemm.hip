@@ -26,6 +26,8 @@
 // and wave: 256 x 128 tile (512 -> 512 @24x80) stage wait 57 | barrier 314 | DMA issue 267 | fragment reads + MFMA issue 468 | total 1192
 // (MFMA pipe busy 512); 256 x 256 tile (256 -> 256 @48x160) 68 | 861 | 207 | 484 | 1707 (pipe busy 1024).  Issuing the DMA behind the MFMAs
 // instead of in front of the fragment reads was tried on that evidence and lost 1.7 % (same-box A/B), s_setprio around the MFMAs 0.7 %.
+// The ping-pong loop built on it (256 -> 256 @48x160): load phase 499 | first barrier 101 | MFMA issue 568 | wait + second barrier 179 per K-step
+// and wave -- the two groups' MFMA phases fill ~76 % of a SIMD's K-step (60 % before).
 #ifdef MTE_STAMPS
 __device__ unsigned long long g_igemm_stamps[16384 * 8];
 extern "C" int mtei_igemm_stamps(unsigned long long* host, int n) {
@@ -389,6 +391,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
         // reads (lgkmcnt(0)) BEFORE the barrier that ends its load phase, so the slot of K-step k - 1 is free for the DMA of stage k + 3
         // from the next half-step on; every wave waits for its parts of stage k + 1 before the barrier that ends the half-step in which
         // it handled K-step k, which is at least one barrier before anyone reads that stage.
+        // (the same loop on 16 waves of 64 x 64, two waves of each group per SIMD, measured no better: 66.9 vs 66.5 us on the 256 -> 256 layer)
         constexpr bool PP = LD == 2 && WM == 2 && WN == 4 && TM == 4 && TN == 2 && ST == 4;
         if constexpr (PP) {
             const int grp = __builtin_amdgcn_readfirstlane(wm);
@@ -402,7 +405,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             // (Issuing half of the stage's DMA behind the MFMAs instead -- the load phase is the longer one -- was tried: 66 -> 73 us on the
             //  256 -> 256 layer; a DMA instruction behind the wave's own MFMAs is slower still.)
             if (grp == 1) __builtin_amdgcn_s_barrier();
+#ifdef MTE_STAMPS
+            unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_cmp = 0, t_a, t_b;
+            const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#define PP_STAMP(ACC) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); ACC += t_b - t_a; t_a = t_b; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PP_STAMP(ACC)
+#endif
             for (int k = 0; k < nst; ++k) {
+#ifdef MTE_STAMPS
+                t_a = __builtin_amdgcn_s_memtime();
+#endif
                 const int rem = nst - 2 - k;                   // stages this wave has issued behind stage k + 1: min(rem, 2)
                 read_frags(k % ST);
                 if (k + AHEAD < nst) dma_fast(s_begin + k + AHEAD, (k + AHEAD) % ST);
@@ -411,13 +424,24 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
                 if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
                 else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PP_STAMP(t_dma)                                // load phase: fragment reads + DMA issue + their waits
                 __builtin_amdgcn_s_barrier();
+                PP_STAMP(t_bar)
                 mfmas();
+                PP_STAMP(t_cmp)                                // MFMA issue
                 if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
                 else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                PP_STAMP(t_wait)                               // wait + second barrier
             }
+#ifdef MTE_STAMPS
+            if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048 && (threadIdx.x >> 6) < 4) {
+                unsigned long long* o = g_igemm_stamps + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+                o[0] = t_wait; o[1] = t_bar; o[2] = t_dma; o[3] = t_cmp; o[4] = __builtin_amdgcn_s_memtime() - t_start; o[5] = nst; o[6] = 1;
+            }
+#endif
+#undef PP_STAMP
             if (grp == 0) __builtin_amdgcn_s_barrier();
         } else {
 #endif

@@ -54,5 +54,9 @@ for shp in shapes:
     ks = a[:, 5]
     per = a[:, :5] / ks[:, None]
     m = np.median(per, axis=0)
+    if np.median(a[:, 6]) == 1:
+        print("%d -> %d k%d @%dx%d (ping-pong loop): %d waves stamped, %d K-steps; s_memtime cycles per K-step and wave (median): load phase (reads + DMA "
+              "issue + waits) %.1f | first barrier %.1f | MFMA issue %.1f | wait + second barrier %.1f | total %.1f" % (cin, cout, k, H, W, len(a), int(np.median(ks)), m[2], m[1], m[3], m[0], m[4]))
+        continue
     print("%d -> %d k%d @%dx%d: %d waves stamped, %d K-steps; s_memtime cycles per K-step and wave (median): "
           "stage wait %.1f | barrier %.1f | DMA issue %.1f | fragment reads + MFMA issue %.1f | total %.1f" % (cin, cout, k, H, W, len(a), int(np.median(ks)), m[0], m[1], m[2], m[3], m[4]))
