@@ -142,7 +142,8 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape, devlib):
         K.use_patch_kernels(True)
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 3, 8, 48, 160), (64, 256, 5, 2, 96, 320), (96, 512, 3, 3, 10, 52), (128, 256, 1, 8, 48, 160)])
+@pytest.mark.parametrize("shape", [(256, 256, 3, 8, 48, 160), (64, 256, 5, 2, 96, 320), (96, 512, 3, 3, 10, 52), (128, 256, 1, 8, 48, 160),
+                                   (32, 256, 1, 2, 16, 48), (64, 512, 1, 1, 24, 40), (96, 256, 1, 2, 10, 52)])      # (the last three: 1, 2 and 3 K-steps)
 def test_igemm_pingpong_loop_matches_one_barrier_loop(shape, devlib):
     """The 8-wave ping-pong form of the 256x256 tile (two wave groups half a K-step apart, round 3) against the 16-wave one-barrier form and
     the 4-wave 128x128 tiles: same K order and fp32 accumulation chain per output, so all three are bit-identical -- repeated, because a
