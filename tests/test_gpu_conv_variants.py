@@ -27,6 +27,8 @@ SHAPES = [  # cin, cout, k, B, H, W
     # round 3: the 8-input-channel stem kernels (csrc/conv_stem.hip): reduction over (tap, channel), ragged heights, k = 3 / 5 / 7
     (3, 32, 5, 1, 37, 96), (3, 16, 3, 2, 9, 32), (3, 32, 7, 1, 16, 32), (8, 24, 5, 2, 16, 64),
     (128, 128, 3, 2, 16, 64), (200, 128, 3, 1, 12, 32), (64, 128, 3, 2, 8, 64), (256, 128, 3, 1, 13, 32), (72, 96, 3, 2, 9, 32), (64, 72, 3, 1, 6, 96),
+    # round 3: the second form of the LDS-patch forward -- tall (16-row) tiles with a ragged last tile, one / two / three slices, 5x5 and 7x7
+    (32, 32, 3, 1, 24, 64), (72, 32, 3, 1, 20, 32), (32, 32, 5, 1, 40, 64), (40, 32, 5, 1, 20, 32), (32, 24, 7, 1, 21, 32), (136, 64, 3, 1, 11, 64),
 ]
 
 
