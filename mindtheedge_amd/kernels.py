@@ -595,7 +595,8 @@ class _BandChain:
     """The exact-border band chain of a folded pack layer (thin strips: 16 x 5 x 640 pixels and the like, launches that fill a
     fraction of the chip) on a stream of its own, beside the layer's full-size kernels: `with chain:` forks from the current
     stream, `chain.join()` makes the current stream wait for everything the block enqueued.  With the side streams switched
-    off (serial profiling) it does nothing and the chain stays on the current stream."""
+    off (serial profiling), or without MTE_BAND_STREAM=1 (the default, see _BAND_STREAM), it does nothing and the chain stays on the
+    current stream."""
 
     def __init__(self):
         self.stream = None
@@ -636,7 +637,10 @@ class _BandChain:
             torch.cuda.current_stream().wait_event(ev)
 
 
-_BAND_STREAM = not os.environ.get("MTE_NO_BAND_STREAM")    # development A/B: band chains on the main chain
+# OFF by default: on one GPU without a process group the third stream is worth +0.4 % (profiles/r03_band_stream_ab.txt), but as soon as RCCL's
+# streams exist it shares a hardware queue with the main chain or the weight-gradient stream and the step goes from 25.4 to 35.1 ms
+# (bench.py under MTE_BENCH_DIST_SELFTEST=1, GPU_MAX_HW_QUEUES 8 or 16 alike) -- the multi-GPU path must not pay for it.  MTE_BAND_STREAM=1 turns it on.
+_BAND_STREAM = bool(os.environ.get("MTE_BAND_STREAM")) and not os.environ.get("MTE_NO_BAND_STREAM")
 
 
 def join_side_stream():
