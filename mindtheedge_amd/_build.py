@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmte_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_stem.hip", "norm_act.hip", "pack3d.hip", "pack_fold.hip", "heads_misc.hip", "edge_loss.hip", "eval_metrics.hip", "dee_post.hip", "chamfer.hip", "canny.hip", "san.hip", "data_prep.hip"]
+SOURCES = ["conv_igemm.hip", "conv_igemm8.hip", "conv_patch.hip", "conv_stem.hip", "norm_act.hip", "pack3d.hip", "pack_fold.hip", "heads_misc.hip", "edge_loss.hip", "eval_metrics.hip", "dee_post.hip", "chamfer.hip", "canny.hip", "san.hip", "data_prep.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=off"]
 
 
@@ -53,13 +53,14 @@ def build(force=False, verbose=False, dev=True):
     """Compile every .hip for gfx950 and link the C-ABI shared library next to the sources (and, dev=True, its -DMTE_DEV twin)."""
     hipcc = _hipcc()
     hdr = os.path.join(CSRC, "common.hpp")
+    hdr2 = os.path.join(CSRC, "conv_args.hpp")
     os.makedirs(os.path.join(CSRC, "dev"), exist_ok=True)
     variants = [("", [], LIB)] + ([("dev", ["-DMTE_DEV"], DEV_LIB)] if dev else [])
     jobs = []
     for sub, extra, _ in variants:
         for s in SOURCES:
             src, obj = os.path.join(CSRC, s), os.path.join(CSRC, sub, s.replace(".hip", ".o"))
-            dig = _digest([src, hdr], " ".join(FLAGS + extra))
+            dig = _digest([src, hdr, hdr2], " ".join(FLAGS + extra))
             if force or _stale(obj, dig):
                 jobs.append(([hipcc] + FLAGS + extra + ["-c", src, "-o", obj], obj, dig))
 

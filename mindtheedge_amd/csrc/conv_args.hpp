@@ -1,0 +1,25 @@
+// Argument block of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_igemm8.hip).
+#pragma once
+#include "common.hpp"
+
+struct ConvArgs {
+    const void* x; long ldx;        // input pixels, elements per pixel (>= Cin_p)
+    const void* w;                  // [N][taps][Cin_p] packed weights, same element type as x
+    const float* bias;              // [N] or null
+    void* y; long ldy; int out_f32; // output pixels
+    int B, H, W, Cin_p, N, KH, KW;
+    long M;
+    int splits; float* ws;          // split-K: split s STORES its partial sums into its own slab ws[s][M][N] (fp32); splitk_finish_kernel adds
+                                    // the slabs in order -- no floating-point atomics, the result does not depend on the arrival order
+    int accum;                      // 1: y += conv (sum formed in fp32, rounded once) -- second gradient of a two-consumer activation
+    int solo;                       // host-side hint (MTE_CONV_SOLO): nothing runs beside this launch on another stream
+    // Sparse form (SAN branch, round 3): GEMM row m is pixel rows[m] of the dense NHWC maps, for m < *nrows (device-side count).  The
+    // input map is zero-filled off the active set, so gathering a row's taps from it IS the sparse convolution's sum over active
+    // neighbours; outputs are scattered to the same sites, nothing is written elsewhere.  Work scales with the active count: tiles past
+    // *nrows return at once (the grid is sized for the dense capacity M, the count never visits the host).
+    const int* rows; const int* nrows;
+};
+
+// conv_igemm8.hip: the 8-phase 256-row tile kernels (bf16, buffer-descriptor LDS-DMA).  bn = 256 or 128 output columns per tile.
+// Returns MTE_ERR_UNSUPPORTED when the shape is outside what the kernel covers (the caller then takes the older tile forms).
+__attribute__((visibility("hidden"))) int igemm8_launch(ConvArgs a, int bn, hipStream_t st);

@@ -21,6 +21,7 @@
 // s+1 are in flight while step s computes).  LDS rows are 64 B; 16-B chunk c of row r is stored at chunk
 // slot c ^ ((r>>2)&3), which makes every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
 #include "common.hpp"
+#include "conv_args.hpp"
 
 // In-loop s_memtime sums of the DMA main loop (diagnostic build only: -DMTE_STAMPS, tools/igemm_stamps.py).  Round-3 reading, cycles per K-step
 // and wave: 256 x 128 tile (512 -> 512 @24x80) stage wait 57 | barrier 314 | DMA issue 267 | fragment reads + MFMA issue 468 | total 1192
@@ -37,23 +38,6 @@ extern "C" int mtei_igemm_stamps(unsigned long long* host, int n) {
 
 namespace {
 
-struct ConvArgs {
-    const void* x; long ldx;        // input pixels, elements per pixel (>= Cin_p)
-    const void* w;                  // [N][taps][Cin_p] packed weights, same element type as x
-    const float* bias;              // [N] or null
-    void* y; long ldy; int out_f32; // output pixels
-    int B, H, W, Cin_p, N, KH, KW;
-    long M;
-    int splits; float* ws;          // split-K: split s STORES its partial sums into its own slab ws[s][M][N] (fp32); splitk_finish_kernel adds
-                                    // the slabs in order -- no floating-point atomics, the result does not depend on the arrival order
-    int accum;                      // 1: y += conv (sum formed in fp32, rounded once) -- second gradient of a two-consumer activation
-    int solo;                       // host-side hint (MTE_CONV_SOLO): nothing runs beside this launch on another stream
-    // Sparse form (SAN branch, round 3): GEMM row m is pixel rows[m] of the dense NHWC maps, for m < *nrows (device-side count).  The
-    // input map is zero-filled off the active set, so gathering a row's taps from it IS the sparse convolution's sum over active
-    // neighbours; outputs are scattered to the same sites, nothing is written elsewhere.  Work scales with the active count: tiles past
-    // *nrows return at once (the grid is sized for the dense capacity M, the count never visits the host).
-    const int* rows; const int* nrows;
-};
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -681,6 +665,8 @@ launched:
 }
 
 int g_igemm_big_min_tiles = 224;
+int g_igemm8 = 3;                                    // development knob (mte_debug_set(23, v)): bit 0 = 8-phase 256 x 256 kernel, bit 1 = its 256 x 128 form
+int g_igemm8_min_tiles = 200;                        // development knob (mte_debug_set(24, v))
 int g_igemm_pp = 1;                                  // development knob (mte_debug_set(21, v)): 0 = the 16-wave one-barrier loop on the 256 x 256 tile
 int g_igemm_big = 3;                                 // development knob (mte_debug_set(6, v)): 0 128x128 only, 1 + 256x128, 2 + 256x256, 3 + 192x96
 
@@ -704,6 +690,33 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         long smax = can_split ? ws_elems / (a.M * a.N) : 1;                    // one [M][N] slab per split
         if (smax > 8) smax = 8;
         const long reach256 = t256 * (can_split ? (ksteps / 16 < smax ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : smax) : 1);
+        // ---- round 4: the 8-phase kernels (conv_igemm8.hip) take every launch the 256-row tiles took
+        if (g_igemm8 && dma_ok && !a.out_f32 && !a.rows && a.N > 64) {
+            const bool wide = a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128);
+            int bn = 0, splits = 1;
+            if (wide && t256 >= g_igemm8_min_tiles) bn = 256;                                      // enough 256 x 256 tiles for the chip
+            else if ((g_igemm8 & 2) && tiles_big >= g_igemm8_min_tiles) bn = 128;                   // 256 x 128 tiles
+            else if (wide && can_split && t256 < 128 && ksteps >= 32) {                            // few tiles, long reduction: split K
+                bn = 256;
+                long sp = 256 / t256;                                                              // one round of workgroups
+                if (sp > smax) sp = smax;
+                if (sp > ksteps / 16) sp = ksteps / 16;                                            // >= 8 K-tiles per split
+                splits = (int)(sp < 1 ? 1 : sp);
+            } else if (wide && t256 >= 128) bn = 256;
+            if (bn) {
+                ConvArgs b = a;
+                b.splits = splits;
+                const int rc = igemm8_launch(b, bn, st);
+                if (rc == MTE_OK) {
+                    if (splits > 1) {
+                        long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
+                        hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)g), dim3(256), 0, st, a.ws, splits, a.bias, (T*)a.y, a.ldy, a.M, a.N, a.accum);
+                    }
+                    return mte_check_launch();
+                }
+                if (rc != MTE_ERR_UNSUPPORTED) return rc;
+            }
+        }
         if (g_igemm_big >= 2 && dma_ok && !a.out_f32 && a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128) &&
             (t256 >= g_igemm_big_min_tiles || (can_split && t256 < 96 && reach256 >= 160))) {   // (96: below it choose_splits does split)
             // enough tiles without a K split: 8 waves of 128 x 64 in the ping-pong loop (same-box A/B per layer: 256 -> 256 3x3 @48x160
@@ -1527,6 +1540,8 @@ int mte_debug_set(int key, int value) {
     if (key == 17) { g_igemm_ablate = value; return MTE_OK; }
     if (key == 19) { g_igemm_pair_ksteps = value; return MTE_OK; }
     if (key == 21) { g_igemm_pp = value; return MTE_OK; }
+    if (key == 23) { g_igemm8 = value; return MTE_OK; }
+    if (key == 24) { g_igemm8_min_tiles = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
