@@ -22,4 +22,4 @@ struct ConvArgs {
 
 // conv_igemm8.hip: the 8-phase 256-row tile kernels (bf16, buffer-descriptor LDS-DMA).  bn = 256 or 128 output columns per tile.
 // Returns MTE_ERR_UNSUPPORTED when the shape is outside what the kernel covers (the caller then takes the older tile forms).
-__attribute__((visibility("hidden"))) int igemm8_launch(ConvArgs a, int bn, hipStream_t st);
+__attribute__((visibility("hidden"))) int igemm8_launch(ConvArgs a, int bn, int persistent, hipStream_t st);

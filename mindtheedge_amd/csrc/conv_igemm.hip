@@ -693,20 +693,29 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         // ---- round 4: the 8-phase kernels (conv_igemm8.hip) take every launch the 256-row tiles took
         if (g_igemm8 && dma_ok && !a.out_f32 && !a.rows && a.N > 64) {
             const bool wide = a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128);
+            const int nkt = (ksteps + 1) / 2;                                                      // K-tiles of 64
             int bn = 0, splits = 1;
-            if (wide && t256 >= g_igemm8_min_tiles) bn = 256;                                      // enough 256 x 256 tiles for the chip
-            else if ((g_igemm8 & 2) && tiles_big >= g_igemm8_min_tiles) bn = 128;                   // 256 x 128 tiles
-            else if (wide && can_split && t256 < 128 && ksteps >= 32) {                            // few tiles, long reduction: split K
+            // Same-box A/B against the older tile forms over the training step's shapes (tools/igemm8_check.py bench; profiles/r04_igemm8_ab.txt):
+            // one workgroup per CU, so a launch of SEVERAL rounds of tiles pays prologue + epilogue (~ 6 K-tiles' worth) per round, where the
+            // 256 x 128 kernel it replaces runs two workgroups per CU: short reductions over many tiles stay with the older forms.
+            if (g_igemm8 & 4) {                                                                    // (development: every eligible launch)
+                if (wide && t256 >= g_igemm8_min_tiles) bn = 256;
+                else if (tiles_big >= g_igemm8_min_tiles) bn = 128;
+            } else if (wide && (g_igemm8 & 1) && t256 >= g_igemm8_min_tiles) {
+                if (nkt >= (t256 <= 256 ? 18 : 36)) bn = 256;
+            } else if ((g_igemm8 & 2) && tiles_big >= g_igemm8_min_tiles && tiles_big <= 256 && nkt >= 36) bn = 128;
+            if (!bn && wide && (g_igemm8 & 1) && can_split && t256 < 128 && ksteps >= 32) {        // few tiles, long reduction: split K
                 bn = 256;
                 long sp = 256 / t256;                                                              // one round of workgroups
                 if (sp > smax) sp = smax;
                 if (sp > ksteps / 16) sp = ksteps / 16;                                            // >= 8 K-tiles per split
-                splits = (int)(sp < 1 ? 1 : sp);
-            } else if (wide && t256 >= 128) bn = 256;
+                const int per = (int)((ksteps + sp - 1) / (sp < 1 ? 1 : sp));
+                splits = (ksteps + per - 1) / per;                                                 // (no empty split)
+            }
             if (bn) {
                 ConvArgs b = a;
                 b.splits = splits;
-                const int rc = igemm8_launch(b, bn, st);
+                const int rc = igemm8_launch(b, bn, (g_igemm8 >> 3) & 1, st);
                 if (rc == MTE_OK) {
                     if (splits > 1) {
                         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;

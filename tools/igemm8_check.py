@@ -61,11 +61,12 @@ def check():
                 return out
 
             for split in (False, True):
+              for v8, name in ((7, "tile per workgroup"), (15, "persistent")):
                 ref = run(0, split)
                 if split:                                        # different split counts: equal up to the last bf16 rounding; the new kernel must repeat itself
-                    first = run(3, True)
+                    first = run(v8, True)
                     d = (first.float() - ref.float()).abs()
-                    tol = ref.float().abs() * 2.0 ** -7 + 1e-3
+                    tol = ref.float().abs() * 2.0 ** -6 + 1e-3       # (accumulate: the unsplit tile forms round conv + bias to bf16 before the sum, the split-K finish does not)
                     nbad = int((d > tol).sum())
                     if nbad:
                         print("   split-K result off: %d elements beyond one bf16 ulp, max |d| %.3e" % (nbad, float(d.max())))
@@ -73,14 +74,14 @@ def check():
                     ref = first
                 miss = 0
                 for r in range(reps):
-                    y = run(3, split)
+                    y = run(v8, split)
                     if not torch.equal(y, ref):
                         miss += 1
                         if miss == 1:
                             d = (y.float() - ref.float()).abs()
                             print("   first mismatch rep %d: %d elements differ, max |d| %.3e (ref max %.3e)" % (r, int((d > 0).sum()), float(d.max()), float(ref.float().abs().max())))
                 bad += miss
-                print("%5d -> %-4d k%d B%d %3dx%-4d ldx %-4s acc %d split %d : %d / %d repetitions differ" % (cin, cout, k, B, H, W, ldx, accumulate, split, miss, reps))
+                print("%5d -> %-4d k%d B%d %3dx%-4d ldx %-4s acc %d split %d %-18s: %d / %d repetitions differ" % (cin, cout, k, B, H, W, ldx, accumulate, split, name, miss, reps))
     S(23, 3); S(24, 200); S(6, 3)
     print("MISMATCHES:", bad)
     return bad
@@ -95,13 +96,13 @@ def bench():
               (384, 256, 3, 48, 160, 1), (256, 256, 3, 48, 160, 10), (512, 256, 3, 24, 80, 2), (64, 128, 3, 96, 320, 2), (256, 128, 3, 48, 160, 2),
               (128, 256, 3, 48, 160, 2), (256, 512, 3, 24, 80, 2), (512, 512, 3, 12, 40, 2), (128, 128, 1, 96, 320, 2), (256, 256, 1, 48, 160, 4),
               (512, 512, 1, 24, 80, 4)]
-    tot = {0: 0.0, 3: 0.0}
+    tot = {0: 0.0, 3: 0.0, 7: 0.0, 15: 0.0}
     for cin, cout, k, H, W, cnt in shapes:
         x, wf, b, _ = make(cin, cout, k, B, H, W)
         fl = 2.0 * B * H * W * cin * cout * k * k
-        t = {0: [], 3: []}
+        t = {0: [], 3: [], 7: [], 15: []}
         for rnd in range(5):
-            for v8 in (0, 3):
+            for v8 in (0, 3, 7, 15):
                 S(23, v8)
                 for _ in range(2):
                     K.conv_forward(x, wf, b, cout, k, k)
@@ -115,9 +116,10 @@ def bench():
         m = {v: sorted(t[v])[len(t[v]) // 2] for v in t}
         for v in m:
             tot[v] += m[v] * cnt
-        print("%5d -> %-4d k%d @%3dx%-4d x%-2d  old %7.1f us %6.0f TF   8-phase %7.1f us %6.0f TF   %+5.1f %%" % (
-            cin, cout, k, H, W, cnt, m[0] * 1e3, fl / m[0] / 1e9, m[3] * 1e3, fl / m[3] / 1e9, (m[0] / m[3] - 1) * 100))
-    print("weighted sum per step: old %.3f ms, 8-phase %.3f ms" % (tot[0], tot[3]))
+        print("%5d -> %-4d k%d @%3dx%-4d x%-2d  old %7.1f us %6.0f TF   dispatch rule %7.1f us %6.0f TF %+5.1f %%   8-phase everywhere %7.1f us %6.0f TF %+5.1f %%   persistent %7.1f us %6.0f TF %+5.1f %%" % (
+            cin, cout, k, H, W, cnt, m[0] * 1e3, fl / m[0] / 1e9, m[3] * 1e3, fl / m[3] / 1e9, (m[0] / m[3] - 1) * 100, m[7] * 1e3, fl / m[7] / 1e9, (m[0] / m[7] - 1) * 100,
+            m[15] * 1e3, fl / m[15] / 1e9, (m[0] / m[15] - 1) * 100))
+    print("weighted sum per step: old %.3f ms, dispatch rule %.3f ms, 8-phase everywhere %.3f ms, persistent everywhere %.3f ms" % (tot[0], tot[3], tot[7], tot[15]))
     S(23, 3)
 
 
