@@ -715,7 +715,9 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
             if (bn) {
                 ConvArgs b = a;
                 b.splits = splits;
-                const int rc = igemm8_launch(b, bn, (g_igemm8 >> 3) & 1, st);
+                // several rounds of tiles: the tile-walking form (the stream of half-tiles runs on across tiles: +1-2 % on the 480- / 960-tile launches)
+                const int persistent = ((g_igemm8 >> 3) & 1) | (bn == 256 && splits == 1 && t256 > 256 && !(g_igemm8 & 16) ? 1 : 0);
+                const int rc = igemm8_launch(b, bn, persistent, st);
                 if (rc == MTE_OK) {
                     if (splits > 1) {
                         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;

@@ -32,11 +32,20 @@
 //     tile with 8-byte LDS writes (2-byte ones before) and stores 16-byte row-contiguous chunks.
 // Out-of-image taps, rows past M, columns past N and K-steps past the end of the (split's) reduction are out-of-range buffer offsets:
 // the LDS-DMA writes zeros for them.
+//
+// What the in-loop stamps say (tools/igemm8_stamps.py, profiles/r04_igemm8_stamps_v1.txt; 256 -> 256 3x3 @48x160): a K-tile takes ~3500 cycles for
+// 2 x 4 x 16 MFMAs = 2050 cycles of pipe time per SIMD (58 %, 1385 TFLOP/s in the main loop = the template's own rate on random data); the MFMA
+// sections run at the pipe rate (312 per 16), load sections with 8-12 fragment reads + 2 DMA take 270, and phase 2 -- whose load section also
+// carries the K-half tap bookkeeping (`advance`) -- 420-900.  A wave issues ONE instruction per ~4-5 cycles whatever its kind (the CU visits a
+// SIMD every fourth cycle), so a load section has room for ~60 instructions beside the other group's MFMAs; the round's attempts to shrink that
+// bookkeeping are recorded in profiles/r04_igemm8_loader_ablation.txt and tools/probe/ (tap shift in the scalar buffer offset, validity bit
+// masks, branch-free stepping -- each form correct, each SLOWER here: 36 branch-free scalar instructions per K-half cost more than the branchy
+// form's 5 on the common path, and vector work scheduled between the MFMAs starves both the matrix pipe and the other group's loads).
 #include "common.hpp"
 #include "conv_args.hpp"
 
 #ifdef MTE_STAMPS
-__device__ unsigned long long g_igemm8_stamps[4096 * 8];
+__device__ unsigned long long g_igemm8_stamps[4096 * 24];
 extern "C" int mtei_igemm8_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm8_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
@@ -221,9 +230,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
     MTE8_BARRIER();
     if (grp == 1) MTE8_BARRIER();                                    // group 1 runs one barrier behind from here on
 #ifdef MTE_STAMPS
-    unsigned long long t_ld = 0, t_b1 = 0, t_mm = 0, t_b2 = 0, t_a, t_b;
+    unsigned long long t_st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_a, t_b;      // [phase][load section | first barrier | MFMAs | second barrier]
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-#define ST8(ACC) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); ACC += t_b - t_a; t_a = t_b; __builtin_amdgcn_sched_barrier(0); }
+#define ST8(ACC) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); t_st[ACC] += t_b - t_a; t_a = t_b; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define ST8(ACC)
 #endif
@@ -239,56 +248,58 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
         readA(0, pb);
         stageA(1, buf ^ 1);
         MTE8_WAIT_LGKM(QA * 2);
-        ST8(t_ld)
+        ST8(0)
         MTE8_BARRIER();
-        ST8(t_b1)
+        ST8(1)
         MTE8_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
         quadrant(0, 0, fb0);
-        ST8(t_mm)
+        ST8(2)
         MTE8_BARRIER();
-        ST8(t_b2)
+        ST8(3)
         // ---- phase 2: quadrant (A0, B1); stage B0 of K-tile kt + 2, move the tap state there
         readB(1, fb1, pb);
         stageB(0, kt + 2, buf);
         advance();
-        ST8(t_ld)
+        ST8(4)
         MTE8_BARRIER();
-        ST8(t_b1)
+        ST8(5)
         MTE8_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
         quadrant(0, 1, fb1);
-        ST8(t_mm)
+        ST8(6)
         MTE8_BARRIER();
-        ST8(t_b2)
+        ST8(7)
         // ---- phase 3: quadrant (A1, B1); stage A0 of K-tile kt + 2
         readA(1, pb);
         stageA(0, buf);
-        ST8(t_ld)
+        ST8(8)
         MTE8_BARRIER();
-        ST8(t_b1)
+        ST8(9)
         MTE8_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
         quadrant(1, 1, fb1);
-        ST8(t_mm)
+        ST8(10)
         MTE8_BARRIER();
-        ST8(t_b2)
+        ST8(11)
         // ---- phase 4: quadrant (A1, B0); stage B1 of K-tile kt + 2; K-tile kt + 1 must have landed
         stageB(1, kt + 2, buf);
         MTE8_WAIT_VM(2 * IB + IA);
-        ST8(t_ld)
+        ST8(12)
         MTE8_BARRIER();
-        ST8(t_b1)
+        ST8(13)
         quadrant(1, 0, fb0);
-        ST8(t_mm)
+        ST8(14)
         MTE8_BARRIER();
-        ST8(t_b2)
+        ST8(15)
     }
     if (grp == 0) MTE8_BARRIER();
 #ifdef MTE_STAMPS
     if (lane == 0 && blockIdx.x < 512) {
-        unsigned long long* o = g_igemm8_stamps + ((long)blockIdx.x * 8 + wv) * 8;
-        o[0] = t_ld; o[1] = t_b1; o[2] = t_mm; o[3] = t_b2; o[4] = __builtin_amdgcn_s_memtime() - t_start; o[5] = nkt;
+        unsigned long long* o = g_igemm8_stamps + ((long)blockIdx.x * 8 + wv) * 24;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = t_st[k];
+        o[16] = __builtin_amdgcn_s_memtime() - t_start; o[17] = nkt;
     }
 #endif
     MTE8_WAIT_VM(0);                                                 // the zero-filling DMA of the K-tiles past the end must not land in the output tile
