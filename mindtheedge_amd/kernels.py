@@ -50,16 +50,23 @@ class GradSink:
     A store is only an accumulation ONCE per zeroed buffer.  The sink therefore hands a parameter's view out for one store
     per ``reset()`` (= optimizer.zero_grad()): a second gradient for the same tensor -- a second backward pass without
     zero_grad, or a parameter used twice in one graph -- goes back to autograd, which ADDS it into ``.grad`` (the same flat
-    memory).  A forward pass that knows it shares parameters between two sub-graphs (PackNetSAN01's RGB and RGB+LiDAR passes,
-    reference networks/depth/PackNetSAN01.py:324-338) calls ``suspend()``: until the next ``reset()`` EVERY gradient takes the
-    autograd route, so each parameter's AccumulateGrad node runs once with the sum of both uses and the all-reduce trigger
-    (post-accumulate hook) never fires on half a gradient."""
+    memory) on the main stream.  The first store may have been queued on the weight-gradient side stream, so before handing the
+    second gradient to autograd the sink makes the current stream wait for the side streams (``join_side_stream``): the add can
+    never overtake the store (round-3 advisor finding).  What the sink canNOT repair is the ready() announcement: it went out with
+    the first, incomplete gradient, so with a consumer attached (``on_ready``: the bucketed all-reduce) a second gradient for an
+    already announced parameter raises instead of reducing half a gradient.  A forward pass that knows it shares parameters
+    between two sub-graphs (PackNetSAN01's RGB and RGB+LiDAR passes, reference networks/depth/PackNetSAN01.py:324-338) calls
+    ``suspend()`` BEFORE its backward: until the next ``reset()`` EVERY gradient takes the autograd route, so each parameter's
+    AccumulateGrad node runs once with the sum of both uses and the all-reduce trigger (post-accumulate hook) never fires on half
+    a gradient."""
 
     def __init__(self):
         self.views = {}          # param.data_ptr() -> flat fp32 gradient view
         self.on_ready = None
         self.written = set()     # parameters whose view already holds this step's (first) gradient
+        self.announced = set()   # ... and whose gradient was announced through ready()
         self.suspended = False
+        self._suspend_resets = 0
 
     def register(self, p, view):
         self.views[p.data_ptr()] = view
@@ -70,7 +77,14 @@ class GradSink:
             return None
         key = p.data_ptr()
         v = self.views.get(key)
-        if v is not None and key not in self.written and p.grad is not None and p.grad.data_ptr() == v.data_ptr() and v.shape == p.shape:
+        if v is not None and key in self.written:
+            # a second gradient for a parameter whose view already took this step's store: autograd will add it into the same memory
+            if key in self.announced and self.on_ready is not None:
+                raise MteError("a parameter received a second gradient after its first one was announced to the gradient all-reduce: "
+                               "call kernels.suspend_grad_sink() in the forward pass of a graph that uses parameters twice")
+            join_side_stream()
+            return None
+        if v is not None and p.grad is not None and p.grad.data_ptr() == v.data_ptr() and v.shape == p.shape:
             return v
         return None
 
@@ -82,14 +96,26 @@ class GradSink:
         return v
 
     def reset(self):
-        """the gradient buffer was cleared (zero_grad): every view may take one store again"""
+        """the gradient buffer was cleared (zero_grad): every view may take one store again.  A suspension survives the FIRST
+        zero_grad after it (forward -> zero_grad -> backward is a legal order: the backward that needs the suspension is still to
+        come); the optimizer step (end_step) or a second zero_grad ends it -- staying suspended one step too long costs speed only."""
         self.written.clear()
+        self.announced.clear()
+        if self.suspended:
+            self._suspend_resets += 1
+            if self._suspend_resets >= 2:
+                self.suspended = False
+
+    def end_step(self):
+        """the optimizer consumed the gradients: a forward pass's suspension ends here"""
         self.suspended = False
 
     def suspend(self):
         self.suspended = True
+        self._suspend_resets = 0
 
     def ready(self, p):
+        self.announced.add(p.data_ptr())
         if self.on_ready is not None:
             self.on_ready(p)
 

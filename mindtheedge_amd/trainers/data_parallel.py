@@ -214,6 +214,8 @@ class FusedAdam(torch.optim.Optimizer):
         if self.flatp.grad.is_cuda:
             K.join_side_stream()
         gscale = self.reducer.finish() if self.reducer is not None else 1.0
+        if self.flatp.sink is not None:
+            self.flatp.sink.end_step()                       # (a forward pass's gradient-sink suspension lasts until its gradients are consumed)
         g = self.param_groups[0]
         if self.flatp.grad.is_cuda:
             # step count and learning rate reach the kernel through device memory, so the launch is identical every step (HIP-graph

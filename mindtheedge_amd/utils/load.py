@@ -91,21 +91,44 @@ def read_checkpoint(path, unsafe=False):
         return torch.load(path, map_location='cpu', weights_only=False, pickle_module=_AllowListPickle)
 
 
+def backwards_state_dict(state_dict):
+    """Key names of an old-format (`.pth.tar`) model file in today's layout (reference load.py:169-201): every key gains the
+    `model.` prefix, `model.model.` collapses to `model.`, `pose_network` / `disp_network` become `pose_net` / `depth_net`, and the
+    depth network's `conv3.0.weight` / `conv3.0.bias` lose the Sequential index."""
+    renames = (('model.model.', 'model.'), ('pose_network.', 'pose_net.'), ('disp_network.', 'depth_net.'))
+    out = type(state_dict)() if hasattr(state_dict, 'items') else {}
+    for key, val in state_dict.items():
+        key = 'model.' + key
+        if 'disp_network' in key:
+            key = key.replace('conv3.0.weight', 'conv3.weight').replace('conv3.0.bias', 'conv3.bias')
+        for old, new in renames:
+            key = key.replace(old, new)
+        out[key] = val
+    return out
+
+
 def load_network(network, path, prefixes=''):
-    """Prefix-stripped, shape-checked, non-strict checkpoint load (reference load.py:117-166)."""
+    """Prefix-stripped, shape-checked, non-strict checkpoint load (reference load.py:117-166).
+
+    As upstream, a prefix matches ANYWHERE in a key (`prefix + '.' in key`: `module.model.depth_net.conv1.weight` loads with
+    prefix `depth_net`) and everything up to and including its first occurrence is cut; the cut key is what the next prefix of the
+    list is tested against.  A `.pth.tar` path goes through backwards_state_dict first."""
+    prefixes = make_list(prefixes)
     if isinstance(path, str):
         ckpt = read_checkpoint(path)
         sd = ckpt.get('state_dict', ckpt)
+        if path.endswith('.pth.tar'):
+            sd = backwards_state_dict(sd)
     else:                                        # a state dict (reference :139-140: the resume path passes one)
         sd = path
     own = network.state_dict()
     picked = {}
     for key, val in sd.items():
-        for prefix in make_list(prefixes):
-            for p in ([prefix + '.', 'model.' + prefix + '.'] if prefix else ['']):
-                if key.startswith(p):
-                    k = key[len(p):]
-                    if k in own and tuple(own[k].shape) == tuple(val.shape):
-                        picked[k] = val
+        for prefix in prefixes:
+            p = prefix + '.'
+            if p in key:
+                key = key[key.find(p) + len(p):]
+                if key in own and tuple(own[key].shape) == tuple(val.shape):
+                    picked[key] = val
     network.load_state_dict(picked, strict=False)
     return network

@@ -438,8 +438,14 @@ def test_two_pass_gradients_with_the_flat_gradient_sink_equal_plain_autograd():
             assert len(fired) == len(set(fired)) == sum(1 for _ in net.parameters())     # once per parameter
         for h in hooks:
             h.remove()
-        # a single-pass step afterwards goes back to in-place stores (zero_grad re-arms the sink)
+        # a single-pass step afterwards goes back to in-place stores: the suspension ends when the optimizer consumes the gradients
+        # (FusedAdam.step -> end_step) or at the second zero_grad after it -- it survives ONE zero_grad, so that forward -> zero_grad ->
+        # backward keeps it (round-3 advisor finding)
         flat.zero_grad()
+        assert flat.sink.suspended
+        flat.sink.end_step()
+        assert not flat.sink.suspended
+        flat.sink.suspend(); flat.zero_grad(); flat.zero_grad()
         assert not flat.sink.suspended
         out = net(rgb)
         sum(i.float().mean() for i in out["inv_depths"]).backward()
