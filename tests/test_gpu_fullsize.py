@@ -123,12 +123,13 @@ def test_full_size_side_stream_schedule_does_not_change_gradients():
     assert float(gb.norm()) > 0
 
 
-def test_high_resolution_768x2560_training_step_is_finite_and_matches_fp32_loss():
-    """BASELINE.json's high-resolution configuration (768x2560): one bf16 training step, every gradient finite, loss within
-    the north-star tolerance of the fp32-mode loss of the same kernels."""
+def test_high_resolution_768x2560_batch2_training_step_is_finite_and_matches_fp32_loss():
+    """BASELINE.json's high-resolution configuration (768x2560, batch 2 per GPU): one bf16 training step at EXACTLY that batch geometry
+    (round-3 verdict: only B = 1 had run), every gradient finite, loss within the north-star tolerance of the fp32-mode loss of the same
+    kernels, and -- GroupNorm is per sample -- the inverse depth of sample 1 in the batch equal to the same frame run alone."""
     from mindtheedge_amd import kernels as K
     from mindtheedge_amd.utils.synthetic import synthetic_batch
-    batch = synthetic_batch(1, 768, 2560, 5, torch.device("cuda"))
+    batch = synthetic_batch(2, 768, 2560, 5, torch.device("cuda"))
     losses = {}
     try:
         for dtype in ("bf16", "fp32"):
@@ -144,7 +145,13 @@ def test_high_resolution_768x2560_training_step_is_finite_and_matches_fp32_loss(
                 for n, p in net.named_parameters():
                     if p.requires_grad and p.grad is not None:
                         assert bool(torch.isfinite(p.grad).all()), n
-                assert tuple(out["inv_depths"][0].shape) == (1, 1, 768, 2560) if "inv_depths" in out else True
+                inv = out["inv_depths"][0].detach().float()
+                assert tuple(inv.shape) == (2, 1, 768, 2560)
+                with torch.no_grad():
+                    alone = net(batch["rgb"][1:2])["inv_depths"][0].float()
+                # same bf16 products; only the GroupNorm statistics' summation order and the split-K / tile alignment differ between the launches
+                assert rel_err(alone[0].cpu(), inv[1].cpu()) < 4e-2
+                assert float((alone[0] - inv[1]).abs().mean()) < 8e-3 * float(inv[1].abs().mean())
             losses[dtype] = float(loss.detach())
             del net, model, out, loss
             torch.cuda.empty_cache()
