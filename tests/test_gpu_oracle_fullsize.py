@@ -176,7 +176,9 @@ def test_training_step_bf16_mode_vs_oracle_at_384x1280(oracle_step):
     print("[bf16] inv-depth mean rel err per scale %s | full-loss gradient: cosine %.4f, norm ratio %.4f"
           % (["%.2e" % m for m in means], cos, ratio))
     assert max(means) <= BF16_INV_MEAN_BOUND, means        # the rounding noise is zero-mean
-    assert cos >= 0.5 and 0.5 <= ratio <= 2.0, (cos, ratio)
+    # (round 4, profiles/r04_bf16_training_fidelity.txt: measured cosine 0.9999, norm ratio 0.9999 against the oracle -- per ELEMENT the two
+    #  gradients differ by O(1) where |Sobel|' = sign follows the forward noise, as a DIRECTION the bf16 gradient is the oracle's)
+    assert cos >= 0.998 and 0.99 <= ratio <= 1.01, (cos, ratio)
     for n, g in got["grads"].items():
         assert bool(torch.isfinite(g).all()), n
 

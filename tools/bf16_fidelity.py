@@ -141,6 +141,9 @@ compare_gradients("    init", batches[0])
 print("\n(ii) training runs")
 l32, s32, final32 = train("fp32", batches)
 l16, s16, final16 = train("bf16", batches)
+# control: the SAME mode twice.  The backward pass is not bit-reproducible (fp32 atomics in a few weight-gradient tails), and Adam divides
+# by sqrt(v): where a gradient element is noise-sized its +-lr step follows the noise -- how far do two identical runs drift apart?
+l32b, s32b, _ = train("fp32", batches)
 print("    step   loss fp32    loss bf16    rel diff | displacement theta_t - theta_0: cosine(bf16, fp32)  norm ratio bf16/fp32  |fp32 displacement|")
 for t in sorted(s32):
     c, r = cos_ratio(s16[t], s32[t])
@@ -148,6 +151,12 @@ for t in sorted(s32):
     a16 = sum(l16[max(0, t - NB):t]) / min(NB, t)
     print("    %4d   %.6f   %.6f   %+.2e |                                   %.4f               %.4f                 %.4e"
           % (t, a32, a16, (a16 - a32) / abs(a32), c, r, float(s32[t].double().norm())))
+print("    control, fp32 run against a SECOND fp32 run (same seeds; the backward's atomics order is the only difference):")
+for t in sorted(s32):
+    c, r = cos_ratio(s32b[t], s32[t])
+    a32 = sum(l32[max(0, t - NB):t]) / min(NB, t)
+    a32b = sum(l32b[max(0, t - NB):t]) / min(NB, t)
+    print("    %4d   %.6f   %.6f   %+.2e |                                   %.4f               %.4f" % (t, a32, a32b, (a32b - a32) / abs(a32), c, r))
 print("    (losses: mean over the last %d steps = one pass over the batch set; first pass fp32 %.6f / bf16 %.6f)" % (NB, sum(l32[:NB]) / NB, sum(l16[:NB]) / NB))
 worst = max(abs(a - b) / abs(a) for a, b in zip(l32, l16))
 print("    largest per-step loss difference over the run: %.2e relative" % worst)
