@@ -1165,22 +1165,17 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
             const unsigned ad = sb + YB + offX[j];
             x1[j][0] = lds_tr16<16 * ROWB_X>(ad); x1[j][1] = lds_tr16<20 * ROWB_X>(ad);
         }
-        if constexpr (TNO == 2)
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(y0[0][0]), "+v"(y0[0][1]), "+v"(y0[TNO - 1][0]), "+v"(y0[TNO - 1][1]),
-                         "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]), "+v"(x0[1][1]));
-        else
-            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(y0[0][0]), "+v"(y0[0][1]), "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]), "+v"(x0[1][1]));
+        // first k16 step's operands are in once the second step's 2 * (TNO + TC) reads are all that is outstanding (LDS returns in order)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TNO + TC)) : "memory");
+        __builtin_amdgcn_sched_barrier(0);            // (the compiler moves register-only MFMAs across an asm wait: pin both sides)
 #pragma unroll
         for (int i = 0; i < TNO; ++i)
 #pragma unroll
             for (int j = 0; j < TC; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(y0[i][0], y0[i][1]), tr_operand(x0[j][0], x0[j][1]), acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);            // keep the first k16 step's MFMAs ahead of the wait for the second step's reads
-        if constexpr (TNO == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y1[0][0]), "+v"(y1[0][1]), "+v"(y1[TNO - 1][0]), "+v"(y1[TNO - 1][1]),
-                         "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]));
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y1[0][0]), "+v"(y1[0][1]), "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TNO; ++i)
 #pragma unroll
@@ -1301,6 +1296,10 @@ template <typename T> int dispatch_wgrad(const WgradArgs& a, hipStream_t st, int
         const bool fits = ((a.M + a.KW) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((a.M - 1) * a.ldy + a.N) * 2 < 0x7ff00000L;
         if (g_wgrad_dma && fits && a.N > 32 && a.Cin_p > 32)
         {
+            // (round 4, measured and NOT adopted: 8 waves of 128 x 64 on the same tile -- 1.5 transposing reads per MFMA instead of 2 -- run 20-30 % slower
+            //  than the 16-wave form on every 256-multiple layer, 256 -> 256 @48x160 167 vs 130 us with the unpack pass: with one barrier per
+            //  32-pixel step the loop needs its four waves per SIMD; development knob 8 = 3 selects it)
+            if (g_wgrad_big == 3 && a.N % 256 == 0 && a.Cin_p % 256 == 0) return launch_wgrad_dma<2, 4, 4, 2>(a, st, parts_cap, parts_out);   // 256 x 256, 8 waves
             if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p % 256 == 0) return launch_wgrad_dma<4, 4, 2, 2>(a, st, parts_cap, parts_out);   // 256 x 256, 16 waves
             if (g_wgrad_big && a.N % 256 == 0 && a.Cin_p >= 128) return launch_wgrad_dma<4, 2, 2, 2>(a, st, parts_cap, parts_out);     // 256 x 128, 8 waves
             if (g_wgrad_big && a.N >= 128 && a.Cin_p % 256 == 0) return launch_wgrad_dma<2, 4, 2, 2>(a, st, parts_cap, parts_out);     // 128 x 256, 8 waves
