@@ -119,6 +119,13 @@ int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float
  * mte_gn_elu_bwd takes the matching one-pass route by itself where the slab of (y, dz) fits (low-resolution layers).
  * (development knob 13 of the -DMTE_DEV build: 0 = streaming two-pass kernels everywhere.) */
 int mte_gn_fwd_is_single_pass(int HW, int C, int has_y2, int dtype);
+/* Round 4: the same route for slabs too large for one workgroup (512 channels at 24x80, 256 at 48x160, 128 at 96x320): a CLUSTER of
+ * 2-8 workgroups holds the slab in registers and exchanges its partial sums through the record area of `stats` (fixed order:
+ * bit-reproducible; the whole buffer must be zero at entry -- MTE_OPT_GN_PREZEROED callers guarantee it, otherwise the library clears it).
+ * The cluster's size depends on the batch, so callers that know B ask mte_gn_fwd_is_single_pass_b; stats_ready = 0 is allowed wherever it
+ * returns 1.  Replaces the same reference ops (nn.GroupNorm(16, C) + nn.ELU of Conv2D, layers01.py:32-38; residual tail :62-73).
+ * (development knob 25 of the -DMTE_DEV build: 0 = no cluster kernels.) */
+int mte_gn_fwd_is_single_pass_b(int B, int HW, int C, int has_y2, int dtype);
 int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats, int stats_ready,
                    const float* gamma, const float* beta, void* z, long ldz,
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);

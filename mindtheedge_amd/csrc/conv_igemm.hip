@@ -1553,6 +1553,7 @@ int mte_debug_set(int key, int value) {
     if (key == 23) { g_igemm8 = value; return MTE_OK; }
     if (key == 24) { g_igemm8_min_tiles = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
+    if (key == 25) return mtei_set_gn(4, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
     if (key == 6) { g_igemm_big = value; return MTE_OK; }
     if (key == 8) { g_wgrad_big = value; return MTE_OK; }

@@ -603,6 +603,261 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
     }
 }
 
+// =====================================================================================================================
+// CLUSTER kernels (round 4): the slab idea for the layers whose (sample, group) slab is too large for ONE workgroup -- 512
+// channels at 24x80 (123 KB), 256 at 48x160 (246 KB), 128 at 96x320 (491 KB, forward) -- where the two dependent streaming
+// launches of 12-50 us each run at 1.3-3 TB/s.  CL workgroups of 256 threads share a slab, each holds its pixel range in
+// registers; the partial sums meet through a few words of global memory:
+//   every workgroup: partials -> its record (agent-scope relaxed stores = write-through), s_waitcnt vmcnt(0), ticket += 1;
+//                    thread 0 polls the ticket (agent-scope relaxed loads) until all CL arrived, then the records are read
+//                    with agent-scope loads and added IN SLOT ORDER by every workgroup (same totals everywhere, bit-reproducible).
+// Forward = 1 read + 1 write (was 2 + 1), backward = 2 reads + 1 write (was 4 + 1).  The hand-off needs every workgroup of a
+// cluster resident at the same time: the grid is B * 16 * CL <= 1024 workgroups of 256 threads with <= 128 VGPRs (4 per CU),
+// the members of a cluster are 8 block ids apart (one XCD, dispatched together), and the poll is bounded.  The exchange words:
+// forward -- this (sample, group)'s share of the statistics buffer's record area (zero at entry: arena / cleared by the
+// launcher; the last reader puts the two counters back to zero); backward -- counters in `red` (zero at entry), records (two
+// floats per workgroup: its share of the group sums) in the same record area (overwritten, not accumulated).
+// =====================================================================================================================
+#define GN_CLUSTER_MAP()                                                                               \
+    constexpr int P = Elem<T>::PER16;                                                                  \
+    constexpr int NT = 256;                                                                            \
+    const int L_ = blockIdx.x, k_ = L_ >> 3;                                                           \
+    const int w = k_ % CL, g = (k_ / CL) % GN_GROUPS, b = (L_ & 7) + 8 * (k_ / (CL * GN_GROUPS));      \
+    if (b >= a.B) return;                                                                              \
+    const int gs = a.C / GN_GROUPS;                                                                    \
+    const int cps = 1 << a.cps_shift;                                                                  \
+    const int ppw = (a.HW + CL - 1) / CL;                  /* pixels per workgroup */                  \
+    const int p0 = w * ppw, p1 = min(a.HW, p0 + ppw);                                                  \
+    const int nchunks = max(0, p1 - p0) << a.cps_shift;                                                \
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;                                           \
+    const int ch0 = g * gs + (t & (cps - 1)) * P;                                                      \
+    double* xch = mte_gn_partials(a.stats, a.B) + ((long)b * MTE_GN_SLOTS(a.B) * 32) + (long)g * (MTE_GN_SLOTS(a.B) * 2);
+
+constexpr unsigned GN_SPIN_MAX = 1u << 24;
+
+// thread 0: all CL workgroups of the cluster have published (bounded: a hand-off that cannot complete leaves wrong numbers, not a hung GPU)
+__device__ __forceinline__ void cluster_wait(unsigned* ticket, unsigned want) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < GN_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+}
+// thread 0, after its workgroup has read the records: the last reader of the cluster zeroes both counters (the buffer can be used again)
+__device__ __forceinline__ void cluster_done(unsigned* ticket, unsigned* done, unsigned cl) {
+    if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cl - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T, bool HAS2, int NCH, int CL>
+__global__ __launch_bounds__(256, 4) void gn_fwd_cluster_kernel(GnArgs a) {
+    GN_CLUSTER_MAP();
+    __shared__ float s_w[NT / 64];
+    __shared__ double s_tot[2];
+    RawRow<HAS2> raw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) load_raw<T, HAS2>(a, (long)b * a.HW + p0 + (id >> a.cps_shift), ch0, raw[i]);
+    }
+    float sc[P];
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (t + i * NT < nchunks) {
+            float v[P];
+            finish_v<T, HAS2>(raw[i], sc, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) s += v[k];
+        }
+    }
+    const double nw = (double)max(0, p1 - p0) * gs;
+    const double Sw = block_sum<NT>(s, s_w, lane, wave);
+    const float mw = nw > 0.0 ? (float)(Sw / nw) : 0.f;    // this workgroup's mean: its second moment is centred on it
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (t + i * NT < nchunks) {
+            float v[P];
+            keep_packed<HAS2>(raw[i]);
+            finish_v<T, HAS2>(raw[i], sc, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) { const float d = v[k] - mw; q = fmaf(d, d, q); }
+        }
+    }
+    const double Qw = block_sum<NT>(q, s_w, lane, wave);
+    unsigned* ticket = (unsigned*)xch; unsigned* done = (unsigned*)(xch + 1);
+    if (t == 0) {
+        __hip_atomic_store(xch + 2 + 2 * w, Sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(xch + 3 + 2 * w, Qw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_wait(ticket, CL);
+        // sum (v - m)^2 over the slab from the per-workgroup (S_w, Q_w about m_w = (float)(S_w / n_w)): Q = sum_w [Q_w + 2 (m_w - m) (S_w - n_w m_w) + n_w (m_w - m)^2]
+        double S = 0.0, sw[CL], qw[CL];
+#pragma unroll
+        for (int k = 0; k < CL; ++k) {
+            sw[k] = __hip_atomic_load(xch + 2 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qw[k] = __hip_atomic_load(xch + 3 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S += sw[k];
+        }
+        const double n = (double)a.HW * gs, m = S / n;
+        double Q = 0.0;
+#pragma unroll
+        for (int k = 0; k < CL; ++k) {
+            const double nk = (double)max(0, min(a.HW, (k + 1) * ppw) - k * ppw) * gs;
+            const double mk = nk > 0.0 ? (double)(float)(sw[k] / nk) : 0.0, dm = mk - m;
+            Q += qw[k] + 2.0 * dm * (sw[k] - nk * mk) + nk * dm * dm;
+        }
+        s_tot[0] = S; s_tot[1] = Q + S * S / n;            // (sum, sum of squares): the stream kernels' format
+        cluster_done(ticket, done, CL);
+    }
+    __syncthreads();
+    const double n = (double)a.HW * gs, S = s_tot[0], sumsq = s_tot[1];
+    if (w == 0 && t < 2) a.stats[((long)b * GN_GROUPS + g) * 2 + t] = t ? sumsq : S;
+    const double md = S / n;
+    double var = sumsq / n - md * md;                      // what the consumers of `stats` will compute
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)md;
+    float ka[P], kb[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float gm = a.gamma[ch0 + k];
+        ka[k] = rstd * gm;
+        kb[k] = a.beta[ch0 + k] - meanf * rstd * gm;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) {
+            float v[P];
+            keep_packed<HAS2>(raw[i]);
+            finish_v<T, HAS2>(raw[i], sc, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) v[k] = elu1(fmaf(v[k], ka[k], kb[k]));
+            *(u32x4_t*)((T*)a.z + ((long)b * a.HW + p0 + (id >> a.cps_shift)) * a.ldz + ch0) = pack16<T>(v);
+        }
+    }
+}
+
+template <typename T, bool HAS2, bool HASDB, int NCH, int CL>
+__global__ __launch_bounds__(256, 4) void gn_bwd_cluster_kernel(GnArgs a) {
+    GN_CLUSTER_MAP();
+    __shared__ float s_part[(NT / 64) * 32];
+    __shared__ float s_r1[32], s_r2[32], s_db[32], s_S[2];
+    __shared__ double s_st[2];
+    if (t < 2) s_st[t] = a.stats[((long)b * GN_GROUPS + g) * 2 + t];
+    RawRow<HAS2> raw[NCH];
+    u32x4_t gr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) {
+            const long pix = (long)b * a.HW + p0 + (id >> a.cps_shift);
+            load_raw<T, HAS2>(a, pix, ch0, raw[i]);
+            gr[i] = *(const u32x4_t*)((const T*)a.dz + pix * a.lddz + ch0);
+        }
+    }
+    __syncthreads();
+    const double n = (double)a.HW * gs;
+    const double md = s_st[0] / n;
+    double var = s_st[1] / n - md * md;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)md, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float xa = rstd, xb = -mean * rstd;
+    float ka[P], kb[P], sc[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float gm = a.gamma[ch0 + k];
+        ka[k] = rstd * gm; kb[k] = a.beta[ch0 + k] - mean * rstd * gm;
+    }
+    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    float r1[P], r2[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { r1[k] = 0.f; r2[k] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (t + i * NT < nchunks) {
+            float v[P], gz[P];
+            finish_v<T, HAS2>(raw[i], sc, v);
+            unpack16<T>(gr[i], gz);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float dyh = gz[k] * elu_grad(fmaf(v[k], ka[k], kb[k]));
+                r1[k] += dyh; r2[k] = fmaf(dyh, fmaf(v[k], xa, xb), r2[k]);
+            }
+        }
+    }
+    block_channel_sums<NT, P>(r1, cps, lane, wave, s_part, s_r1, gs);
+    block_channel_sums<NT, P>(r2, cps, lane, wave, s_part, s_r2, gs);
+    // ---- the apply pass needs the GROUP sums S1 = sum_c gamma_c r1_c, S2 = sum_c gamma_c r2_c of the whole slab: every workgroup publishes
+    // its two partial sums (record area, 2 floats per workgroup; counters in `red`) and adds the CL records up in slot order; the per-channel
+    // sums only feed dgamma / dbeta, which every workgroup adds for itself (sums over the batch: float atomics, as in the slab kernels)
+    float* rec = (float*)xch;
+    unsigned* ticket = (unsigned*)(a.red + ((long)b * a.C + g * gs) * 2); unsigned* done = ticket + 1;
+    if (t < 64) {
+        const float gm = t < gs ? a.gamma[g * gs + t] : 0.f;
+        const float S1w = wave_sum(t < gs ? gm * s_r1[t] : 0.f), S2w = wave_sum(t < gs ? gm * s_r2[t] : 0.f);
+        if (t < gs) {
+            atomicAdd(&a.dgamma[g * gs + t], s_r2[t]);
+            atomicAdd(&a.dbeta[g * gs + t], s_r1[t]);
+        }
+        if (t == 0) {
+            __hip_atomic_store(rec + 2 * w, S1w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + 2 * w + 1, S2w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cluster_wait(ticket, CL);
+            float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < CL; ++k) {
+                S1 += __hip_atomic_load(rec + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S2 += __hip_atomic_load(rec + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_S[0] = S1; s_S[1] = S2;
+            cluster_done(ticket, done, CL);
+        }
+    }
+    __syncthreads();
+    const float inv_n = 1.f / ((float)a.HW * gs);
+    const float c1 = rstd * rstd * (s_S[1] * inv_n);
+    const float c0 = rstd * (s_S[0] * inv_n) - mean * c1;
+    float db[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) db[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = t + i * NT;
+        if (id < nchunks) {
+            const long pix = (long)b * a.HW + p0 + (id >> a.cps_shift);
+            float v[P], gz[P];
+            keep_packed<HAS2>(raw[i]);
+            asm volatile("" : "+v"(gr[i]));
+            finish_v<T, HAS2>(raw[i], sc, v);
+            unpack16<T>(gr[i], gz);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float dyh = gz[k] * elu_grad(fmaf(v[k], ka[k], kb[k]));
+                v[k] = dyh * ka[k] - fmaf(v[k], c1, c0);
+                if constexpr (HASDB) db[k] += v[k];
+            }
+            *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
+            if constexpr (HAS2) {
+                if (a.d2) {
+#pragma unroll
+                    for (int k = 0; k < P; ++k) v[k] *= sc[k];
+                    *(u32x4_t*)((T*)a.d2 + pix * a.ldd2 + ch0) = pack16<T>(v);
+                }
+            }
+        }
+    }
+    if constexpr (HASDB) {
+        block_channel_sums<NT, P>(db, cps, lane, wave, s_part, s_db, gs);
+        if (t < gs) atomicAdd(&a.dbias[g * gs + t], s_db[t]);
+    }
+}
+
 int g_gn_min_rows = 32, g_gn_target = 2048;         // development knobs (mte_debug_set(2 / 3, v))
 int g_gn_slab = 1;                                  // development knob (mte_debug_set(13, v)): 0 = stream kernels only
 
@@ -665,6 +920,53 @@ template <typename T, bool HAS2, bool HASDB> bool launch_bwd_slab(const GnArgs& 
     return false;
 }
 
+int g_gn_cluster = 1;                               // development knob (mte_debug_set(25, v)): 0 = no cluster kernels
+
+// cluster geometry for a slab of n chunks that is too large for the slab kernels: CL workgroups of 256 threads, NCH chunks per thread.
+// regs = 16-byte registers a thread holds per chunk (forward: 1 + second input; backward: 2 + second input).  0 = not a cluster shape.
+int cluster_plan(int B, int HW, int C, long n, int sh, int regs, int* nch) {
+    if (!g_gn_cluster || n <= GN_SLAB_MAX || B < 1) return 0;
+    const int slots = MTE_GN_SLOTS(B);
+    const int samples8 = (B + 7) / 8 * 8;                  // the grid covers whole sets of 8 samples
+    int cl = 8;
+    while (cl > 1 && (samples8 * GN_GROUPS * cl > 1024 || 2 + 2 * cl > slots * 2)) cl >>= 1;
+    if (cl < 2) return 0;
+    const long per_wg = (long)((HW + cl - 1) / cl) << sh;  // chunks of the largest pixel range
+    const int need = (int)((per_wg + 255) / 256);
+    int n_ = 2;
+    while (n_ < need) n_ <<= 1;
+    if (n_ * regs > 12) return 0;                          // <= 128 VGPRs without spills (measured on the compiler's report): four workgroups per CU stay resident
+    *nch = n_;
+    return cl;
+}
+
+template <typename T, bool HAS2, int CL> bool launch_fwd_cluster_cl(const GnArgs& a, int nch, hipStream_t st) {
+    const dim3 grid(8u * GN_GROUPS * CL * ((a.B + 7) / 8));
+#define GN_FWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 ? 2 : 1) <= 12) { hipLaunchKernelGGL((gn_fwd_cluster_kernel<T, HAS2, NCH, CL>), grid, dim3(256), 0, st, a); return true; } }
+    GN_FWD_CL(2) GN_FWD_CL(4) GN_FWD_CL(8)
+#undef GN_FWD_CL
+    return false;
+}
+template <typename T, bool HAS2> bool launch_fwd_cluster(const GnArgs& a, int cl, int nch, hipStream_t st) {
+    if (cl == 8) return launch_fwd_cluster_cl<T, HAS2, 8>(a, nch, st);
+    if (cl == 4) return launch_fwd_cluster_cl<T, HAS2, 4>(a, nch, st);
+    if (cl == 2) return launch_fwd_cluster_cl<T, HAS2, 2>(a, nch, st);
+    return false;
+}
+template <typename T, bool HAS2, bool HASDB, int CL> bool launch_bwd_cluster_cl(const GnArgs& a, int nch, hipStream_t st) {
+    const dim3 grid(8u * GN_GROUPS * CL * ((a.B + 7) / 8));
+#define GN_BWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 ? 3 : 2) <= 12) { hipLaunchKernelGGL((gn_bwd_cluster_kernel<T, HAS2, HASDB, NCH, CL>), grid, dim3(256), 0, st, a); return true; } }
+    GN_BWD_CL(2) GN_BWD_CL(4)
+#undef GN_BWD_CL
+    return false;
+}
+template <typename T, bool HAS2, bool HASDB> bool launch_bwd_cluster(const GnArgs& a, int cl, int nch, hipStream_t st) {
+    if (cl == 8) return launch_bwd_cluster_cl<T, HAS2, HASDB, 8>(a, nch, st);
+    if (cl == 4) return launch_bwd_cluster_cl<T, HAS2, HASDB, 4>(a, nch, st);
+    if (cl == 2) return launch_bwd_cluster_cl<T, HAS2, HASDB, 2>(a, nch, st);
+    return false;
+}
+
 template <typename T> int run_stats(GnArgs& a, hipStream_t stream) {
     constexpr int NT = 1024;
     const int rstep = NT / (a.C / Elem<T>::PER16);
@@ -705,6 +1007,20 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
         else done = launch_bwd_slab<T, false, false>(a, n, stream);
         if (done) return mte_check_launch();
     }
+    if (n > GN_SLAB_MAX && !(a.y2 && a.dbias)) {
+        int nch = 0;
+        const int cl = cluster_plan(a.B, a.HW, a.C, n, sh, a.y2 ? 3 : 2, &nch);
+        if (cl) {
+            a.cps_shift = sh;
+            if (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+            if (mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+            bool done;
+            if (a.y2) done = launch_bwd_cluster<T, true, false>(a, cl, nch, stream);
+            else if (a.dbias) done = launch_bwd_cluster<T, false, true>(a, cl, nch, stream);
+            else done = launch_bwd_cluster<T, false, false>(a, cl, nch, stream);
+            if (done) return mte_check_launch();
+        }
+    }
     a.blocks_per_sample = gn_blocks(a.B, a.HW, 256 / (a.C / Elem<T>::PER16));
     dim3 grid(a.blocks_per_sample, a.B);
     const size_t lds = sizeof(float) * a.C * 2;
@@ -728,6 +1044,7 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
 extern "C" int mtei_set_gn(int which, int value) {
     if (which == 2) { g_gn_slab = value; return MTE_OK; }
     if (which == 3) { g_gn_zigzag = value; return MTE_OK; }
+    if (which == 4) { g_gn_cluster = value; return MTE_OK; }
     if (value < 1) return MTE_ERR_ARG;
     if (which == 0) g_gn_min_rows = value; else g_gn_target = value;
     return MTE_OK;
@@ -742,6 +1059,17 @@ int mte_gn_fwd_is_single_pass(int HW, int C, int has_y2, int dtype) {
     if (!gn_shape_ok(C, dtype)) return 0;
     const long n = slab_chunks(HW, C, dtype, &sh);
     return (n > 0 && n <= GN_SLAB_MAX) ? 1 : 0;
+}
+
+// The same question for a batch of B samples: also 1 where a cluster of workgroups holds the slab (norm_act.hip, CLUSTER kernels; the
+// cluster's size depends on the batch).  Callers that know B ask this one.
+int mte_gn_fwd_is_single_pass_b(int B, int HW, int C, int has_y2, int dtype) {
+    int sh = 0, nch = 0;
+    if (!gn_shape_ok(C, dtype)) return 0;
+    const long n = slab_chunks(HW, C, dtype, &sh);
+    if (n <= 0) return 0;
+    if (n <= GN_SLAB_MAX) return 1;
+    return cluster_plan(B, HW, C, n, sh, has_y2 ? 2 : 1, &nch) ? 1 : 0;
 }
 
 // doubles of a statistics buffer for batch B (final sums + arrival tickets + per-block records, see common.hpp)
@@ -769,11 +1097,21 @@ int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const flo
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats;
     a.gamma = gamma; a.beta = beta; a.z = z; a.ldz = ldz; a.B = B; a.HW = HW; a.C = C; a.eps = eps;
     if (!stats_ready) {
-        if (!mte_gn_fwd_is_single_pass(HW, C, y2 != nullptr, dtype)) return MTE_ERR_ARG;
+        if (!mte_gn_fwd_is_single_pass_b(B, HW, C, y2 != nullptr, dtype)) return MTE_ERR_ARG;
         int sh = 0;
         const long n = slab_chunks(HW, C, dtype, &sh);
         a.cps_shift = sh;
         bool ok;
+        if (n > GN_SLAB_MAX) {                             // a cluster of workgroups per (sample, group)
+            int nch = 0;
+            const int cl = cluster_plan(B, HW, C, n, sh, y2 ? 2 : 1, &nch);
+            // the cluster's exchange words live in the record area of the statistics buffer and must be zero at entry
+            if (!g_mte_gn_prezeroed &&
+                mte_memset_async(mte_gn_partials(stats, B), 0, sizeof(double) * (size_t)B * MTE_GN_SLOTS(B) * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+            if (dtype == MTE_DT_BF16) ok = y2 ? launch_fwd_cluster<bf16_t, true>(a, cl, nch, stream) : launch_fwd_cluster<bf16_t, false>(a, cl, nch, stream);
+            else ok = y2 ? launch_fwd_cluster<float, true>(a, cl, nch, stream) : launch_fwd_cluster<float, false>(a, cl, nch, stream);
+            return ok ? mte_check_launch() : MTE_ERR_ARG;
+        }
         if (dtype == MTE_DT_BF16) ok = y2 ? launch_fwd_slab<bf16_t, true>(a, n, stream) : launch_fwd_slab<bf16_t, false>(a, n, stream);
         else ok = y2 ? launch_fwd_slab<float, true>(a, n, stream) : launch_fwd_slab<float, false>(a, n, stream);
         return ok ? mte_check_launch() : MTE_ERR_ARG;

@@ -810,8 +810,8 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
     st = _stream()
     ready = 1
     stats = gn_stats_buffer(B, y1.device)
-    if lib.mte_gn_fwd_is_single_pass(H * W, C, 1 if y2 is not None else 0, _dt(y1)) == 1:
-        ready = 0                      # low-resolution layer: one kernel holds each (sample, group) slab on chip -- statistics + apply
+    if lib.mte_gn_fwd_is_single_pass_b(B, H * W, C, 1 if y2 is not None else 0, _dt(y1)) == 1:
+        ready = 0                      # one kernel holds each (sample, group) slab on chip (one workgroup, or a cluster of them) -- statistics + apply
     else:
         lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
