@@ -47,6 +47,7 @@ struct GnArgs {
     int blocks_per_sample;
     int cps_shift;                     // slab kernels: log2(chunks per pixel inside one group)
     int reverse;                       // stream kernels: walk the samples last-to-first (see gn_zigzag)
+    int b0, nb, ppl;                   // cluster kernels: this launch covers samples [b0, b0 + nb), nb <= ppl = samples a full launch takes (8, 4, 2 or 1)
 };
 
 // Pixel rows are processed in batches of GN_U: all 16-byte loads of a batch are issued before any of its stores, so a
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
 //                    thread 0 polls the ticket (agent-scope relaxed loads) until all CL arrived, then the records are read
 //                    with agent-scope loads and added IN SLOT ORDER by every workgroup (same totals everywhere, bit-reproducible).
 // Forward = 1 read + 1 write (was 2 + 1), backward = 2 reads + 1 write (was 4 + 1).  The hand-off needs every workgroup of a
-// cluster resident at the same time: the grid is B * 16 * CL <= 1024 workgroups of 256 threads with <= 128 VGPRs (4 per CU),
+// cluster resident at the same time: a launch has <= 1024 LIVE workgroups of 256 threads with <= 128 VGPRs (4 per CU; a batch whose
+// clusters exceed that goes out in 2-4 launches over sample ranges),
 // the members of a cluster are 8 block ids apart (one XCD, dispatched together), and the poll is bounded.  The exchange words:
 // forward -- this (sample, group)'s share of the statistics buffer's record area (zero at entry: arena / cleared by the
 // launcher; the last reader puts the two counters back to zero); backward -- counters in `red` (zero at entry), records (two
@@ -622,8 +624,11 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
     constexpr int P = Elem<T>::PER16;                                                                  \
     constexpr int NT = 256;                                                                            \
     const int L_ = blockIdx.x, k_ = L_ >> 3;                                                           \
-    const int w = k_ % CL, g = (k_ / CL) % GN_GROUPS, b = (L_ & 7) + 8 * (k_ / (CL * GN_GROUPS));      \
-    if (b >= a.B) return;                                                                              \
+    /* a launch covers `ppl` = 8, 4, 2 or 1 samples: sample s owns 8 / ppl XCD labels, each with 16 * ppl / 8 of its groups (whole   */ \
+    /* 128-byte lines: neighbouring groups meet in one L2); the CL members of a cluster are 8 block ids apart (one label)             */ \
+    const int nx_ = 8 / a.ppl, gp_ = GN_GROUPS / nx_;                                                  \
+    const int w = k_ % CL, g = ((L_ & 7) % nx_) * gp_ + (k_ / CL) % gp_, b = a.b0 + (L_ & 7) / nx_;    \
+    if (b >= a.b0 + a.nb) return;                                                                      \
     const int gs = a.C / GN_GROUPS;                                                                    \
     const int cps = 1 << a.cps_shift;                                                                  \
     const int ppw = (a.HW + CL - 1) / CL;                  /* pixels per workgroup */                  \
@@ -693,23 +698,19 @@ __global__ __launch_bounds__(256, 4) void gn_fwd_cluster_kernel(GnArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cluster_wait(ticket, CL);
-        // sum (v - m)^2 over the slab from the per-workgroup (S_w, Q_w about m_w = (float)(S_w / n_w)): Q = sum_w [Q_w + 2 (m_w - m) (S_w - n_w m_w) + n_w (m_w - m)^2]
-        double S = 0.0, sw[CL], qw[CL];
+        // sum v^2 over the slab from the per-workgroup (S_w, Q_w = sum (v - m_w)^2 about m_w = (float)(S_w / n_w)):
+        // sum_w v^2 = Q_w + 2 m_w S_w - n_w m_w^2 for ANY m_w, exactly -- one pass over the records, in slot order
+        double S = 0.0, SQ = 0.0;
 #pragma unroll
         for (int k = 0; k < CL; ++k) {
-            sw[k] = __hip_atomic_load(xch + 2 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            qw[k] = __hip_atomic_load(xch + 3 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            S += sw[k];
-        }
-        const double n = (double)a.HW * gs, m = S / n;
-        double Q = 0.0;
-#pragma unroll
-        for (int k = 0; k < CL; ++k) {
+            const double sk = __hip_atomic_load(xch + 2 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double qk = __hip_atomic_load(xch + 3 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double nk = (double)max(0, min(a.HW, (k + 1) * ppw) - k * ppw) * gs;
-            const double mk = nk > 0.0 ? (double)(float)(sw[k] / nk) : 0.0, dm = mk - m;
-            Q += qw[k] + 2.0 * dm * (sw[k] - nk * mk) + nk * dm * dm;
+            const double mk = nk > 0.0 ? (double)(float)(sk / nk) : 0.0;
+            S += sk;
+            SQ += qk + 2.0 * mk * sk - nk * mk * mk;
         }
-        s_tot[0] = S; s_tot[1] = Q + S * S / n;            // (sum, sum of squares): the stream kernels' format
+        s_tot[0] = S; s_tot[1] = SQ;                       // (sum, sum of squares): the stream kernels' format
         cluster_done(ticket, done, CL);
     }
     __syncthreads();
@@ -924,46 +925,66 @@ int g_gn_cluster = 1;                               // development knob (mte_deb
 
 // cluster geometry for a slab of n chunks that is too large for the slab kernels: CL workgroups of 256 threads, NCH chunks per thread.
 // regs = 16-byte registers a thread holds per chunk (forward: 1 + second input; backward: 2 + second input).  0 = not a cluster shape.
-int cluster_plan(int B, int HW, int C, long n, int sh, int regs, int* nch) {
+int cluster_plan(int B, int HW, int C, long n, int sh, int regs, int* nch, int* per_launch) {
     if (!g_gn_cluster || n <= GN_SLAB_MAX || B < 1) return 0;
     const int slots = MTE_GN_SLOTS(B);
-    const int samples8 = (B + 7) / 8 * 8;                  // the grid covers whole sets of 8 samples
-    int cl = 8;
-    while (cl > 1 && (samples8 * GN_GROUPS * cl > 1024 || 2 + 2 * cl > slots * 2)) cl >>= 1;
-    if (cl < 2) return 0;
+    // the registers decide the workgroups per slab: <= 128 VGPRs without spills (measured on the compiler's report) = 12 sixteen-byte data
+    // registers per thread, so four workgroups per CU stay resident
+    int nmax = 8;
+    while (nmax * regs > 12) nmax >>= 1;
+    if (nmax < 2) return 0;
+    // (measured, tools/gn_bench.py: clusters of 16 with the batch in two launches of 4 samples -- 256 channels at 48x160 backward, 128 at 96x320
+    //  forward -- run 1.4-2.3x SLOWER than the streaming kernels: 66 vs 48 us, 89 vs 38 us; a cluster pays only when ONE launch of <= 8
+    //  workgroups per slab covers 8 samples)
+    int cl = 2;
+    while (cl < 8 && ((long)((HW + cl - 1) / cl) << sh) > 256L * nmax) cl <<= 1;
     const long per_wg = (long)((HW + cl - 1) / cl) << sh;  // chunks of the largest pixel range
-    const int need = (int)((per_wg + 255) / 256);
+    if (per_wg > 256L * nmax || 2 + 2 * cl > slots * 2) return 0;
     int n_ = 2;
-    while (n_ < need) n_ <<= 1;
-    if (n_ * regs > 12) return 0;                          // <= 128 VGPRs without spills (measured on the compiler's report): four workgroups per CU stay resident
+    while (256L * n_ < per_wg) n_ <<= 1;
     *nch = n_;
+    // every LIVE workgroup of a launch must be resident (1024 of 256 threads): samples per launch; the batch goes out in several launches
+    const int pl = 8;                                      // (the block map would also deal 4, 2 or 1 samples to the 8 XCD labels)
+    if (pl * GN_GROUPS * cl > 1024) return 0;
+    if ((B + pl - 1) / pl > 4) return 0;                   // more than four launches: the streaming kernels are the better form
+    *per_launch = pl;
     return cl;
 }
 
-template <typename T, bool HAS2, int CL> bool launch_fwd_cluster_cl(const GnArgs& a, int nch, hipStream_t st) {
-    const dim3 grid(8u * GN_GROUPS * CL * ((a.B + 7) / 8));
-#define GN_FWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 ? 2 : 1) <= 12) { hipLaunchKernelGGL((gn_fwd_cluster_kernel<T, HAS2, NCH, CL>), grid, dim3(256), 0, st, a); return true; } }
+template <typename T, bool HAS2, int CL> bool launch_fwd_cluster_cl(GnArgs a, int nch, int per_launch, hipStream_t st) {
+    const dim3 grid((unsigned)(per_launch * GN_GROUPS * CL));
+    a.ppl = per_launch;
+#define GN_FWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 ? 2 : 1) <= 12) { \
+        for (a.b0 = 0; a.b0 < a.B; a.b0 += per_launch) { a.nb = a.B - a.b0 < per_launch ? a.B - a.b0 : per_launch;          \
+            hipLaunchKernelGGL((gn_fwd_cluster_kernel<T, HAS2, NCH, CL>), grid, dim3(256), 0, st, a); }                      \
+        return true; } }
     GN_FWD_CL(2) GN_FWD_CL(4) GN_FWD_CL(8)
 #undef GN_FWD_CL
     return false;
 }
-template <typename T, bool HAS2> bool launch_fwd_cluster(const GnArgs& a, int cl, int nch, hipStream_t st) {
-    if (cl == 8) return launch_fwd_cluster_cl<T, HAS2, 8>(a, nch, st);
-    if (cl == 4) return launch_fwd_cluster_cl<T, HAS2, 4>(a, nch, st);
-    if (cl == 2) return launch_fwd_cluster_cl<T, HAS2, 2>(a, nch, st);
+template <typename T, bool HAS2> bool launch_fwd_cluster(const GnArgs& a, int cl, int nch, int per_launch, hipStream_t st) {
+    if (cl == 16) return launch_fwd_cluster_cl<T, HAS2, 16>(a, nch, per_launch, st);
+    if (cl == 8) return launch_fwd_cluster_cl<T, HAS2, 8>(a, nch, per_launch, st);
+    if (cl == 4) return launch_fwd_cluster_cl<T, HAS2, 4>(a, nch, per_launch, st);
+    if (cl == 2) return launch_fwd_cluster_cl<T, HAS2, 2>(a, nch, per_launch, st);
     return false;
 }
-template <typename T, bool HAS2, bool HASDB, int CL> bool launch_bwd_cluster_cl(const GnArgs& a, int nch, hipStream_t st) {
-    const dim3 grid(8u * GN_GROUPS * CL * ((a.B + 7) / 8));
-#define GN_BWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 ? 3 : 2) <= 12) { hipLaunchKernelGGL((gn_bwd_cluster_kernel<T, HAS2, HASDB, NCH, CL>), grid, dim3(256), 0, st, a); return true; } }
+template <typename T, bool HAS2, bool HASDB, int CL> bool launch_bwd_cluster_cl(GnArgs a, int nch, int per_launch, hipStream_t st) {
+    const dim3 grid((unsigned)(per_launch * GN_GROUPS * CL));
+    a.ppl = per_launch;
+#define GN_BWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 ? 3 : 2) <= 12) { \
+        for (a.b0 = 0; a.b0 < a.B; a.b0 += per_launch) { a.nb = a.B - a.b0 < per_launch ? a.B - a.b0 : per_launch;          \
+            hipLaunchKernelGGL((gn_bwd_cluster_kernel<T, HAS2, HASDB, NCH, CL>), grid, dim3(256), 0, st, a); }               \
+        return true; } }
     GN_BWD_CL(2) GN_BWD_CL(4)
 #undef GN_BWD_CL
     return false;
 }
-template <typename T, bool HAS2, bool HASDB> bool launch_bwd_cluster(const GnArgs& a, int cl, int nch, hipStream_t st) {
-    if (cl == 8) return launch_bwd_cluster_cl<T, HAS2, HASDB, 8>(a, nch, st);
-    if (cl == 4) return launch_bwd_cluster_cl<T, HAS2, HASDB, 4>(a, nch, st);
-    if (cl == 2) return launch_bwd_cluster_cl<T, HAS2, HASDB, 2>(a, nch, st);
+template <typename T, bool HAS2, bool HASDB> bool launch_bwd_cluster(const GnArgs& a, int cl, int nch, int per_launch, hipStream_t st) {
+    if (cl == 16) return launch_bwd_cluster_cl<T, HAS2, HASDB, 16>(a, nch, per_launch, st);
+    if (cl == 8) return launch_bwd_cluster_cl<T, HAS2, HASDB, 8>(a, nch, per_launch, st);
+    if (cl == 4) return launch_bwd_cluster_cl<T, HAS2, HASDB, 4>(a, nch, per_launch, st);
+    if (cl == 2) return launch_bwd_cluster_cl<T, HAS2, HASDB, 2>(a, nch, per_launch, st);
     return false;
 }
 
@@ -1008,16 +1029,16 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
         if (done) return mte_check_launch();
     }
     if (n > GN_SLAB_MAX && !(a.y2 && a.dbias)) {
-        int nch = 0;
-        const int cl = cluster_plan(a.B, a.HW, a.C, n, sh, a.y2 ? 3 : 2, &nch);
+        int nch = 0, pl = 0;
+        const int cl = cluster_plan(a.B, a.HW, a.C, n, sh, a.y2 ? 3 : 2, &nch, &pl);
         if (cl) {
             a.cps_shift = sh;
             if (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
             if (mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
             bool done;
-            if (a.y2) done = launch_bwd_cluster<T, true, false>(a, cl, nch, stream);
-            else if (a.dbias) done = launch_bwd_cluster<T, false, true>(a, cl, nch, stream);
-            else done = launch_bwd_cluster<T, false, false>(a, cl, nch, stream);
+            if (a.y2) done = launch_bwd_cluster<T, true, false>(a, cl, nch, pl, stream);
+            else if (a.dbias) done = launch_bwd_cluster<T, false, true>(a, cl, nch, pl, stream);
+            else done = launch_bwd_cluster<T, false, false>(a, cl, nch, pl, stream);
             if (done) return mte_check_launch();
         }
     }
@@ -1064,12 +1085,12 @@ int mte_gn_fwd_is_single_pass(int HW, int C, int has_y2, int dtype) {
 // The same question for a batch of B samples: also 1 where a cluster of workgroups holds the slab (norm_act.hip, CLUSTER kernels; the
 // cluster's size depends on the batch).  Callers that know B ask this one.
 int mte_gn_fwd_is_single_pass_b(int B, int HW, int C, int has_y2, int dtype) {
-    int sh = 0, nch = 0;
+    int sh = 0, nch = 0, pl = 0;
     if (!gn_shape_ok(C, dtype)) return 0;
     const long n = slab_chunks(HW, C, dtype, &sh);
     if (n <= 0) return 0;
     if (n <= GN_SLAB_MAX) return 1;
-    return cluster_plan(B, HW, C, n, sh, has_y2 ? 2 : 1, &nch) ? 1 : 0;
+    return cluster_plan(B, HW, C, n, sh, has_y2 ? 2 : 1, &nch, &pl) ? 1 : 0;
 }
 
 // doubles of a statistics buffer for batch B (final sums + arrival tickets + per-block records, see common.hpp)
@@ -1103,13 +1124,13 @@ int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const flo
         a.cps_shift = sh;
         bool ok;
         if (n > GN_SLAB_MAX) {                             // a cluster of workgroups per (sample, group)
-            int nch = 0;
-            const int cl = cluster_plan(B, HW, C, n, sh, y2 ? 2 : 1, &nch);
+            int nch = 0, pl = 0;
+            const int cl = cluster_plan(B, HW, C, n, sh, y2 ? 2 : 1, &nch, &pl);
             // the cluster's exchange words live in the record area of the statistics buffer and must be zero at entry
             if (!g_mte_gn_prezeroed &&
                 mte_memset_async(mte_gn_partials(stats, B), 0, sizeof(double) * (size_t)B * MTE_GN_SLOTS(B) * 32, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-            if (dtype == MTE_DT_BF16) ok = y2 ? launch_fwd_cluster<bf16_t, true>(a, cl, nch, stream) : launch_fwd_cluster<bf16_t, false>(a, cl, nch, stream);
-            else ok = y2 ? launch_fwd_cluster<float, true>(a, cl, nch, stream) : launch_fwd_cluster<float, false>(a, cl, nch, stream);
+            if (dtype == MTE_DT_BF16) ok = y2 ? launch_fwd_cluster<bf16_t, true>(a, cl, nch, pl, stream) : launch_fwd_cluster<bf16_t, false>(a, cl, nch, pl, stream);
+            else ok = y2 ? launch_fwd_cluster<float, true>(a, cl, nch, pl, stream) : launch_fwd_cluster<float, false>(a, cl, nch, pl, stream);
             return ok ? mte_check_launch() : MTE_ERR_ARG;
         }
         if (dtype == MTE_DT_BF16) ok = y2 ? launch_fwd_slab<bf16_t, true>(a, n, stream) : launch_fwd_slab<bf16_t, false>(a, n, stream);
