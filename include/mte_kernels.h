@@ -54,9 +54,10 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
 #define MTE_OPT_GN_PREZEROED 0
 int mte_set_option(int option, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
- * pixels is split over workgroups; when their number fits stage_parts each one stores its PARTIAL gradient in its own part
- * (plain stores; *parts_out = parts written, mte_unpack_conv_wgrad adds them), otherwise -- always with stage_parts = 1 --
- * they are combined with fp32 atomics in part 0 (*parts_out = 1). */
+ * pixels is split over at most stage_parts workgroup groups; each one stores its PARTIAL gradient in its own part (plain stores;
+ * *parts_out = parts written, mte_unpack_conv_wgrad adds them in part order: round 4 -- no floating-point atomics on the conv weight
+ * gradient's path, the result does not depend on the order in which workgroups finish).  mte_unpack_conv_wgrad with parts > 32 uses
+ * up to 32 further slabs BEHIND the parts as scratch: a stage of more than 32 parts is allocated with parts + 32 slabs. */
 int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int stage_parts, int* parts_out,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
 /* OIHW fp32 master weights -> forward pack [Cout][taps][Cin_p] and (optional) dgrad pack [Cin_p][taps rot180][Cout_p] */

@@ -1241,10 +1241,12 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st, int parts_cap, int* parts_out)
     const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    // one partial gradient per pixel split (plain stores, summed in part order by the unpack pass): never more splits than the caller's stage
+    // has parts -- round 4: the fp32-atomic combine that used to take over beyond stage_parts is gone from this kernel's launch path, the
+    // weight gradient is a fixed-order sum (the atomics cost 0.4 ms per step when they were the default, and made the result order-dependent)
+    if (splits > parts_cap) splits = parts_cap < 1 ? 1 : parts_cap;
     a.blocks_per_split = (int)((nblk + splits - 1) / splits);
     a.splits = (int)((nblk + a.blocks_per_split - 1) / a.blocks_per_split);
-    // partial gradients per pixel split when the caller's stage has room for them: plain stores, summed by the unpack pass
-    // (the fp32 atomics of the combine-in-place form cost 0.4 ms per step: up to 64 K per workgroup onto shared addresses)
     if (a.splits > 1 && a.splits <= parts_cap) {
         a.part_stride = (long)a.N * taps * a.Cin_p;
         if (parts_out) *parts_out = a.splits;
@@ -1480,25 +1482,27 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
 }
 
 // First level of the two-level combine of many partial gradients (the LDS-patch weight gradient leaves one slab per workgroup,
-// 128..512 of them): part 0 += sum of parts 1..P-1.  Block (x, y) adds PC consecutive parts over 1024 consecutive floats with
-// 16-byte loads, all PC loads of a thread in flight together, then 4 float atomics per thread into part 0 (P/PC adders per
-// address).  The fp32-atomic combine this replaces pushed every workgroup's whole slab (75-105 MB per launch) through the
-// ~1.3 TB/s atomic path onto the SAME 150-200 KB: 58-80 us of a 190-330 us kernel.
+// 128..512 of them).  Block (x, y) adds the RP_PC consecutive parts [y * RP_PC, (y + 1) * RP_PC) over 1024 consecutive floats with
+// 16-byte loads, all RP_PC loads of a thread in flight together, IN PART ORDER, and stores the sum as slab y of the scratch area BEHIND the
+// parts (st + parts * elems); the unpack pass then adds the <= 32 scratch slabs in order.  Round 4: plain stores instead of float atomics
+// onto part 0 -- the weight gradient no longer depends on the order in which workgroups arrive (bit-reproducible backward for the conv
+// weights), for (parts / 16) / parts = 6 % more bytes.  (History: the one-level fp32-atomic combine pushed every workgroup's whole slab,
+// 75-105 MB per launch, through the ~1.3 TB/s atomic path onto the SAME 150-200 KB: 58-80 us of a 190-330 us kernel.)
 constexpr int RP_PC = 16;
-__global__ __launch_bounds__(256) void reduce_parts_kernel(float* __restrict__ st, long elems, int parts) {
+__global__ __launch_bounds__(256) void reduce_parts_kernel(float* __restrict__ st, long elems, int parts, int pc) {
     const long i4 = blockIdx.x * 256L + threadIdx.x;                 // float4 index inside a slab
     if (i4 * 4 >= elems) return;
-    const int p0 = 1 + blockIdx.y * RP_PC;
-    f32x4_t v[RP_PC];
+    const int p0 = blockIdx.y * pc, p1 = min(parts, p0 + pc);        // this block's parts (pc = a multiple of RP_PC)
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int q = p0; q < p1; q += RP_PC) {
+        f32x4_t v[RP_PC];
 #pragma unroll
-    for (int k = 0; k < RP_PC; ++k)
-        v[k] = p0 + k < parts ? *(const f32x4_t*)(st + (long)(p0 + k) * elems + i4 * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    f32x4_t acc = v[0];
+        for (int k = 0; k < RP_PC; ++k)
+            v[k] = q + k < p1 ? *(const f32x4_t*)(st + (long)(q + k) * elems + i4 * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 1; k < RP_PC; ++k) acc += v[k];
-    float* dst = st + i4 * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(dst + k, acc[k]);
+        for (int k = 0; k < RP_PC; ++k) acc += v[k];
+    }
+    *(f32x4_t*)(st + ((long)parts + blockIdx.y) * elems + i4 * 4) = acc;
 }
 
 // column sums of a [M][N] (row stride ld) matrix: bias gradient
@@ -1675,11 +1679,13 @@ int mte_unpack_conv_wgrad(float* dw_stage, int parts, float* dw_oihw, int Cout, 
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dw_stage || !dw_oihw || parts < 1) return MTE_ERR_ARG;
     const dim3 grid(Cout, (Cin + 63) / 64);
-    if (parts > 32) {                                                // many partials: parallel first level, then the transpose reads one slab
+    if (parts > 32) {                                                // many partials: parallel first level into the scratch slabs behind them, then <= 32 to add
         const long elems = (long)Cout * KH * KW * Cin_p;
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((elems / 4 + 255) / 256), (unsigned)((parts - 1 + RP_PC - 1) / RP_PC)), dim3(256), 0, stream,
-                           dw_stage, elems, parts);
-        parts = 1;
+        const int pc = ((parts + 31) / 32 + RP_PC - 1) / RP_PC * RP_PC;              // parts per first-level block: <= 32 groups
+        const int groups = (parts + pc - 1) / pc;
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((elems / 4 + 255) / 256), (unsigned)groups), dim3(256), 0, stream, dw_stage, elems, parts, pc);
+        dw_stage += (long)parts * elems;
+        parts = groups;
     }
     hipLaunchKernelGGL(unpack_wgrad_kernel, grid, dim3(256), sizeof(float) * KH * KW * 65, stream, dw_stage, dw_oihw, Cout, Cin, KH * KW, Cin_p, parts);
     return mte_check_launch();

@@ -674,6 +674,7 @@ template <int K, int NT, int SL, int NW = 4, int NH = 1, int THW = 8> int launch
     // ~2 workgroups per CU in total; the 147 KB wide variant (NH = 2) holds one per CU: one round of workgroups, half the slabs to add up
     long groups = ((NH == 2 ? 256 : g_patch_wgrad_wgs) + nslices - 1) / nslices;
     if (groups > ntiles) groups = ntiles;
+    if (groups > parts_cap) groups = parts_cap < 1 ? 1 : parts_cap;   // one slab per workgroup group, always (round 4: no fp32-atomic combine on this launch path)
     a.groups = (int)groups;
     static bool attr_set = false;
     if (!attr_set) {

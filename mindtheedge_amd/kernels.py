@@ -736,7 +736,7 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     stem = _stem_ok(W, Cp, cout, kh, kw, x.dtype)
     if stem:
         cap = 2048                       # 25 KB slabs: eight 256-thread workgroups per CU keep this bandwidth-bound stream busy
-    stage = torch.empty((cap, cout, kh * kw, Cp), dtype=torch.float32, device=x.device)
+    stage = torch.empty((cap + (32 if cap > 32 else 0), cout, kh * kw, Cp), dtype=torch.float32, device=x.device)   # (+ 32: scratch of the two-level part sum)
     parts = ctypes.c_int(1)
     if stem:
         lib.mte_conv2d_stem_wgrad(xp, ldx, dyp, lddy, stage.data_ptr(), cap, ctypes.byref(parts), B, H, W, cout, kh, kw, st)
