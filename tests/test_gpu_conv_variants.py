@@ -112,7 +112,7 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape, devlib):
     cin, cout, k, B, H, W = shape
 
     def run(big):
-        K.lib.mte_debug_set(6, big)
+        K.lib.mte_debug_set(6, big); K.lib.mte_debug_set(23, 0)      # (the older tile forms are the subject: 8-phase kernels off)
         K.lib.mte_debug_set(7, 1)
         orig, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)
         try:
@@ -129,7 +129,7 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape, devlib):
             return y.float().cpu(), None if dx is None else dx.float().cpu()
         finally:
             K._splitk_workspace = orig
-            K.lib.mte_debug_set(6, 3)
+            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
             K.lib.mte_debug_set(7, 224)
 
     K.use_patch_kernels(False)
@@ -162,7 +162,7 @@ def test_igemm_pingpong_loop_matches_one_barrier_loop(shape, devlib):
     K.use_patch_kernels(False)
 
     def run(big, pp):
-        K.lib.mte_debug_set(6, big)
+        K.lib.mte_debug_set(6, big); K.lib.mte_debug_set(23, 0)      # (the older tile forms are the subject: 8-phase kernels off)
         K.lib.mte_debug_set(7, 1)
         K.lib.mte_debug_set(21, pp)
         y = K.conv_forward(xa, wf, b, cout, k, k)
@@ -176,7 +176,7 @@ def test_igemm_pingpong_loop_matches_one_barrier_loop(shape, devlib):
     finally:
         K._splitk_workspace = orig
         K.use_patch_kernels(True)
-        K.lib.mte_debug_set(6, 3)
+        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
         K.lib.mte_debug_set(7, 224)
         K.lib.mte_debug_set(21, 1)
 
@@ -192,7 +192,7 @@ def test_big_tile_split_k_matches_small_tiles(shape, devlib):
     try:
         outs = []
         for big in (2, 0, 2, 0):
-            K.lib.mte_debug_set(6, big)
+            K.lib.mte_debug_set(6, big); K.lib.mte_debug_set(23, 0)      # (the older tile forms are the subject: 8-phase kernels off)
             g = torch.Generator().manual_seed(11 + cin)
             w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
             b = (torch.rand(cout, generator=g) - 0.5).cuda()
@@ -203,7 +203,7 @@ def test_big_tile_split_k_matches_small_tiles(shape, devlib):
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
         assert float(outs[0].abs().mean()) > 0.1                 # (not trivially zero)
     finally:
-        K.lib.mte_debug_set(6, 3)
+        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
         K.use_patch_kernels(True)
 
 
@@ -216,7 +216,7 @@ def test_igemm_192x96_tiles_match_128x128_tiles(shape, devlib):
     cin, cout, k, B, H, W = shape
 
     def run(big):
-        K.lib.mte_debug_set(6, big)
+        K.lib.mte_debug_set(6, big); K.lib.mte_debug_set(23, 0)      # (the older tile forms are the subject: 8-phase kernels off)
         K.lib.mte_debug_set(7, 1)
         orig, K._splitk_workspace = K._splitk_workspace, lambda *a: (None, 0)
         try:
@@ -231,7 +231,7 @@ def test_igemm_192x96_tiles_match_128x128_tiles(shape, devlib):
             return y.float().cpu(), acc.float().cpu()
         finally:
             K._splitk_workspace = orig
-            K.lib.mte_debug_set(6, 3)
+            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
             K.lib.mte_debug_set(7, 224)
 
     K.use_patch_kernels(False)
@@ -241,4 +241,61 @@ def test_igemm_192x96_tiles_match_128x128_tiles(shape, devlib):
         assert torch.equal(y3, y0) and torch.equal(a3, a0)
         assert float(y0.abs().mean()) > 0.05
     finally:
+        K.use_patch_kernels(True)
+
+
+IGEMM8_SHAPES = [  # cin, cout, k, B, H, W, channels per input pixel (None = cin): odd K-step counts, column / row tails, 64 / 96 / 160-channel taps
+    (64, 256, 3, 2, 24, 40, None), (96, 256, 3, 3, 10, 52, None), (32, 384, 5, 1, 17, 33, None), (128, 384, 1, 2, 16, 48, None),
+    (256, 256, 3, 2, 48, 80, None), (64, 200, 3, 2, 40, 64, 96), (128, 128, 3, 2, 48, 96, None), (96, 128, 3, 1, 33, 47, None),
+    (512, 104, 3, 1, 24, 80, None), (160, 136, 3, 1, 31, 45, 200), (32, 128, 7, 1, 64, 96, None), (1024, 512, 3, 1, 12, 40, None),
+]
+
+
+@pytest.mark.parametrize("persistent", [False, True])
+@pytest.mark.parametrize("shape", IGEMM8_SHAPES)
+def test_eight_phase_igemm_equals_the_128x128_tile_bit_for_bit(devlib, shape, persistent):
+    """round 4 (csrc/conv_igemm8.hip): the 8-phase kernels -- 256 x 256 and 256 x 128 tiles, one tile per workgroup and the tile-walking
+    form -- accumulate the same K-steps in the same order as every other tile form, so forced onto small and awkward shapes (development
+    knob 23 = 7 / 15, 24 = 1) they must reproduce the 4-wave 128 x 128 kernel BIT FOR BIT, repeatedly (a stale LDS slot or a fragment read
+    that overtakes its DMA shows on some repetitions only), with and without accumulation into the output and through a channel-slice
+    output; the split-K form (different grouping of the fp32 sums) to one bf16 rounding."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W, ldx = shape
+    K.set_compute_dtype("bf16")
+    K.use_patch_kernels(False)
+    saved = K._splitk_workspace
+    try:
+        g = torch.Generator().manual_seed(3 + cin + cout)
+        w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+        b = (torch.rand(cout, generator=g) - 0.5).cuda()
+        buf = K.new_act(B, ldx or cin, H, W)
+        buf.copy_((torch.rand(B, ldx or cin, H, W, generator=g) * 2 - 1).cuda())
+        x = K.channel_slice(buf, 0, cin) if ldx else buf
+        wf, _ = K.WeightPack().get(w, x.dtype, True)
+        y0 = K.new_act(B, cout + 8, H, W)
+        y0.copy_(torch.randn(B, cout + 8, H, W, generator=g).cuda())
+
+        def run(v8, split, accumulate):
+            devlib.mte_debug_set(23, v8); devlib.mte_debug_set(24, 1000000 if split else 1); devlib.mte_debug_set(6, 0)
+            K._splitk_workspace = (lambda M, N, dev: (torch.empty((8 * M * N,), dtype=torch.float32, device=dev), 8 * M * N)) if split else (lambda *a: (None, 0))
+            out = y0.clone()
+            K.conv_forward(x, wf, b, cout, k, k, out=K.channel_slice(out, 0, cout), accumulate=accumulate)
+            torch.cuda.synchronize()
+            return out
+
+        v8 = 15 if persistent else 7
+        for accumulate in (False, True):
+            ref = run(0, False, accumulate)
+            for rep in range(3):
+                assert torch.equal(run(v8, False, accumulate), ref), (shape, accumulate, rep)
+            assert torch.equal(ref[:, cout:], y0[:, cout:])                     # nothing written past the slice
+        # split-K: the new kernel against itself (bitwise) and against the unsplit result (one bf16 rounding)
+        first = run(v8, True, False)
+        assert torch.equal(run(v8, True, False), first)
+        ref = run(0, False, False)
+        d = (first.float() - ref.float()).abs()
+        assert float((d - ref.float().abs() * 2.0 ** -7).max()) <= 1e-3
+    finally:
+        K._splitk_workspace = saved
+        devlib.mte_debug_set(23, 3); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
         K.use_patch_kernels(True)

@@ -27,10 +27,12 @@ for cin, cout, k, B, H, W in shapes:
     pack = K.WeightPack()
     wf, wb = pack.get(w, xa.dtype, True)
 
-    def run(big, pp):
+    def run(big, pp, v8=0):
         K.lib.mte_debug_set(6, big)
         K.lib.mte_debug_set(7, 1)
         K.lib.mte_debug_set(21, pp)
+        K.lib.mte_debug_set(23, v8)                   # 8-phase kernels (round 4): 0 off, 7 every eligible launch, 15 the tile-walking form
+        K.lib.mte_debug_set(24, 1)
         if noise is not None:                         # something else on the chip: another queue streaming HBM and a GEMM under the launch
             with torch.cuda.stream(noise):
                 nb.copy_(na)
@@ -40,10 +42,11 @@ for cin, cout, k, B, H, W in shapes:
         return y
 
     ref = run(0, 0).clone()
-    for big, pp, name in ((1, 0, "256x128 8 waves"), (2, 0, "256x256 16 waves"), (2, 1, "256x256 ping-pong")):
+    for big, pp, v8, name in ((1, 0, 0, "256x128 8 waves"), (2, 0, 0, "256x256 16 waves"), (2, 1, 0, "256x256 ping-pong"),
+                              (0, 0, 7, "8-phase"), (0, 0, 15, "8-phase tile-walking")):
         miss = 0
         for r in range(reps):
-            y = run(big, pp)
+            y = run(big, pp, v8)
             if not torch.equal(y, ref):
                 miss += 1
                 if miss == 1:
@@ -51,6 +54,6 @@ for cin, cout, k, B, H, W in shapes:
                     print("   first mismatch at rep %d: %d elements differ, max |d| %.3e" % (r, int((d > 0).sum()), float(d.max())))
         bad += miss
         print("%4d -> %-4d k%d B%d %dx%-4d %-20s %d / %d repetitions differ" % (cin, cout, k, B, H, W, name, miss, reps))
-K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(7, 224); K.lib.mte_debug_set(21, 1)
+K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(7, 224); K.lib.mte_debug_set(21, 1); K.lib.mte_debug_set(23, 3); K.lib.mte_debug_set(24, 200)
 print("MISMATCHES:", bad)
 sys.exit(1 if bad else 0)
