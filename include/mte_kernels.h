@@ -49,8 +49,8 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
                      float* workspace, long workspace_elems, int accumulate, mte_stream_t stream);
 /* Library options.  MTE_OPT_GN_PREZEROED (0): when 1, the GroupNorm statistics / reduction / bias-gradient buffers handed to
- * mte_gn_stats and mte_gn_elu_bwd are already zero (the caller clears one arena per step with a single fill) and the library
- * skips its own per-call fills. */
+ * mte_gn_stats and mte_gn_elu_bwd -- and, since round 4, that call's dgamma / dbeta -- are already zero (the caller clears one arena
+ * per step with a single fill; a zeroed flat gradient buffer qualifies) and the library skips its own per-call fills. */
 #define MTE_OPT_GN_PREZEROED 0
 int mte_set_option(int option, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over

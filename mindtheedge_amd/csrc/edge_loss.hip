@@ -15,15 +15,15 @@
 //     row, so every global access is a 16-byte load / store (1 KiB per wave instruction);
 //   * every global load of a workgroup (tile + halo, labels, normals) is issued before its first use, so a workgroup pays
 //     one memory latency, not one per phase;
-//   * sums accumulate in fp32 per thread and per wave, are combined in fp64 per workgroup and leave it as one fp64 atomic
-//     per value into the accumulators of its (scale, sample): <= 240 adds per address, spread over the launch (the
-//     mask statistics are skipped when there is no mask).  A fixed-order reduction of per-workgroup partials by the last
-//     workgroup was measured first: its serial sweep over 2,568 partial records took ~120 us, six times the stencil;
-//   * the LAST workgroup to arrive (one agent-scope release per workgroup, one ticket, one acquire in the last one:
-//     cdna_hip_programming.md guideline 16 / in-launch split-K recipe) computes alpha, the loss scalars and the backward
-//     coefficients on the device: no reduce / finalize launches, no host sync.
+//   * sums: fp32 per thread and per wave, fp64 per workgroup; a workgroup leaves ONE 128-byte record, the last workgroup of a
+//     (scale, sample) to arrive (agent-scope ticket) adds that image's <= 240 records in a fixed order, and the LAST of those computes
+//     alpha, the loss scalars and the backward coefficients on the device from an LDS copy of the 32 images' sums (one thread per
+//     scale): no reduce / finalize launches, no host sync, no floating-point atomics -- losses and coefficients are bit-reproducible
+//     (round 4; rounds 1-3 added each value with one fp64 atomic per workgroup: 1,680 adds on one cache line per full-resolution
+//     image cost half of the launch, and the single-thread scalar tail another 15 us: forward 73 -> see profiles/README.md).
 // HBM-bound: 12 B/pixel forward (inv, edge, normal), 16 B/pixel backward (+4 B gradient write).
 #include "common.hpp"
+#include "edge_direction.hpp"
 
 namespace {
 
@@ -31,6 +31,8 @@ constexpr int TW = 64, TH = 32;         // output tile (256 threads x 2 passes x
 constexpr int LS = 72;                  // LDS row stride in floats: image column j of the tile sits at index 4 + j (16-byte aligned interior)
 constexpr int MAXS = 4;                 // scales per launch
 constexpr int NP = 13;                  // partial sums per workgroup: 6 edge sums, 4 mask statistics, 3 silog sums
+constexpr int REC = 16;                 // doubles per workgroup record (one 128-byte line)
+constexpr int FWD_TILES_PER_WG = 3;     // forward: consecutive tiles per workgroup (856 workgroups at T8: one round of the 1024 slots)
 
 struct EdgeScale {
     const float* pred;                  // inv-depth (from_inv), depth, or probability map
@@ -38,14 +40,16 @@ struct EdgeScale {
     float* gmap;                        // forward: optional edge-strength map output
     float* dpred;                       // backward output
     int H, W, tiles_x, tiles_y, first_block, vec;                // vec: 16-byte accesses are legal (W % 4 == 0, aligned bases)
+    int groups;                         // workgroups per image: each takes `tiles_per_wg` consecutive tiles (row-major)
 };
 
 struct EdgeMulti {
     EdgeScale s[MAXS];
-    int nscales, B, nblocks;
+    int nscales, B, nblocks, tiles_per_wg;
     int from_inv, is_grad, is_sigmoid, finalize;
     float thresh, weight, pos_to_neg;
-    double* results;                    // [nscales][B][NP] accumulators (zeroed by the launcher)
+    double* results;                    // [nscales][B][NP] sums of each (scale, sample) (zeroed by the launcher; written by the image's last workgroup)
+    double* records;                    // [nblocks][REC]: one record of partial sums per workgroup
     unsigned* counter;                  // [0] launch ticket, [1 + s*B + b] ticket of (scale, sample) (zeroed by the launcher)
     float* losses;                      // forward out: [nscales]
     float* coef;                        // forward out / backward in: [nscales][2B + 1]
@@ -55,18 +59,18 @@ struct EdgeMulti {
     const float* silog_gout;            // backward: upstream gradient of the silog loss (device, nullable = 1)
 };
 
-__device__ __forceinline__ int direction_code(float n) {
-    // thresholds = float32(k*pi/8), half-open bins, later assignments win (grad_loss.py:80-93)
-    const float P1 = (float)(1 * 3.14159265358979323846 / 8), P3 = (float)(3 * 3.14159265358979323846 / 8),
-                P5 = (float)(5 * 3.14159265358979323846 / 8), P7 = (float)(7 * 3.14159265358979323846 / 8);
-    int code = 0;                                                   // 0: h
-    if ((n >= -P5 && n < -P3) || (n >= P3 && n < P5)) code = 1;     // v
-    if ((n >= -P7 && n < -P5) || (n >= P1 && n < P3)) code = 2;     // rl
-    if ((n >= -P3 && n < -P1) || (n >= P5 && n < P7)) code = 3;     // lr
-    return code;
+// 1 / x as v_rcp_f32 (1 ulp) + one Newton step: r' = r + r (1 - x r), the two fmas of the IEEE division sequence without its scaling and
+// fix-up instructions (3 instructions instead of ~10).  x is in [1e-6, ~1e3] here -- no denormals, overflow or division by zero to fix up -- and
+// the result is within 1 ulp of the correctly rounded quotient (almost always equal to it).
+__device__ __forceinline__ float rcp_newton(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.f), r);
 }
-
-__device__ __forceinline__ float to_depth(int from_inv, float v) { return from_inv ? 1.f / fmaxf(v, 1e-6f) : v; }
+#if defined(MTE_EDGE_ABLATE) && (MTE_EDGE_ABLATE & 4)
+__device__ __forceinline__ float to_depth(int from_inv, float v) { return from_inv ? 1.f / fmaxf(v, 1e-6f) : v; }   // diagnostic: the IEEE division of rounds 1-3
+#else
+__device__ __forceinline__ float to_depth(int from_inv, float v) { return from_inv ? rcp_newton(fmaxf(v, 1e-6f)) : v; }
+#endif
 
 // 4 consecutive floats of row `row` starting at column x (x % 4 == 0); zero beyond the image
 __device__ __forceinline__ f32x4_t load4(const float* base, long row, int x, int W, int vec) {
@@ -155,29 +159,47 @@ __device__ __forceinline__ void sobel4(const float w[3][6], int k, float& sh, fl
 }
 // 1-ulp reciprocal (v_rcp_f32): enough wherever the result is not differenced against a neighbour (the depth tile keeps IEEE division)
 __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float sigmoidf(float x) { return rcpf(1.f + __expf(-x)); }
+// natural log / exp on the transcendental unit without the denormal-range scaling of __logf / __expf (5 extra instructions each): every
+// argument here is >= 1e-4 (p + 0.001, 10 (inv + 1e-5), 10 / depth), and an exp that underflows may flush to zero (1 + t follows)
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
-struct BlockId { int s, b, x0, y0; };
+// wave-wide sum, every lane ends with the total: xor butterfly over quad_perm / row_half_mirror / row_mirror DPP operands (lanes 1, 2, 4, 8 apart)
+// and the two lane-swap instructions of gfx950 (rows, then halves) -- 6 adds + 2 swaps instead of 6 ds_bpermute round trips
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);          // {rows 0 0 2 2, rows 1 1 3 3}
+    v = __builtin_bit_cast(float, (unsigned)r16[0]) + __builtin_bit_cast(float, (unsigned)r16[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto r32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);          // {lower half twice, upper half twice}
+    return __builtin_bit_cast(float, (unsigned)r32[0]) + __builtin_bit_cast(float, (unsigned)r32[1]);
+}
+
+struct BlockId { int s, b, t0, t1; };                            // tiles t0 .. t1 - 1 of sample b of scale s
 __device__ __forceinline__ BlockId decode_block(const EdgeMulti& a) {
     BlockId id;
     int s = 0;
 #pragma unroll
     for (int k = 1; k < MAXS; ++k) if (k < a.nscales && (int)blockIdx.x >= a.s[k].first_block) s = k;
-    int r = blockIdx.x - a.s[s].first_block;
-    const int tx = r % a.s[s].tiles_x; r /= a.s[s].tiles_x;
-    const int ty = r % a.s[s].tiles_y;
-    id.s = s; id.b = r / a.s[s].tiles_y; id.x0 = tx * TW; id.y0 = ty * TH;
+    const int r = blockIdx.x - a.s[s].first_block;
+    const int g = r % a.s[s].groups, tiles = a.s[s].tiles_x * a.s[s].tiles_y;
+    id.s = s; id.b = r / a.s[s].groups;
+    id.t0 = g * a.tiles_per_wg; id.t1 = id.t0 + a.tiles_per_wg < tiles ? id.t0 + a.tiles_per_wg : tiles;
     return id;
 }
 
 // ---------------- forward -----------------------------------------------------------------------------------------
-__device__ void finalize_losses(const EdgeMulti& a);
+__device__ void finalize_losses(const EdgeMulti& a, double* stage, int stage_elems);
 
 // FAST = the training configuration on every scale (16-byte accesses legal, inverse depth in, Sobel + normals + sigmoid, no mask):
 // the flags are compile-time there.  The generic instantiation carries every runtime flag -- its body is ~10k instructions
 // (scalar and vector access paths, magnitude / probability / mask branches), several times what the instruction cache likes.
 template <bool FAST>
-__global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
+__global__ __launch_bounds__(256, FAST ? 4 : 2) void edge_loss_fwd_kernel(EdgeMulti a) {
     __shared__ __attribute__((aligned(16))) float sd[(TH + 2) * LS];
     __shared__ float sred[4][NP];
     __shared__ int s_last;
@@ -193,39 +215,44 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
     const int from_inv = FAST ? 1 : a.from_inv;
     const long img = (long)id.b * sc.H;
 
-    // every global load of the workgroup first: one memory latency for the tile, the labels and the normals together
-    DepthTile<1> tile;
-    if (is_grad) tile.issue(sc, vec, id.b, id.x0, id.y0);
-    f32x4_t e4[2], n4[2], m4[2], d4[2], i4[2];
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int gy = id.y0 + r0 + 16 * ps;
-        const bool ok = gy < sc.H;
-        e4[ps] = ok ? load4(sc.edge, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (has_normal && is_grad) n4[ps] = ok ? load4(sc.normal, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (has_mask) m4[ps] = ok ? load4(sc.mask, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (silog) {
-            d4[ps] = ok ? load4(a.gt_depth, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            i4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-        if (!is_grad) i4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    if (is_grad) tile.commit(sc, from_inv, id.x0, id.y0, sd);
-    __syncthreads();
-
     float acc[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+    // a workgroup walks `tiles_per_wg` consecutive tiles of its image and keeps the sums in registers: the record / ticket round trips
+    // at the end (two dependent trips to the memory side, ~5 us with the slot held) are paid once per 3 tiles instead of per tile
+    for (int t = id.t0; t < id.t1; ++t) {
+    const int x0 = (t % sc.tiles_x) * TW, y0 = (t / sc.tiles_x) * TH;
+    if (t != id.t0) __syncthreads();                              // the previous tile's window reads are done
+        // every global load of the workgroup first: one memory latency for the tile, the labels and the normals together
+        DepthTile<1> tile;
+        if (is_grad) tile.issue(sc, vec, id.b, x0, y0);
+        f32x4_t e4[2], n4[2], m4[2], d4[2], i4[2];
+    #pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int gy = y0 + r0 + 16 * ps;
+            const bool ok = gy < sc.H;
+            e4[ps] = ok ? load4(sc.edge, img + gy, x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (has_normal && is_grad) n4[ps] = ok ? load4(sc.normal, img + gy, x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (has_mask) m4[ps] = ok ? load4(sc.mask, img + gy, x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (silog) {
+                d4[ps] = ok ? load4(a.gt_depth, img + gy, x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                i4[ps] = ok ? load4(sc.pred, img + gy, x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            if (!is_grad) i4[ps] = ok ? load4(sc.pred, img + gy, x0 + c, sc.W, vec) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        if (is_grad) tile.commit(sc, from_inv, x0, y0, sd);
+        __syncthreads();
+
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-        const int ly = r0 + 16 * ps, gy = id.y0 + ly;
+        const int ly = r0 + 16 * ps, gy = y0 + ly;
         if (gy >= sc.H) continue;
         float w[3][6];
         if (is_grad) window(sd, ly + 1, c, w);
         f32x4_t g4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (id.x0 + c + k >= sc.W) { g4[k] = 0.f; continue; }
+            if (x0 + c + k >= sc.W) { g4[k] = 0.f; continue; }
             float g;
             if (is_grad) {
                 float sh, sv, srl, slr;
@@ -243,10 +270,14 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
             // p = 1 / (1 + t), 1 - p = t p with t = exp(-(g - thresh)): the reference forms 1 - p by subtraction in float32, which
             // loses everything once p rounds towards 1 (g - thresh > ~8); t p is exact to an ulp and agrees wherever that is defined
             float p, omp;
-            if (is_sigmoid) { const float t = __expf(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
+            if (is_sigmoid) { const float t = fast_exp(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
             else { p = g; omp = 1.f - g; }
             const float e = e4[ps][k];
-            const float pos = -e * __logf(p + 0.001f), neg = -(1.f - e) * __logf(omp + 0.001f);
+#if defined(MTE_EDGE_ABLATE) && (MTE_EDGE_ABLATE & 2)
+            const float pos = -e * g, neg = -(1.f - e) * g;          // diagnostic: no exp / rcp / log
+#else
+            const float pos = -e * fast_log(p + 0.001f), neg = -(1.f - e) * fast_log(omp + 0.001f);
+#endif
             acc[2] += pos; acc[3] += neg;
             if (has_mask) {
                 const float m = m4[ps][k];
@@ -260,95 +291,131 @@ __global__ __launch_bounds__(256, 4) void edge_loss_fwd_kernel(EdgeMulti a) {
             if (silog) {
                 const float d = d4[ps][k];
                 if (d > 0.f) {
-                    const float gt = 1.f / fmaxf(d, 1e-6f);
-                    const float dl = __logf((i4[ps][k] + 1e-5f) * 10.f) - __logf(gt * 10.f);
+                    const float gt = rcpf(fmaxf(d, 1e-6f));           // feeds a log: 1 ulp here is 6e-8 absolute there
+                    const float dl = fast_log((i4[ps][k] + 1e-5f) * 10.f) - fast_log(gt * 10.f);
                     acc[10] += dl; acc[11] = fmaf(dl, dl, acc[11]); acc[12] += 1.f;
                 }
             }
         }
-        if (!FAST && sc.gmap) store4(sc.gmap, img + gy, id.x0 + c, sc.W, vec, g4);
+        if (!FAST && sc.gmap) store4(sc.gmap, img + gy, x0 + c, sc.W, vec, g4);
     }
-    // fp32 within the wave, fp64 across the waves and across workgroups
+    }   // tiles of this workgroup
+#if defined(MTE_EDGE_ABLATE) && (MTE_EDGE_ABLATE & 1)
+    { float tt = 0.f; for (int i = 0; i < NP; ++i) tt += acc[i]; if (tt == 123.456f) a.losses[0] = tt; return; }      // diagnostic: no reductions, atomics, tickets
+#endif
+    // ---- sums.  fp32 per thread and per wave (xor butterfly in DPP / lane-swap instructions), fp64 from there on.  Round 4: NO atomic
+    //      adds.  The workgroup leaves ONE record (its own 128-byte line); the last workgroup of a (scale, sample) to arrive adds that
+    //      image's <= 240 records in a FIXED order and writes the image's sums; the last of those finishes the losses.  Every sum of the
+    //      launch has a fixed order, so losses and coefficients are bit-reproducible.  (Before: one fp64 atomicAdd per value into the
+    //      image's accumulators -- 7 x 240 adds on ONE cache line per full-resolution image, serialised at its L2 channel: 27 us of a
+    //      54 us launch.  A first fixed-order attempt in round 1 had ONE workgroup sweep all 2,568 records: ~120 us.)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         if (i >= 4 && i < 10 && !has_mask) continue;
         if (i >= 10 && !silog) continue;
-        const float s = wave_sum(acc[i]);
+        const float s = wave_sum_dpp(acc[i]);
         if (lane == 0) sred[wave][i] = s;
     }
     __syncthreads();
-    if (tid < NP) {
-        const bool live = !((tid >= 4 && tid < 10 && !has_mask) || (tid >= 10 && !silog));
-        if (live) {
-            // RETURNING atomic: the value comes back only after the add has been performed at the memory side, so once this wave
-            // has its results every add of this workgroup is globally visible (a no-return add is acknowledged earlier: with it
-            // the ticket below was seen to overtake an add about once per few thousand workgroups)
-            const double before = atomicAdd(&a.results[((long)id.s * a.B + id.b) * NP + tid],
-                                            (double)sred[0][tid] + (double)sred[1][tid] + (double)sred[2][tid] + (double)sred[3][tid]);
-            asm volatile("" ::"v"(before));
-        }
+    const bool live = tid < NP && !((tid >= 4 && tid < 10 && !has_mask) || (tid >= 10 && !silog));
+    if (live) {
+        // RETURNING exchange: the value comes back only after the store has been performed at the memory side (a plain store, or a
+        // no-return atomic, is acknowledged earlier: the ticket below was seen to overtake it about once per few thousand workgroups)
+        const double v = (double)sred[0][tid] + (double)sred[1][tid] + (double)sred[2][tid] + (double)sred[3][tid];
+        const unsigned long long before = atomicExch((unsigned long long*)(a.records + (long)blockIdx.x * REC) + tid, (unsigned long long)__double_as_longlong(v));
+        asm volatile("" ::"v"(before));
     }
-    // ---- the last workgroup to arrive finishes the losses.  The payload is the fp64 atomics above: device-scope, performed at
-    //      the memory side (nothing of it sits in this CU's L1 / this XCD's L2), so there is nothing for a write-back fence to
-    //      write back -- the adding wave waits for its returned values (vmcnt), the workgroup meets at a barrier, then one lane
-    //      draws a ticket, and the last workgroup reads the accumulators with agent-scope loads.  Two levels of tickets -- per (scale, sample), then one per
-    //      launch -- because 2,568 workgroups on ONE word serialise at ~88 tickets/us (29 us, longer than the stencil itself).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        int last = 0;
-        const unsigned per_image = (unsigned)(sc.tiles_x * sc.tiles_y);
-        const unsigned old = __hip_atomic_fetch_add(a.counter + 1 + id.s * a.B + id.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == per_image - 1) {
-            const unsigned old2 = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = old2 == (unsigned)(a.nscales * a.B - 1);
-        }
-        s_last = last;
-    }
+    const int per_image = sc.groups;                               // records (= workgroups) of this image
+    if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter + 1 + id.s * a.B + id.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(per_image - 1);
     __syncthreads();
     if (!s_last) return;
-    finalize_losses(a);
+    // ---- last workgroup of this (scale, sample): value v = tid % 16 of records k, k + 16, ... (k = tid / 16), then the 16 part sums in order
+    {
+        double* s_fin = (double*)sd;                               // the tile is dead (barriers above)
+        const int v = tid & 15, k = tid >> 4;
+        const double* rec = a.records + ((long)sc.first_block + (long)id.b * per_image) * REC + v;
+        double part = 0.0;
+        if (v < NP && !((v >= 4 && v < 10 && !has_mask) || (v >= 10 && !silog))) {
+#pragma unroll 4
+            for (int j = k; j < per_image; j += 16) part += __hip_atomic_load(rec + (long)j * REC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_fin[k * 16 + v] = part;
+        __syncthreads();
+        if (live) {
+            double tot = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) tot += s_fin[kk * 16 + tid];
+            const unsigned long long before = atomicExch((unsigned long long*)(a.results + ((long)id.s * a.B + id.b) * NP) + tid, (unsigned long long)__double_as_longlong(tot));
+            asm volatile("" ::"v"(before));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.nscales * a.B - 1);
+        __syncthreads();
+        if (!s_last) return;
+    }
+    finalize_losses(a, (double*)sd, (TH + 2) * LS / 2);
 }
 
-// Runs in the last workgroup: every accumulator is complete.  Thread 0 does the scalar arithmetic of comp_cross_entropy
-// (grad_loss.py:161-219) and SilogLoss (supervised_loss.py:57-69) once per scale.
+// Runs in the last workgroup: every accumulator is complete.  The scalar arithmetic of comp_cross_entropy (grad_loss.py:161-219) and
+// SilogLoss (supervised_loss.py:57-69) is a few hundred dependent reads of the accumulators; straight from memory (agent-scope loads,
+// one L2 round trip each, one thread) that serial tail was ~45 us of a 73 us launch (round 4: forward 73 -> see profiles/README.md).  So the
+// whole workgroup first copies the accumulators into LDS (`stage`: the depth tile's storage, free by now; one round trip), and one
+// thread PER SCALE (+ one for the silog loss, in another wave) does the arithmetic from there.
 __device__ __forceinline__ double acc_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ void finalize_losses(const EdgeMulti& a) {
+struct AccView {
+    const double* g; const double* l;                            // l != nullptr: the LDS copy
+    __device__ __forceinline__ double operator()(long i) const { return l ? l[i] : acc_load(g + i); }
+};
+__device__ void finalize_losses(const EdgeMulti& a, double* stage, int stage_elems) {
     const int tid = threadIdx.x;
-    if (tid != 0 || !a.finalize) return;
-    for (int s = 0; s < a.nscales; ++s) {
-        const double* R = a.results + (long)s * a.B * NP;
-        double mi[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int b = 0; b < a.B; ++b)
-            for (int k = 0; k < 4; ++k) mi[k] += acc_load(R + b * NP + 6 + k);
-        const bool has_mask = a.s[s].mask != nullptr;
-        const bool binary = has_mask && mi[2] == 0.0 && mi[0] > 0.0 && mi[1] > 0.0;      // unique(mask) == {0, 1}
-        const double nvalid = binary ? mi[3] : (double)a.B * a.s[s].H * a.s[s].W;
-        double wneg_total = 0.0;
-        for (int b = 0; b < a.B; ++b) wneg_total += (double)(float)acc_load(R + b * NP + 1);
-        double total = 0.0;
-        float* coef = a.coef + (long)s * (2 * a.B + 1);
-        for (int b = 0; b < a.B; ++b) {
-            const double* sums = R + b * NP;
-            const float wp = (float)acc_load(sums), wn = (float)acc_load(sums + 1);
-            const float alpha = wneg_total == 0.0 ? 1.f : wn / (wp + wn);
-            const double P = binary ? acc_load(sums + 4) : acc_load(sums + 2), N = binary ? acc_load(sums + 5) : acc_load(sums + 3);
-            total += (double)a.pos_to_neg * alpha * P + (double)(1.f - alpha) * N;
-            coef[2 * b] = (float)((double)a.weight * a.pos_to_neg * alpha / nvalid);
-            coef[2 * b + 1] = (float)((double)a.weight * (1.f - alpha) / nvalid);
-        }
-        coef[2 * a.B] = binary ? 1.f : 0.f;
-        a.losses[s] = (float)((double)a.weight * total / nvalid);
+    if (!a.finalize) return;
+    const int n = a.nscales * a.B * NP;
+    const bool staged = n <= stage_elems;
+    if (staged) {
+        __syncthreads();                                          // every wave is done with the tile
+        for (int i = tid; i < n; i += 256) stage[i] = acc_load(a.results + i);
+        __syncthreads();
     }
-    if (a.gt_depth) {                                             // loss = 10 sqrt(E[d^2] - 0.85 E[d]^2);  aux = (mean, 10/sqrt(S)/n)
+    const AccView R0{a.results, staged ? stage : nullptr};
+    const int lanes = staged ? a.nscales : 1;                     // one thread per scale from LDS; one thread for all of them from memory
+    if (tid < lanes) {
+        for (int s = staged ? tid : 0; s < (staged ? tid + 1 : a.nscales); ++s) {
+            const long R = (long)s * a.B * NP;
+            double mi[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int b = 0; b < a.B; ++b)
+                for (int k = 0; k < 4; ++k) mi[k] += R0(R + b * NP + 6 + k);
+            const bool has_mask = a.s[s].mask != nullptr;
+            const bool binary = has_mask && mi[2] == 0.0 && mi[0] > 0.0 && mi[1] > 0.0;      // unique(mask) == {0, 1}
+            const double nvalid = binary ? mi[3] : (double)a.B * a.s[s].H * a.s[s].W;
+            double wneg_total = 0.0;
+            for (int b = 0; b < a.B; ++b) wneg_total += (double)(float)R0(R + b * NP + 1);
+            double total = 0.0;
+            float* coef = a.coef + (long)s * (2 * a.B + 1);
+            for (int b = 0; b < a.B; ++b) {
+                const long sums = R + b * NP;
+                const float wp = (float)R0(sums), wn = (float)R0(sums + 1);
+                const float alpha = wneg_total == 0.0 ? 1.f : wn / (wp + wn);
+                const double P = binary ? R0(sums + 4) : R0(sums + 2), N = binary ? R0(sums + 5) : R0(sums + 3);
+                total += (double)a.pos_to_neg * alpha * P + (double)(1.f - alpha) * N;
+                coef[2 * b] = (float)((double)a.weight * a.pos_to_neg * alpha / nvalid);
+                coef[2 * b + 1] = (float)((double)a.weight * (1.f - alpha) / nvalid);
+            }
+            coef[2 * a.B] = binary ? 1.f : 0.f;
+            a.losses[s] = (float)((double)a.weight * total / nvalid);
+        }
+    }
+    if (a.gt_depth && tid == (staged ? 64 : 0)) {                 // loss = 10 sqrt(E[d^2] - 0.85 E[d]^2);  aux = (mean, 10/sqrt(S)/n)
         double ss[3] = {0.0, 0.0, 0.0};
         for (int b = 0; b < a.B; ++b)
-            for (int k = 0; k < 3; ++k) ss[k] += acc_load(a.results + (long)b * NP + 10 + k);
-        const double n = ss[2];
-        const double m1 = ss[0] / n, m2 = ss[1] / n;
+            for (int k = 0; k < 3; ++k) ss[k] += R0((long)b * NP + 10 + k);
+        const double n1 = ss[2];
+        const double m1 = ss[0] / n1, m2 = ss[1] / n1;
         const double S = m2 - 0.85 * m1 * m1;
         if (a.silog_loss) *a.silog_loss = (float)(sqrt(S) * 10.0);
-        if (a.silog_aux) { a.silog_aux[0] = (float)m1; a.silog_aux[1] = (float)(10.0 / sqrt(S) / n); }
+        if (a.silog_aux) { a.silog_aux[0] = (float)m1; a.silog_aux[1] = (float)(10.0 / sqrt(S) / n1); }
     }
 }
 
@@ -381,21 +448,21 @@ __global__ void edge_loss_finalize_kernel(const double* __restrict__ sums, int B
 }
 
 // ---------------- backward ----------------------------------------------------------------------------------------
-// transposed Sobel weights: d s_code(p) / d depth(p + t) for tap t = (dy, dx):  h: dx (2 - |dy|), v: dy (2 - |dx|), rl: dx - dy, lr: dx + dy
-__device__ __forceinline__ float tap_weight(int code, int dy, int dx) {
-    const float kh = (float)(dx * (2 - (dy < 0 ? -dy : dy))), kv = (float)(dy * (2 - (dx < 0 ? -dx : dx)));
-    const float krl = (float)(dx - dy), klr = (float)(dx + dy);
-    return code == 0 ? kh : (code == 1 ? kv : (code == 2 ? krl : klr));
-}
-
+// Transposed Sobel.  d s_code(p) / d depth(p + t) for tap t = (dy, dx) is  h: dx (2 - |dy|), v: dy (2 - |dx|), rl: dx - dy, lr: dx + dy.  With the
+// four tap patterns X[t] = dx, Y[t] = dy, Xc[t] = dx [dy = 0], Yc[t] = dy [dx = 0] these are h = X + Xc, v = Y + Yc, rl = X - Y, lr = X + Y, so
+//   d loss / d depth(q) = sum_t  A(q - t) X[t] + B(q - t) Y[t] + C(q - t) Xc[t] + D(q - t) Yc[t]
+// with per-pixel planes A = G [code != v], B = G (v: 1, rl: -1, lr: 1, h: 0), C = G [code = h], D = G [code = v].  X and Y are separable
+// (column sums of A, row differences of B shared by the 4 pixels of a thread), Xc / Yc touch one row / one column, and C, D need no storage:
+// C = A where B = 0, D = B where A = 0 (G = 0 makes all four vanish).  ~80 instructions per 4 pixels; the per-tap select by the neighbour's
+// code it replaces (rounds 1-3) took ~420.  Magnitude mode (no normals): A = C = the h part, B = D = the v part.
 template <bool FAST>
 __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
-    // depth on the tile + 2-pixel halo; G = d loss / d s(p) (and the direction code) on the tile + 1-pixel halo
+    // depth on the tile + 2-pixel halo; the planes A, B of G = d loss / d s(p) on the tile + 1-pixel halo
     __shared__ __attribute__((aligned(16))) float sd[(TH + 4) * LS];
-    __shared__ __attribute__((aligned(16))) float sga[(TH + 2) * LS], sgb[(TH + 2) * LS];
-    __shared__ __attribute__((aligned(16))) int scode[(TH + 2) * LS];
-    const BlockId id = decode_block(a);
+    __shared__ __attribute__((aligned(16))) float sga[(TH + 2) * LS], sgb[(TH + 2) * LS];        // planes A and B (see above)
+    const BlockId id = decode_block(a);                            // one tile per workgroup (tiles_per_wg = 1)
     const EdgeScale& sc = a.s[id.s];
+    const int x0 = (id.t0 % sc.tiles_x) * TW, y0 = (id.t0 / sc.tiles_x) * TH;
     const int tid = threadIdx.x;
     const int c = (tid & 15) * 4, r0 = tid >> 4;
     const long img = (long)id.b * sc.H;
@@ -415,22 +482,22 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
     f32x4_t ge[NG], gn[NG], gm[NG];
     f32x4_t inv4[2], d4[2], oe4[2], om4[2];
     if (is_grad) {
-        tile.issue(sc, vec, id.b, id.x0, id.y0);
+        tile.issue(sc, vec, id.b, x0, y0);
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int i = tid + k * 256;
             const int ly = i / (TW / 4 + 2), q = i % (TW / 4 + 2);               // q < 16: interior group, 16 / 17: left / right halo column
-            const int gy = id.y0 + ly - 1;
+            const int gy = y0 + ly - 1;
             const bool group = q < TW / 4;
             const int j0 = group ? q * 4 : (q == TW / 4 ? -1 : TW);
             ge[k] = f32x4_t{0.f, 0.f, 0.f, 0.f}; gn[k] = ge[k]; gm[k] = f32x4_t{1.f, 1.f, 1.f, 1.f};
             if (i < GITEMS && (unsigned)gy < (unsigned)sc.H) {
                 if (group) {
-                    ge[k] = load4(sc.edge, img + gy, id.x0 + j0, sc.W, vec);
-                    if (!magnitude) gn[k] = load4(sc.normal, img + gy, id.x0 + j0, sc.W, vec);
-                    if (use_keep) gm[k] = load4(sc.mask, img + gy, id.x0 + j0, sc.W, vec);
-                } else if ((unsigned)(id.x0 + j0) < (unsigned)sc.W) {
-                    const long idx = (img + gy) * sc.W + id.x0 + j0;
+                    ge[k] = load4(sc.edge, img + gy, x0 + j0, sc.W, vec);
+                    if (!magnitude) gn[k] = load4(sc.normal, img + gy, x0 + j0, sc.W, vec);
+                    if (use_keep) gm[k] = load4(sc.mask, img + gy, x0 + j0, sc.W, vec);
+                } else if ((unsigned)(x0 + j0) < (unsigned)sc.W) {
+                    const long idx = (img + gy) * sc.W + x0 + j0;
                     ge[k][0] = sc.edge[idx];
                     if (!magnitude) gn[k][0] = sc.normal[idx];
                     if (use_keep) gm[k][0] = sc.mask[idx];
@@ -440,25 +507,25 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
     }
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-        const int gy = id.y0 + r0 + 16 * ps;
-        const bool ok = gy < sc.H && id.x0 + c < sc.W;
+        const int gy = y0 + r0 + 16 * ps;
+        const bool ok = gy < sc.H && x0 + c < sc.W;
         const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-        inv4[ps] = ok ? load4(sc.pred, img + gy, id.x0 + c, sc.W, vec) : z;
-        if (silog) d4[ps] = ok ? load4(a.gt_depth, img + gy, id.x0 + c, sc.W, vec) : z;
+        inv4[ps] = ok ? load4(sc.pred, img + gy, x0 + c, sc.W, vec) : z;
+        if (silog) d4[ps] = ok ? load4(a.gt_depth, img + gy, x0 + c, sc.W, vec) : z;
         if (!is_grad) {
-            oe4[ps] = ok ? load4(sc.edge, img + gy, id.x0 + c, sc.W, vec) : z;
-            om4[ps] = (ok && use_keep) ? load4(sc.mask, img + gy, id.x0 + c, sc.W, vec) : f32x4_t{1.f, 1.f, 1.f, 1.f};
+            oe4[ps] = ok ? load4(sc.edge, img + gy, x0 + c, sc.W, vec) : z;
+            om4[ps] = (ok && use_keep) ? load4(sc.mask, img + gy, x0 + c, sc.W, vec) : f32x4_t{1.f, 1.f, 1.f, 1.f};
         }
     }
     if (is_grad) {
-        tile.commit(sc, from_inv, id.x0, id.y0, sd);
+        tile.commit(sc, from_inv, x0, y0, sd);
         __syncthreads();
 #pragma unroll
         for (int kq = 0; kq < NG; ++kq) {
             const int i = tid + kq * 256;
             if (i >= GITEMS) break;
             const int ly = i / (TW / 4 + 2), q = i % (TW / 4 + 2);
-            const int gy = id.y0 + ly - 1;
+            const int gy = y0 + ly - 1;
             const bool group = q < TW / 4;
             const int j0 = group ? q * 4 : (q == TW / 4 ? -1 : TW);
             const int np = group ? 4 : 1;
@@ -475,12 +542,13 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k >= np) break;
-                const int gx = id.x0 + j0 + k;
-                float ga = 0.f, gb = 0.f; int code = 0;
+                const int gx = x0 + j0 + k;
+                float ga = 0.f, gb = 0.f;       // planes A (X coefficient) and B (Y coefficient)
                 if (rowok && (unsigned)gx < (unsigned)sc.W) {
                     float sh, sv, srl, slr;
                     sobel4(w, k, sh, sv, srl, slr);
                     float g, da, db = 0.f;        // d g / d s_a, d g / d s_b
+                    int code = 0;
                     if (!magnitude) {
                         code = direction_code(n4[k]);
                         const float s = code == 0 ? sh : (code == 1 ? sv : (code == 2 ? srl : slr));
@@ -491,17 +559,21 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
                         da = sv / g; db = sh / g;                  // a = v, b = h
                     }
                     float p, omp;                  // p and 1 - p without cancellation (see the forward kernel)
-                    if (is_sigmoid) { const float t = __expf(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
+                    if (is_sigmoid) { const float t = fast_exp(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
                     else { p = g; omp = 1.f - g; }
                     const float e = e4[k];
                     const float keep = (use_keep && m4[k] == 0.f) ? 0.f : 1.f;
                     const float dp = is_sigmoid ? p * omp : 1.f;
                     const float dg = keep * dp * (-cpos * e * rcpf(p + 0.001f) + cneg * (1.f - e) * rcpf(omp + 0.001f));
-                    ga = dg * da; gb = dg * db;
+                    if (magnitude) { ga = dg * db; gb = dg * da; }             // h part, v part
+                    else {
+                        const float G = dg * da;
+                        ga = code != 1 ? G : 0.f;
+                        gb = code == 1 ? G : (code == 2 ? -G : (code == 3 ? G : 0.f));
+                    }
                 }
                 const int o = ly * LS + 4 + j0 + k;
-                sga[o] = ga; scode[o] = code;
-                if (magnitude) sgb[o] = gb;
+                sga[o] = ga; sgb[o] = gb;
             }
         }
         __syncthreads();
@@ -509,32 +581,27 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
     const float m1 = silog ? a.silog_aux[0] : 0.f, ksl = silog ? a.silog_aux[1] * (a.silog_gout ? a.silog_gout[0] : 1.f) : 0.f;
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-        const int ly = r0 + 16 * ps, gy = id.y0 + ly;
-        if (gy >= sc.H || id.x0 + c >= sc.W) continue;
+        const int ly = r0 + 16 * ps, gy = y0 + ly;
+        if (gy >= sc.H || x0 + c >= sc.W) continue;
         f32x4_t out = {0.f, 0.f, 0.f, 0.f};
         if (is_grad) {
-            // d loss / d depth(q) = sum_p G(p) K_code(p)[q - p]: the 3 x 6 windows of G and code around the 4 pixels
-            float wa[3][6], wb[3][6]; int wc[3][6];
+            // the 3 x 6 windows of the planes around the 4 pixels; window column j = image column c - 1 + j, pixel k sits at column k + 1
+            float wa[3][6], wb[3][6];
             window(sga, ly + 1, c, wa);
-            if (magnitude) window(sgb, ly + 1, c, wb);
+            window(sgb, ly + 1, c, wb);
+            float ca[6], eb[6], cc1[6];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int* row = scode + (ly + r) * LS + 4 + c;
-                wc[r][0] = row[-1]; wc[r][1] = row[0]; wc[r][2] = row[1]; wc[r][3] = row[2]; wc[r][4] = row[3]; wc[r][5] = row[4];
+            for (int j = 0; j < 6; ++j) {
+                ca[j] = (wa[0][j] + wa[1][j]) + wa[2][j];                                   // column sums of A
+                eb[j] = wb[0][j] - wb[2][j];                                                // row above - row below of B
+                cc1[j] = magnitude ? wa[1][j] : (wb[1][j] == 0.f ? wa[1][j] : 0.f);         // C on the centre row
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float dd = 0.f;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) {
-                        // source pixel p at window (r, k + cc); q - p = (dy, dx) = (1 - r, 1 - cc)
-                        const int dy = 1 - r, dx = 1 - cc;
-                        if (dy == 0 && dx == 0) continue;
-                        if (magnitude) dd += tap_weight(1, dy, dx) * wa[r][k + cc] + tap_weight(0, dy, dx) * wb[r][k + cc];
-                        else dd += tap_weight(wc[r][k + cc], dy, dx) * wa[r][k + cc];
-                    }
+                // source p at window (r, k + cc) reaches q = (1, k + 1) with t = q - p = (1 - r, 1 - cc)
+                const float d0 = magnitude ? wb[0][k + 1] : (wa[0][k + 1] == 0.f ? wb[0][k + 1] : 0.f);       // D above / below q
+                const float d2 = magnitude ? wb[2][k + 1] : (wa[2][k + 1] == 0.f ? wb[2][k + 1] : 0.f);
+                float dd = (ca[k] - ca[k + 2]) + ((eb[k] + eb[k + 1]) + eb[k + 2]) + (cc1[k] - cc1[k + 2]) + (d0 - d2);
                 if (from_inv) {
                     const float inv = inv4[ps][k];
                     const float d = rcpf(fmaxf(inv, 1e-6f));
@@ -548,7 +615,7 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
             for (int k = 0; k < 4; ++k) {
                 const float g = inv4[ps][k];
                 float p, omp;
-                if (is_sigmoid) { const float t = __expf(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
+                if (is_sigmoid) { const float t = fast_exp(-(g - a.thresh)); p = rcpf(1.f + t); omp = t * p; }
                 else { p = g; omp = 1.f - g; }
                 const float keep = (use_keep && m4[k] == 0.f) ? 0.f : 1.f;
                 const float dp = is_sigmoid ? p * omp : 1.f;
@@ -560,14 +627,14 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
             for (int k = 0; k < 4; ++k) {
                 const float d = d4[ps][k];
                 if (d > 0.f) {
-                    const float gt = 1.f / fmaxf(d, 1e-6f);
+                    const float gt = rcpf(fmaxf(d, 1e-6f));           // feeds a log: 1 ulp here is 6e-8 absolute there
                     const float pi = inv4[ps][k] + 1e-5f;
-                    const float dl = __logf(pi * 10.f) - __logf(gt * 10.f);
-                    out[k] += ksl * (dl - 0.85f * m1) / pi;
+                    const float dl = fast_log(pi * 10.f) - fast_log(gt * 10.f);
+                    out[k] += ksl * (dl - 0.85f * m1) * rcpf(pi);
                 }
             }
         }
-        store4(sc.dpred, img + gy, id.x0 + c, sc.W, vec, out);
+        store4(sc.dpred, img + gy, x0 + c, sc.W, vec, out);
     }
 }
 
@@ -632,6 +699,7 @@ bool fast_config(const EdgeMulti& a) {
 }
 
 int setup_scales(EdgeMulti& a, const mte_edge_scale_t* scales, int nscales, int B, bool backward) {
+    const int T = backward ? 1 : FWD_TILES_PER_WG;
     if (!scales || nscales < 1 || nscales > MAXS || B < 1) return -1;
     int blocks = 0;
     for (int s = 0; s < nscales; ++s) {
@@ -644,9 +712,10 @@ int setup_scales(EdgeMulti& a, const mte_edge_scale_t* scales, int nscales, int 
         o.first_block = blocks;
         o.vec = in.W % 4 == 0 && aligned16(in.pred) && aligned16(in.edge) && aligned16(in.normal) && aligned16(in.mask) &&
                 aligned16(in.gmap) && aligned16(in.dpred);
-        blocks += o.tiles_x * o.tiles_y * B;
+        o.groups = (o.tiles_x * o.tiles_y + T - 1) / T;
+        blocks += o.groups * B;
     }
-    a.nscales = nscales; a.B = B; a.nblocks = blocks;
+    a.nscales = nscales; a.B = B; a.nblocks = blocks; a.tiles_per_wg = T;
     return blocks;
 }
 long results_elems(int nscales, int B) { return ((long)nscales * B * NP + 1) & ~1L; }
@@ -656,12 +725,12 @@ long counter_elems(int nscales, int B) { return (((long)nscales * B + 1) * 4 + 1
 
 extern "C" {
 
-// doubles of workspace for a forward launch over these scales: [nscales][B][13] accumulators + the arrival ticket
+// doubles of workspace for a forward launch over these scales: [nscales][B][13] sums + the arrival tickets + one 16-double record per workgroup
 long mte_edge_loss_work_elems(const void* scales, int nscales, int B) {
     EdgeMulti a{};
     const int blocks = setup_scales(a, (const mte_edge_scale_t*)scales, nscales, B, false);
     if (blocks < 0) return -1;
-    return results_elems(nscales, B) + counter_elems(nscales, B);
+    return results_elems(nscales, B) + counter_elems(nscales, B) + (long)blocks * REC;
 }
 
 // Forward of `nscales` (<= 4) depth-edge losses in ONE launch, the silog loss of scale 0 fused in when gt_depth != NULL.
@@ -678,8 +747,8 @@ int mte_edge_loss_multi_fwd(const void* scales, int nscales, int B, int from_inv
     a.weight = weight; a.pos_to_neg = pos_to_neg; a.gt_depth = gt_depth; a.losses = losses; a.coef = coef;
     a.silog_loss = silog_loss; a.silog_aux = silog_aux;
     const long r = results_elems(nscales, B);
-    a.results = work; a.counter = (unsigned*)(work + r);
-    if (mte_memset_async(work, 0, sizeof(double) * (r + counter_elems(nscales, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;     // accumulators + tickets
+    a.results = work; a.counter = (unsigned*)(work + r); a.records = work + r + counter_elems(nscales, B);
+    if (mte_memset_async(work, 0, sizeof(double) * (r + counter_elems(nscales, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;     // sums + tickets (the records are overwritten)
     if (fast_config(a)) hipLaunchKernelGGL(edge_loss_fwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(edge_loss_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();
@@ -702,10 +771,11 @@ int mte_edge_loss_multi_bwd(const void* scales, int nscales, int B, int from_inv
 }
 
 // ---- single-scale entry points (GradLoss / GradLayer called directly): the same kernels with one scale
-// doubles the caller must provide as `sums`: [B][13] accumulators (6 class-balance / BCE sums, 4 mask statistics, 3 unused) + the ticket
+// doubles the caller must provide as `sums`: [B][13] sums (6 class-balance / BCE sums, 4 mask statistics, 3 unused) + the tickets + one 16-double record per workgroup
 long mte_edge_loss_sums_elems(int B, int H, int W) {
-    (void)H; (void)W;
-    return results_elems(1, B) + counter_elems(1, B);
+    if (B < 1 || H < 1 || W < 1) return -1;
+    const long tiles = (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    return results_elems(1, B) + counter_elems(1, B) + (long)B * ((tiles + FWD_TILES_PER_WG - 1) / FWD_TILES_PER_WG) * REC;
 }
 
 // Forward pass of one scale.  sums: mte_edge_loss_sums_elems(B, H, W) doubles (content on entry ignored).  gmap nullable.
@@ -719,7 +789,7 @@ int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal,
     if (blocks < 0) return MTE_ERR_ARG;
     a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.finalize = 0; a.thresh = thresh;
     const long r = results_elems(1, B);
-    a.results = sums; a.counter = (unsigned*)(sums + r);
+    a.results = sums; a.counter = (unsigned*)(sums + r); a.records = sums + r + counter_elems(1, B);
     if (mte_memset_async(sums, 0, sizeof(double) * (r + counter_elems(1, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     hipLaunchKernelGGL(edge_loss_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();

@@ -1019,9 +1019,9 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
     const long n = slab_chunks(a.HW, a.C, dtype, &sh);
     if (n > 0 && n <= GN_SLAB_MAX && !(a.y2 && a.dbias)) {
         a.cps_shift = sh;
-        // the slab kernels ADD this sample's part of dgamma / dbeta (the stream kernels overwrite them): clear them first
-        if (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-        if (mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+        // the slab kernels ADD this sample's part of dgamma / dbeta (the stream kernels overwrite them): clear them first (prezeroed callers did)
+        if (!g_mte_gn_prezeroed && (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess ||
+                                    mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess)) return MTE_ERR_LAUNCH;
         bool done;
         if (a.y2) done = launch_bwd_slab<T, true, false>(a, n, stream);
         else if (a.dbias) done = launch_bwd_slab<T, false, true>(a, n, stream);
@@ -1033,8 +1033,8 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
         const int cl = cluster_plan(a.B, a.HW, a.C, n, sh, a.y2 ? 3 : 2, &nch, &pl);
         if (cl) {
             a.cps_shift = sh;
-            if (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-            if (mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
+            if (!g_mte_gn_prezeroed && (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess ||
+                                        mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess)) return MTE_ERR_LAUNCH;
             bool done;
             if (a.y2) done = launch_bwd_cluster<T, true, false>(a, cl, nch, pl, stream);
             else if (a.dbias) done = launch_bwd_cluster<T, false, true>(a, cl, nch, pl, stream);

@@ -829,8 +829,9 @@ def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbia
     red = _zeros((B, C, 2), torch.float32, y1.device)
     d1 = new_act(B, C, H, W, y1.dtype, y1.device)
     d2 = new_act(B, C, H, W, y1.dtype, y1.device) if need_d2 else None
-    dgamma = dgamma if dgamma is not None else torch.empty((C,), dtype=torch.float32, device=y1.device)
-    dbeta = dbeta if dbeta is not None else torch.empty((C,), dtype=torch.float32, device=y1.device)
+    # zero at entry (MTE_OPT_GN_PREZEROED covers dgamma / dbeta too: the single-pass kernels ADD per-sample parts into them)
+    dgamma = dgamma if dgamma is not None else _zeros((C,), torch.float32, y1.device)
+    dbeta = dbeta if dbeta is not None else _zeros((C,), torch.float32, y1.device)
     if want_dbias and dbias is None:
         dbias = _zeros((C,), torch.float32, y1.device)
     pz, lz = _pl(dz)
@@ -885,8 +886,8 @@ class ConvGnEluFn(torch.autograd.Function):
     def backward(ctx, dz):
         x, w, y, stats, gamma, beta = ctx.saved_tensors
         b = ctx.bias
-        gg, sg = _grad_dst(gamma)
-        gb, sb = _grad_dst(beta)
+        gg, sg = _grad_dst(gamma, zero=True)
+        gb, sb = _grad_dst(beta, zero=True)
         gbias, sbias = _grad_dst(b, zero=True)
         gw, sw = _grad_dst(w)
         dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
@@ -944,8 +945,8 @@ class ResidualTailFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         a, s, stats, gamma, beta = ctx.saved_tensors
-        gg, sg = _grad_dst(gamma)
-        gb, sb = _grad_dst(beta)
+        gg, sg = _grad_dst(gamma, zero=True)
+        gb, sb = _grad_dst(beta, zero=True)
         if ctx.bias_s is not None and ctx.needs_input_grad[5]:
             gbs, sbs = _grad_dst(ctx.bias_s, zero=True)
             da, ds, dgamma, dbeta, dbs = _gn_backward(dz, a, s, ctx.scale, stats, gamma, beta, GN_EPS, True, want_dbias=True,

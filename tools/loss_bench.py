@@ -5,6 +5,18 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("EDGE_DEFS"):                                   # private diagnostic build with extra -D switches (ablations)
+    import glob
+    import subprocess
+    from mindtheedge_amd import _build
+    _build.build()
+    so, obj = "/tmp/libmte_edge_ab.so", "/tmp/edge_loss_ab.o"
+    subprocess.check_call([_build._hipcc()] + _build.FLAGS + ["-DMTE_DEV", "-I", _build.CSRC] + os.environ["EDGE_DEFS"].split() +
+                          ["-c", os.path.join(_build.CSRC, "edge_loss.hip"), "-o", obj])
+    others = [o for o in glob.glob(os.path.join(_build.CSRC, "dev", "*.o")) if not o.endswith("edge_loss.o")]
+    subprocess.check_call([_build._hipcc(), "--offload-arch=gfx950", "-shared", "-o", so, obj] + others)
+    os.environ["MTE_LIB_PATH"] = so
+    print("private build:", os.environ["EDGE_DEFS"])
 import torch  # noqa: E402
 from mindtheedge_amd import kernels as K  # noqa: E402
 from mindtheedge_amd.utils.synthetic import synthetic_batch  # noqa: E402
