@@ -52,6 +52,9 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
  * mte_gn_stats and mte_gn_elu_bwd -- and, since round 4, that call's dgamma / dbeta -- are already zero (the caller clears one arena
  * per step with a single fill; a zeroed flat gradient buffer qualifies) and the library skips its own per-call fills. */
 #define MTE_OPT_GN_PREZEROED 0
+/* MTE_OPT_LOSS_PREZEROED (1): when 1, `work` of mte_edge_loss_multi_fwd and `sums` of mte_edge_loss_fwd are zero on entry (first
+ * mte_edge_loss_work_elems / _sums_elems doubles; same arena) and the launch's own fill is skipped. */
+#define MTE_OPT_LOSS_PREZEROED 1
 int mte_set_option(int option, int value);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
  * pixels is split over at most stage_parts workgroup groups; each one stores its PARTIAL gradient in its own part (plain stores;
@@ -193,7 +196,7 @@ int mte_add_channels(const void* a, long lda, const void* b, long ldb, void* out
  * last workgroup to arrive adds the per-workgroup partial sums in a fixed order and computes alpha, the loss scalars and the
  * backward coefficients on the device (no reduce / finalize launches, no host sync, deterministic sums).
  *   scales : HOST array of nscales (<= 4) records; every map is fp32 [B,H,W]; normal / mask / gmap nullable; dpred = backward output
- *   work   : mte_edge_loss_work_elems() doubles (content on entry ignored)
+ *   work   : mte_edge_loss_work_elems() doubles (content on entry ignored; zero on entry under MTE_OPT_LOSS_PREZEROED)
  *   losses [nscales] <- weight * balanced BCE per scale;  coef [nscales][2B+1] <- backward coefficients
  *   gt_depth (nullable; metric depth, 0 = invalid, at the size of scale 0): fused silog -> silog_loss[1], silog_aux[2]
  *   backward: dpred_s <- gout[s] * d loss_s / d pred_s  (+ silog_gout[0] * d silog / d pred_0); gout / silog_gout: device, nullable = 1 */

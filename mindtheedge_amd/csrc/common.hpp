@@ -94,6 +94,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // that are already zero (carved from one arena it clears with a single memset), so the library skips its ~140 tiny
 // per-layer hipMemsetAsync launches per training step.  Defined in norm_act.hip.
 extern int g_mte_gn_prezeroed;
+// mte_set_option(MTE_OPT_LOSS_PREZEROED, 1): the workspaces handed to mte_edge_loss_multi_fwd / mte_edge_loss_fwd are zero on entry (same arena):
+// the launch's own fill kernel is skipped.  Defined in edge_loss.hip.
+extern int g_mte_loss_prezeroed;
 
 // GroupNorm statistics buffer of a batch of B samples, in doubles (mte_gn_stats_elems(B)):
 //   [0, 32 B)                       final (sum, sum of squares) per (sample, group): what every consumer reads

@@ -38,3 +38,25 @@ MTE_EDGE_FN int direction_code(float n) {
     const unsigned tbl = neg ? 0x9Cu : 0xD8u;                       // k = 0..4 -> {h, lr, v, rl, h} below zero, {h, rl, v, lr, h} above
     return (int)((tbl >> (2 * k)) & 3u);
 }
+
+// The same bins as three range tests + the sign (what the fast loss kernels consume: they select among the four Sobel responses and build the
+// backward planes straight from these masks, never forming the code): k1 = |n| in the first bin next to zero, v = the middle bin, k3 = the
+// bin next to +-pi; on the positive side k1 is rl and k3 is lr, below zero the other way round.
+struct DirMasks { bool v, k1, k3, neg; };
+MTE_EDGE_FN DirMasks direction_masks(float n) {
+    const int p1 = 0x3EC90FDB, p3 = 0x3F96CBE4, p5 = 0x3FFB53D1, p7 = 0x402FEDDF;
+    unsigned u;
+#if defined(__HIPCC__)
+    u = __builtin_bit_cast(unsigned, n);
+#else
+    std::memcpy(&u, &n, 4);
+#endif
+    const int mi = (int)(u & 0x7fffffffu) - (int)(u >> 31);
+    DirMasks m;
+    m.neg = (int)u < 0;
+    m.k1 = (unsigned)(mi - p1) < (unsigned)(p3 - p1);
+    m.v = (unsigned)(mi - p3) < (unsigned)(p5 - p3);
+    m.k3 = (unsigned)(mi - p5) < (unsigned)(p7 - p5);
+    return m;
+}
+MTE_EDGE_FN int code_from_masks(DirMasks m) { return m.v ? 1 : (m.k1 ? (m.neg ? 3 : 2) : (m.k3 ? (m.neg ? 2 : 3) : 0)); }

@@ -25,6 +25,8 @@
 #include "common.hpp"
 #include "edge_direction.hpp"
 
+int g_mte_loss_prezeroed = 0;
+
 namespace {
 
 constexpr int TW = 64, TH = 32;         // output tile (256 threads x 2 passes x 4 pixels)
@@ -32,7 +34,10 @@ constexpr int LS = 72;                  // LDS row stride in floats: image colum
 constexpr int MAXS = 4;                 // scales per launch
 constexpr int NP = 13;                  // partial sums per workgroup: 6 edge sums, 4 mask statistics, 3 silog sums
 constexpr int REC = 16;                 // doubles per workgroup record (one 128-byte line)
-constexpr int FWD_TILES_PER_WG = 3;     // forward: consecutive tiles per workgroup (856 workgroups at T8: one round of the 1024 slots)
+#ifndef MTE_EDGE_FWD_TILES
+#define MTE_EDGE_FWD_TILES 3
+#endif
+constexpr int FWD_TILES_PER_WG = MTE_EDGE_FWD_TILES;     // forward: consecutive tiles per workgroup (3: 856 workgroups at T8, one round of the 1024 slots)
 
 struct EdgeScale {
     const float* pred;                  // inv-depth (from_inv), depth, or probability map
@@ -193,7 +198,70 @@ __device__ __forceinline__ BlockId decode_block(const EdgeMulti& a) {
 }
 
 // ---------------- forward -----------------------------------------------------------------------------------------
+
 __device__ void finalize_losses(const EdgeMulti& a, double* stage, int stage_elems);
+// Sums of one workgroup -> record -> image sums -> losses (shared by the generic and the fast forward kernel).  sd: the depth tile's LDS
+// storage ((TH + 2) * LS floats, dead by now), sred / s_last: LDS scratch of the kernel.
+__device__ __forceinline__ void forward_tail(const EdgeMulti& a, const BlockId& id, float acc[NP], bool has_mask, bool silog,
+                                             float* sd, float (*sred)[NP], int* s_last_p) {
+    const EdgeScale& sc = a.s[id.s];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    volatile int& s_last = *s_last_p;
+    // ---- sums.  fp32 per thread and per wave (xor butterfly in DPP / lane-swap instructions), fp64 from there on.  Round 4: NO atomic
+    //      adds.  The workgroup leaves ONE record (its own 128-byte line); the last workgroup of a (scale, sample) to arrive adds that
+    //      image's <= 240 records in a FIXED order and writes the image's sums; the last of those finishes the losses.  Every sum of the
+    //      launch has a fixed order, so losses and coefficients are bit-reproducible.  (Before: one fp64 atomicAdd per value into the
+    //      image's accumulators -- 7 x 240 adds on ONE cache line per full-resolution image, serialised at its L2 channel: 27 us of a
+    //      54 us launch.  A first fixed-order attempt in round 1 had ONE workgroup sweep all 2,568 records: ~120 us.)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i >= 4 && i < 10 && !has_mask) continue;
+        if (i >= 10 && !silog) continue;
+        const float s = wave_sum_dpp(acc[i]);
+        if (lane == 0) sred[wave][i] = s;
+    }
+    __syncthreads();
+    const bool live = tid < NP && !((tid >= 4 && tid < 10 && !has_mask) || (tid >= 10 && !silog));
+    if (live) {
+        // RETURNING exchange: the value comes back only after the store has been performed at the memory side (a plain store, or a
+        // no-return atomic, is acknowledged earlier: the ticket below was seen to overtake it about once per few thousand workgroups)
+        const double v = (double)sred[0][tid] + (double)sred[1][tid] + (double)sred[2][tid] + (double)sred[3][tid];
+        const unsigned long long before = atomicExch((unsigned long long*)(a.records + (long)blockIdx.x * REC) + tid, (unsigned long long)__double_as_longlong(v));
+        asm volatile("" ::"v"(before));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int per_image = sc.groups;                               // records (= workgroups) of this image
+    if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter + 1 + id.s * a.B + id.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(per_image - 1);
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last workgroup of this (scale, sample): value v = tid % 16 of records k, k + 16, ... (k = tid / 16), then the 16 part sums in order
+    {
+        double* s_fin = (double*)sd;                               // the tile is dead (barriers above)
+        const int v = tid & 15, k = tid >> 4;
+        const double* rec = a.records + ((long)sc.first_block + (long)id.b * per_image) * REC + v;
+        double part = 0.0;
+        if (v < NP && !((v >= 4 && v < 10 && !has_mask) || (v >= 10 && !silog))) {
+#pragma unroll 4
+            for (int j = k; j < per_image; j += 16) part += __hip_atomic_load(rec + (long)j * REC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_fin[k * 16 + v] = part;
+        __syncthreads();
+        if (live) {
+            double tot = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) tot += s_fin[kk * 16 + tid];
+            const unsigned long long before = atomicExch((unsigned long long*)(a.results + ((long)id.s * a.B + id.b) * NP) + tid, (unsigned long long)__double_as_longlong(tot));
+            asm volatile("" ::"v"(before));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.nscales * a.B - 1);
+        __syncthreads();
+        if (!s_last) return;
+    }
+    finalize_losses(a, (double*)sd, (TH + 2) * LS / 2);
+}
 
 // FAST = the training configuration on every scale (16-byte accesses legal, inverse depth in, Sobel + normals + sigmoid, no mask):
 // the flags are compile-time there.  The generic instantiation carries every runtime flag -- its body is ~10k instructions
@@ -303,120 +371,94 @@ __global__ __launch_bounds__(256, FAST ? 4 : 2) void edge_loss_fwd_kernel(EdgeMu
 #if defined(MTE_EDGE_ABLATE) && (MTE_EDGE_ABLATE & 1)
     { float tt = 0.f; for (int i = 0; i < NP; ++i) tt += acc[i]; if (tt == 123.456f) a.losses[0] = tt; return; }      // diagnostic: no reductions, atomics, tickets
 #endif
-    // ---- sums.  fp32 per thread and per wave (xor butterfly in DPP / lane-swap instructions), fp64 from there on.  Round 4: NO atomic
-    //      adds.  The workgroup leaves ONE record (its own 128-byte line); the last workgroup of a (scale, sample) to arrive adds that
-    //      image's <= 240 records in a FIXED order and writes the image's sums; the last of those finishes the losses.  Every sum of the
-    //      launch has a fixed order, so losses and coefficients are bit-reproducible.  (Before: one fp64 atomicAdd per value into the
-    //      image's accumulators -- 7 x 240 adds on ONE cache line per full-resolution image, serialised at its L2 channel: 27 us of a
-    //      54 us launch.  A first fixed-order attempt in round 1 had ONE workgroup sweep all 2,568 records: ~120 us.)
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        if (i >= 4 && i < 10 && !has_mask) continue;
-        if (i >= 10 && !silog) continue;
-        const float s = wave_sum_dpp(acc[i]);
-        if (lane == 0) sred[wave][i] = s;
-    }
-    __syncthreads();
-    const bool live = tid < NP && !((tid >= 4 && tid < 10 && !has_mask) || (tid >= 10 && !silog));
-    if (live) {
-        // RETURNING exchange: the value comes back only after the store has been performed at the memory side (a plain store, or a
-        // no-return atomic, is acknowledged earlier: the ticket below was seen to overtake it about once per few thousand workgroups)
-        const double v = (double)sred[0][tid] + (double)sred[1][tid] + (double)sred[2][tid] + (double)sred[3][tid];
-        const unsigned long long before = atomicExch((unsigned long long*)(a.records + (long)blockIdx.x * REC) + tid, (unsigned long long)__double_as_longlong(v));
-        asm volatile("" ::"v"(before));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int per_image = sc.groups;                               // records (= workgroups) of this image
-    if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter + 1 + id.s * a.B + id.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(per_image - 1);
-    __syncthreads();
-    if (!s_last) return;
-    // ---- last workgroup of this (scale, sample): value v = tid % 16 of records k, k + 16, ... (k = tid / 16), then the 16 part sums in order
-    {
-        double* s_fin = (double*)sd;                               // the tile is dead (barriers above)
-        const int v = tid & 15, k = tid >> 4;
-        const double* rec = a.records + ((long)sc.first_block + (long)id.b * per_image) * REC + v;
-        double part = 0.0;
-        if (v < NP && !((v >= 4 && v < 10 && !has_mask) || (v >= 10 && !silog))) {
-#pragma unroll 4
-            for (int j = k; j < per_image; j += 16) part += __hip_atomic_load(rec + (long)j * REC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_fin[k * 16 + v] = part;
-        __syncthreads();
-        if (live) {
-            double tot = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) tot += s_fin[kk * 16 + tid];
-            const unsigned long long before = atomicExch((unsigned long long*)(a.results + ((long)id.s * a.B + id.b) * NP) + tid, (unsigned long long)__double_as_longlong(tot));
-            asm volatile("" ::"v"(before));
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.nscales * a.B - 1);
-        __syncthreads();
-        if (!s_last) return;
-    }
-    finalize_losses(a, (double*)sd, (TH + 2) * LS / 2);
+    forward_tail(a, id, acc, has_mask, silog, sd, sred, &s_last);
 }
 
 // Runs in the last workgroup: every accumulator is complete.  The scalar arithmetic of comp_cross_entropy (grad_loss.py:161-219) and
 // SilogLoss (supervised_loss.py:57-69) is a few hundred dependent reads of the accumulators; straight from memory (agent-scope loads,
 // one L2 round trip each, one thread) that serial tail was ~45 us of a 73 us launch (round 4: forward 73 -> see profiles/README.md).  So the
-// whole workgroup first copies the accumulators into LDS (`stage`: the depth tile's storage, free by now; one round trip), and one
-// thread PER SCALE (+ one for the silog loss, in another wave) does the arithmetic from there.
+// whole workgroup first copies the sums into LDS (`stage`: the depth tile's storage, free by now; one round trip); one thread per
+// (scale, sample) does the divisions, one per scale the ordered sum (+ one for the silog loss, in another wave).
 __device__ __forceinline__ double acc_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-struct AccView {
-    const double* g; const double* l;                            // l != nullptr: the LDS copy
-    __device__ __forceinline__ double operator()(long i) const { return l ? l[i] : acc_load(g + i); }
-};
+// class-balance arithmetic of one scale from its image sums R[b * NP + i] (comp_cross_entropy, grad_loss.py:161-219)
+struct ScaleStats { bool binary; double nvalid, wneg_total; };
+template <typename V> __device__ __forceinline__ ScaleStats scale_stats(const V& R0, long R, int B, bool has_mask, double numel) {
+    double mi[4] = {0.0, 0.0, 0.0, 0.0};
+    if (has_mask)
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < 4; ++k) mi[k] += R0(R + b * NP + 6 + k);
+    ScaleStats st;
+    st.binary = has_mask && mi[2] == 0.0 && mi[0] > 0.0 && mi[1] > 0.0;          // unique(mask) == {0, 1}
+    st.nvalid = st.binary ? mi[3] : numel;
+    st.wneg_total = 0.0;
+    for (int b = 0; b < B; ++b) st.wneg_total += (double)(float)R0(R + b * NP + 1);
+    return st;
+}
+// sample b of a scale: backward coefficients -> coef[2b], coef[2b + 1]; returns its term of the loss sum
+template <typename V> __device__ __forceinline__ double sample_term(const EdgeMulti& a, const V& R0, long sums, const ScaleStats& st, float* coef, int b) {
+    const float wp = (float)R0(sums), wn = (float)R0(sums + 1);
+    const float alpha = st.wneg_total == 0.0 ? 1.f : wn / (wp + wn);
+    const double P = st.binary ? R0(sums + 4) : R0(sums + 2), N = st.binary ? R0(sums + 5) : R0(sums + 3);
+    coef[2 * b] = (float)((double)a.weight * a.pos_to_neg * alpha / st.nvalid);
+    coef[2 * b + 1] = (float)((double)a.weight * (1.f - alpha) / st.nvalid);
+    return (double)a.pos_to_neg * alpha * P + (double)(1.f - alpha) * N;
+}
+template <typename V> __device__ __forceinline__ void silog_finish(const EdgeMulti& a, const V& R0) {   // loss = 10 sqrt(E[d^2] - 0.85 E[d]^2);  aux = (mean, 10/sqrt(S)/n)
+    double ss[3] = {0.0, 0.0, 0.0};
+    for (int b = 0; b < a.B; ++b)
+        for (int k = 0; k < 3; ++k) ss[k] += R0((long)b * NP + 10 + k);
+    const double n1 = ss[2];
+    const double m1 = ss[0] / n1, m2 = ss[1] / n1;
+    const double S = m2 - 0.85 * m1 * m1;
+    if (a.silog_loss) *a.silog_loss = (float)(sqrt(S) * 10.0);
+    if (a.silog_aux) { a.silog_aux[0] = (float)m1; a.silog_aux[1] = (float)(10.0 / sqrt(S) / n1); }
+}
+struct LdsView { const double* l; __device__ __forceinline__ double operator()(long i) const { return l[i]; } };
+struct MemView { const double* g; __device__ __forceinline__ double operator()(long i) const { return acc_load(g + i); } };
+
 __device__ void finalize_losses(const EdgeMulti& a, double* stage, int stage_elems) {
     const int tid = threadIdx.x;
     if (!a.finalize) return;
-    const int n = a.nscales * a.B * NP;
-    const bool staged = n <= stage_elems;
-    if (staged) {
+    const int n = a.nscales * a.B * NP, images = a.nscales * a.B;
+    if (n + images <= stage_elems) {
+        // the usual case.  (1) sums -> LDS; (2) one thread per (scale, sample): alpha, the two coefficients (fp64 divisions -- done by one
+        // thread per SCALE these were ~3 us of serial tail) and the sample's term of the loss; (3) one thread per scale adds the terms in order
         __syncthreads();                                          // every wave is done with the tile
         for (int i = tid; i < n; i += 256) stage[i] = acc_load(a.results + i);
         __syncthreads();
-    }
-    const AccView R0{a.results, staged ? stage : nullptr};
-    const int lanes = staged ? a.nscales : 1;                     // one thread per scale from LDS; one thread for all of them from memory
-    if (tid < lanes) {
-        for (int s = staged ? tid : 0; s < (staged ? tid + 1 : a.nscales); ++s) {
+        const LdsView R0{stage};
+        double* term = stage + n;
+        for (int i = tid; i < images; i += 256) {
+            const int s = i / a.B, b = i - s * a.B;
             const long R = (long)s * a.B * NP;
-            double mi[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int b = 0; b < a.B; ++b)
-                for (int k = 0; k < 4; ++k) mi[k] += R0(R + b * NP + 6 + k);
-            const bool has_mask = a.s[s].mask != nullptr;
-            const bool binary = has_mask && mi[2] == 0.0 && mi[0] > 0.0 && mi[1] > 0.0;      // unique(mask) == {0, 1}
-            const double nvalid = binary ? mi[3] : (double)a.B * a.s[s].H * a.s[s].W;
-            double wneg_total = 0.0;
-            for (int b = 0; b < a.B; ++b) wneg_total += (double)(float)R0(R + b * NP + 1);
-            double total = 0.0;
+            const ScaleStats st = scale_stats(R0, R, a.B, a.s[s].mask != nullptr, (double)a.B * a.s[s].H * a.s[s].W);
             float* coef = a.coef + (long)s * (2 * a.B + 1);
-            for (int b = 0; b < a.B; ++b) {
-                const long sums = R + b * NP;
-                const float wp = (float)R0(sums), wn = (float)R0(sums + 1);
-                const float alpha = wneg_total == 0.0 ? 1.f : wn / (wp + wn);
-                const double P = binary ? R0(sums + 4) : R0(sums + 2), N = binary ? R0(sums + 5) : R0(sums + 3);
-                total += (double)a.pos_to_neg * alpha * P + (double)(1.f - alpha) * N;
-                coef[2 * b] = (float)((double)a.weight * a.pos_to_neg * alpha / nvalid);
-                coef[2 * b + 1] = (float)((double)a.weight * (1.f - alpha) / nvalid);
-            }
-            coef[2 * a.B] = binary ? 1.f : 0.f;
-            a.losses[s] = (float)((double)a.weight * total / nvalid);
+            term[i] = sample_term(a, R0, R + b * NP, st, coef, b);
+            if (b == 0) coef[2 * a.B] = st.binary ? 1.f : 0.f;
         }
+        if (a.gt_depth && tid == 255) silog_finish(a, R0);         // another wave than the first threads
+        __syncthreads();
+        if (tid < a.nscales) {
+            const int s = tid;
+            const ScaleStats st = scale_stats(R0, (long)s * a.B * NP, a.B, a.s[s].mask != nullptr, (double)a.B * a.s[s].H * a.s[s].W);
+            double total = 0.0;
+            for (int b = 0; b < a.B; ++b) total += term[s * a.B + b];
+            a.losses[s] = (float)((double)a.weight * total / st.nvalid);
+        }
+        return;
     }
-    if (a.gt_depth && tid == (staged ? 64 : 0)) {                 // loss = 10 sqrt(E[d^2] - 0.85 E[d]^2);  aux = (mean, 10/sqrt(S)/n)
-        double ss[3] = {0.0, 0.0, 0.0};
-        for (int b = 0; b < a.B; ++b)
-            for (int k = 0; k < 3; ++k) ss[k] += R0((long)b * NP + 10 + k);
-        const double n1 = ss[2];
-        const double m1 = ss[0] / n1, m2 = ss[1] / n1;
-        const double S = m2 - 0.85 * m1 * m1;
-        if (a.silog_loss) *a.silog_loss = (float)(sqrt(S) * 10.0);
-        if (a.silog_aux) { a.silog_aux[0] = (float)m1; a.silog_aux[1] = (float)(10.0 / sqrt(S) / n1); }
+    if (tid != 0) return;                                         // very large batches: one thread, straight from memory
+    const MemView R0{a.results};
+    for (int s = 0; s < a.nscales; ++s) {
+        const long R = (long)s * a.B * NP;
+        const ScaleStats st = scale_stats(R0, R, a.B, a.s[s].mask != nullptr, (double)a.B * a.s[s].H * a.s[s].W);
+        float* coef = a.coef + (long)s * (2 * a.B + 1);
+        double total = 0.0;
+        for (int b = 0; b < a.B; ++b) total += sample_term(a, R0, R + b * NP, st, coef, b);
+        coef[2 * a.B] = st.binary ? 1.f : 0.f;
+        a.losses[s] = (float)((double)a.weight * total / st.nvalid);
     }
+    if (a.gt_depth) silog_finish(a, R0);
 }
 
 // single-scale finalize (GradLoss called on its own): accumulators [B][NP] -> loss (accumulated into *loss_acc with factor
@@ -638,6 +680,268 @@ __global__ __launch_bounds__(256) void edge_loss_bwd_kernel(EdgeMulti a) {
     }
 }
 
+// ======================= the training configuration: branch-free kernels ============================================================
+// Every scale: 16-byte accesses legal (W % 4 == 0), inverse depth in, Sobel + normals + sigmoid, no mask, no edge-map output (`fast_config`).
+// Round 4.  The generic kernels above spend a third of their instructions on control flow: per-pixel bounds tests compiled to exec-mask
+// branches with their phi copies, divergent loop exits between 4-pixel and 1-pixel items, a load guard per access.  Here
+//   * every global address is CLAMPED into the image and the loaded value selected to zero afterwards -- no guard around a load;
+//   * a thread stages the depth of ITS OWN 8 pixels (the same load feeds the silog term and the chain rule), the halo rows / columns are
+//     single extra loads of the first threads: no index arithmetic by division, no scalar / vector load variants;
+//   * validity is one factor per 4-pixel group folded into the sums (1 - e becomes valid - e), the silog mask is a select;
+//   * the direction bins are three range tests (edge_direction.hpp) that select the Sobel response and the backward planes directly;
+//   * logs stay in base 2 until the sums (the ln 2 is folded into the label factors).
+// Per 8 pixels of a thread: ~1,000 instructions forward (generic: 2,450), ~1,500 backward (3,100).
+struct OwnGroup { bool ok; long off; };                        // a thread's 4 pixels of one row: inside the image?  offset of the (clamped) group
+__device__ __forceinline__ OwnGroup own_group(const EdgeScale& sc, int b, int gy, int gx) {
+    OwnGroup g;
+    g.ok = (unsigned)gy < (unsigned)sc.H && (unsigned)gx < (unsigned)sc.W;
+    const int cy = min(max(gy, 0), sc.H - 1), cx = min(max(gx, 0), sc.W - 4);
+    g.off = ((long)b * sc.H + cy) * sc.W + cx;
+    return g;
+}
+__device__ __forceinline__ f32x4_t sel4(bool ok, const f32x4_t& v) { return f32x4_t{ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f}; }
+__device__ __forceinline__ f32x4_t depth4(bool ok, const f32x4_t& inv) {
+    return f32x4_t{ok ? rcp_newton(fmaxf(inv[0], 1e-6f)) : 0.f, ok ? rcp_newton(fmaxf(inv[1], 1e-6f)) : 0.f,
+                   ok ? rcp_newton(fmaxf(inv[2], 1e-6f)) : 0.f, ok ? rcp_newton(fmaxf(inv[3], 1e-6f)) : 0.f};
+}
+// signed Sobel response of the direction the normal selects
+__device__ __forceinline__ float directed_response(const float w[3][6], int k, const DirMasks& m) {
+    float sh, sv, srl, slr;
+    sobel4(w, k, sh, sv, srl, slr);
+    float s = m.v ? sv : sh;
+    s = m.k1 ? (m.neg ? slr : srl) : s;
+    s = m.k3 ? (m.neg ? srl : slr) : s;
+    return s;
+}
+constexpr float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
+
+__global__ __launch_bounds__(256, 4) void edge_fwd_fast_kernel(EdgeMulti a) {
+    __shared__ __attribute__((aligned(16))) float sd[(TH + 2) * LS];
+    __shared__ float sred[4][NP];
+    __shared__ int s_last;
+    const BlockId id = decode_block(a);
+    const EdgeScale& sc = a.s[id.s];
+    const int tid = threadIdx.x;
+    const int c = (tid & 15) * 4, r0 = tid >> 4;                   // this thread's 4 pixels: columns c..c+3 of rows r0 and r0 + 16
+    const bool silog = a.gt_depth != nullptr && id.s == 0;
+    const float tk = a.thresh * LOG2E;
+    float acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+    for (int t = id.t0; t < id.t1; ++t) {
+        const int x0 = (t % sc.tiles_x) * TW, y0 = (t / sc.tiles_x) * TH;
+        if (t != id.t0) __syncthreads();                          // the previous tile's window reads are done
+        // ---- loads: own pixels (inverse depth, label, normal, ground truth), then the halo of the depth tile
+        OwnGroup og[2];
+        f32x4_t inv4[2], e4[2], n4[2], d4[2];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            og[ps] = own_group(sc, id.b, y0 + r0 + 16 * ps, x0 + c);
+            inv4[ps] = *(const f32x4_t*)(sc.pred + og[ps].off);
+            e4[ps] = *(const f32x4_t*)(sc.edge + og[ps].off);
+            n4[ps] = *(const f32x4_t*)(sc.normal + og[ps].off);
+            if (silog) d4[ps] = *(const f32x4_t*)(a.gt_depth + og[ps].off);
+        }
+        f32x4_t hrow = {0.f, 0.f, 0.f, 0.f}; bool hrow_ok = false;
+        float hcol = 0.f; bool hcol_ok = false;
+        if (tid < 32) {                                            // halo rows -1 and TH: 2 x 16 groups
+            const OwnGroup g = own_group(sc, id.b, y0 + (tid >> 4 ? TH : -1), x0 + c);
+            hrow = *(const f32x4_t*)(sc.pred + g.off); hrow_ok = g.ok;
+        } else if (tid >= 64 && tid < 64 + 2 * (TH + 2)) {         // halo columns -1 and TW of rows -1 .. TH
+            const int i = tid - 64, gy = y0 + (i >> 1) - 1, gx = x0 + (i & 1 ? TW : -1);
+            hcol_ok = (unsigned)gy < (unsigned)sc.H && (unsigned)gx < (unsigned)sc.W;
+            hcol = sc.pred[((long)id.b * sc.H + min(max(gy, 0), sc.H - 1)) * sc.W + min(max(gx, 0), sc.W - 1)];
+        }
+        // ---- depth tile
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) *(f32x4_t*)(sd + (r0 + 16 * ps + 1) * LS + 4 + c) = depth4(og[ps].ok, inv4[ps]);
+        if (tid < 32) *(f32x4_t*)(sd + (tid >> 4 ? TH + 1 : 0) * LS + 4 + c) = depth4(hrow_ok, hrow);
+        else if (tid >= 64 && tid < 64 + 2 * (TH + 2)) {
+            const int i = tid - 64;
+            sd[(i >> 1) * LS + (i & 1 ? 4 + TW : 3)] = hcol_ok ? rcp_newton(fmaxf(hcol, 1e-6f)) : 0.f;
+        }
+        __syncthreads();
+        // ---- the 8 pixels
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            float w[3][6];
+            window(sd, r0 + 16 * ps + 1, c, w);
+            const float vm = og[ps].ok ? 1.f : 0.f;
+            const f32x4_t e = sel4(og[ps].ok, e4[ps]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g = fabsf(directed_response(w, k, direction_masks(n4[ps][k])));
+                // p = 1 / (1 + t), 1 - p = t p with t = exp(-(g - thresh)) (see the generic kernel)
+                const float tt = __builtin_amdgcn_exp2f(__builtin_fmaf(g, -LOG2E, tk));
+                const float p = rcpf(1.f + tt), omp = tt * p;
+                const float ne = e[k] * -LN2, nf = (e[k] - vm) * LN2;            // -e ln 2, -(1 - e) ln 2 (0 outside the image)
+                acc[0] += e[k]; acc[1] += vm - e[k];
+                acc[2] = __builtin_fmaf(ne, __builtin_amdgcn_logf(p + 0.001f), acc[2]);
+                acc[3] = __builtin_fmaf(nf, __builtin_amdgcn_logf(omp + 0.001f), acc[3]);
+            }
+            if (silog) {
+                const f32x4_t d = sel4(og[ps].ok, d4[ps]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float gt = rcpf(fmaxf(d[k], 1e-6f));
+                    const float dl = (__builtin_amdgcn_logf((inv4[ps][k] + 1e-5f) * 10.f) - __builtin_amdgcn_logf(gt * 10.f)) * LN2;
+                    const float m = d[k] > 0.f ? 1.f : 0.f, dlm = d[k] > 0.f ? dl : 0.f;
+                    acc[10] += dlm; acc[11] = __builtin_fmaf(dlm, dlm, acc[11]); acc[12] += m;     // dl itself may be NaN where d = 0
+                }
+            }
+        }
+    }
+#if defined(MTE_EDGE_ABLATE) && (MTE_EDGE_ABLATE & 1)
+    { float tt = 0.f; for (int i = 0; i < NP; ++i) tt += acc[i]; if (tt == 123.456f) a.losses[0] = tt; return; }      // diagnostic: no sums / records / tickets
+#endif
+    forward_tail(a, id, acc, false, silog, sd, sred, &s_last);
+}
+
+// one G evaluation: planes A and B of pixel k of a window (see "Transposed Sobel" above); cp / cn = cpos e, cneg (1 - e) (0 outside the image)
+__device__ __forceinline__ void g_planes(const float w[3][6], int k, float n, float cp, float cn, float tk, float& A, float& B) {
+    const DirMasks m = direction_masks(n);
+    const float s = directed_response(w, k, m);
+    const float tt = __builtin_amdgcn_exp2f(__builtin_fmaf(fabsf(s), -LOG2E, tk));
+    const float p = rcpf(1.f + tt), omp = tt * p;
+    const float dg = (p * omp) * (cn * rcpf(omp + 0.001f) - cp * rcpf(p + 0.001f));
+    const float G = s > 0.f ? dg : (s < 0.f ? -dg : 0.f);           // d |s| / d s
+    const float Gn = m.neg ? G : -G;
+    A = m.v ? 0.f : G;
+    B = m.v ? G : 0.f;
+    B = m.k1 ? Gn : B;                                              // rl above zero (-1), lr below (+1)
+    B = m.k3 ? -Gn : B;
+}
+
+__global__ __launch_bounds__(256, 4) void edge_bwd_fast_kernel(EdgeMulti a) {
+    // depth on the tile + 2-pixel halo; the planes A, B of G = d loss / d s(p) on the tile + 1-pixel halo
+    __shared__ __attribute__((aligned(16))) float sd[(TH + 4) * LS];
+    __shared__ __attribute__((aligned(16))) float sga[(TH + 2) * LS], sgb[(TH + 2) * LS];
+    const BlockId id = decode_block(a);                            // one tile per workgroup
+    const EdgeScale& sc = a.s[id.s];
+    const int x0 = (id.t0 % sc.tiles_x) * TW, y0 = (id.t0 / sc.tiles_x) * TH;
+    const int tid = threadIdx.x;
+    const int c = (tid & 15) * 4, r0 = tid >> 4;
+    const float go = a.gout ? a.gout[id.s] : 1.f;
+    const float* coef = a.coef + (long)id.s * (2 * a.B + 1);
+    const float cpos = coef[2 * id.b] * go, cneg = coef[2 * id.b + 1] * go;
+    const bool silog = a.gt_depth != nullptr && id.s == 0;
+    const float tk = a.thresh * LOG2E;
+    const long img = (long)id.b * sc.H;
+    // ---- loads.  Own pixels: inverse depth, label, normal (+ ground truth); depth halo: rows -2, -1, TH, TH + 1 (threads 0..63) and columns
+    //      -2, -1, TW, TW + 1 of rows -2 .. TH + 1 (threads 64..207); G halo (label + normal of ONE pixel): rows -1 and TH (threads 0..127), columns
+    //      -1 and TW of rows -1 .. TH (threads 128..195)
+    OwnGroup og[2];
+    f32x4_t inv4[2], e4[2], n4[2], d4[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        og[ps] = own_group(sc, id.b, y0 + r0 + 16 * ps, x0 + c);
+        inv4[ps] = *(const f32x4_t*)(sc.pred + og[ps].off);
+        e4[ps] = *(const f32x4_t*)(sc.edge + og[ps].off);
+        n4[ps] = *(const f32x4_t*)(sc.normal + og[ps].off);
+        if (silog) d4[ps] = *(const f32x4_t*)(a.gt_depth + og[ps].off);
+    }
+    f32x4_t hrow = {0.f, 0.f, 0.f, 0.f}; bool hrow_ok = false;
+    float hcol = 0.f; bool hcol_ok = false;
+    int hrow_ly = 0, hcol_idx = 0;
+    if (tid < 64) {
+        const int hr = tid >> 4;                                   // 0, 1: rows -2, -1;  2, 3: rows TH, TH + 1
+        hrow_ly = hr < 2 ? hr : TH + hr;                           // LDS row (tile row + 2)
+        const OwnGroup g = own_group(sc, id.b, y0 + hrow_ly - 2, x0 + c);
+        hrow = *(const f32x4_t*)(sc.pred + g.off); hrow_ok = g.ok;
+    } else if (tid < 64 + 4 * (TH + 4)) {
+        const int i = tid - 64, q = i & 3, j = q < 2 ? q - 2 : TW - 2 + q;       // columns -2, -1, TW, TW + 1
+        const int gy = y0 + (i >> 2) - 2, gx = x0 + j;
+        hcol_ok = (unsigned)gy < (unsigned)sc.H && (unsigned)gx < (unsigned)sc.W;
+        hcol = sc.pred[(img + min(max(gy, 0), sc.H - 1)) * sc.W + min(max(gx, 0), sc.W - 1)];
+        hcol_idx = (i >> 2) * LS + 4 + j;
+    }
+    // the single G pixel of this thread (threads 0..195): LDS position (row gl of the planes, column gj of the image tile) and its labels
+    const bool gx_row = tid < 2 * TW;
+    const int gl = gx_row ? (tid < TW ? 0 : TH + 1) : (tid - 2 * TW) >> 1;                    // plane row = tile row + 1
+    const int gj = gx_row ? (tid & (TW - 1)) : ((tid - 2 * TW) & 1 ? TW : -1);
+    const bool g_has = tid < 2 * TW + 2 * (TH + 2);
+    float ge = 0.f, gn = 0.f; bool g_ok = false;
+    if (g_has) {
+        const int gy = y0 + gl - 1, gx = x0 + gj;
+        g_ok = (unsigned)gy < (unsigned)sc.H && (unsigned)gx < (unsigned)sc.W;
+        const long o = (img + min(max(gy, 0), sc.H - 1)) * sc.W + min(max(gx, 0), sc.W - 1);
+        ge = sc.edge[o]; gn = sc.normal[o];
+    }
+    // ---- depth tile (the own rows' depth stays in registers for the chain rule)
+    f32x4_t dep[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        dep[ps] = depth4(og[ps].ok, inv4[ps]);
+        *(f32x4_t*)(sd + (r0 + 16 * ps + 2) * LS + 4 + c) = dep[ps];
+    }
+    if (tid < 64) *(f32x4_t*)(sd + hrow_ly * LS + 4 + c) = depth4(hrow_ok, hrow);
+    else if (tid < 64 + 4 * (TH + 4)) sd[hcol_idx] = hcol_ok ? rcp_newton(fmaxf(hcol, 1e-6f)) : 0.f;
+    __syncthreads();
+    // ---- planes of G: own pixels, then the halo pixel
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        float w[3][6];
+        window(sd, r0 + 16 * ps + 2, c, w);
+        const f32x4_t e = sel4(og[ps].ok, e4[ps]);
+        const float vm = og[ps].ok ? 1.f : 0.f;
+        f32x4_t A, B;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float Ak, Bk;
+            g_planes(w, k, n4[ps][k], cpos * e[k], cneg * (vm - e[k]), tk, Ak, Bk);
+            A[k] = Ak; B[k] = Bk;
+        }
+        *(f32x4_t*)(sga + (r0 + 16 * ps + 1) * LS + 4 + c) = A;
+        *(f32x4_t*)(sgb + (r0 + 16 * ps + 1) * LS + 4 + c) = B;
+    }
+    if (g_has) {
+        float w[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[r][k] = sd[(gl + r) * LS + 4 + gj - 1 + k];          // plane row gl = depth rows gl .. gl + 2
+        float Ak, Bk;
+        const float e = g_ok ? ge : 0.f;
+        g_planes(w, 0, gn, cpos * e, cneg * ((g_ok ? 1.f : 0.f) - e), tk, Ak, Bk);
+        sga[gl * LS + 4 + gj] = Ak; sgb[gl * LS + 4 + gj] = Bk;
+    }
+    __syncthreads();
+    // ---- transposed Sobel, chain rule through 1 / max(inv, 1e-6), silog gradient
+    const float m1 = silog ? a.silog_aux[0] : 0.f, ksl = silog ? a.silog_aux[1] * (a.silog_gout ? a.silog_gout[0] : 1.f) : 0.f;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        float wa[3][6], wb[3][6];
+        window(sga, r0 + 16 * ps + 1, c, wa);
+        window(sgb, r0 + 16 * ps + 1, c, wb);
+        float ca[6], eb[6], cc1[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            ca[j] = (wa[0][j] + wa[1][j]) + wa[2][j];
+            eb[j] = wb[0][j] - wb[2][j];
+            cc1[j] = wb[1][j] == 0.f ? wa[1][j] : 0.f;
+        }
+        f32x4_t out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d0 = wa[0][k + 1] == 0.f ? wb[0][k + 1] : 0.f, d2 = wa[2][k + 1] == 0.f ? wb[2][k + 1] : 0.f;
+            const float dd = (ca[k] - ca[k + 2]) + ((eb[k] + eb[k + 1]) + eb[k + 2]) + (cc1[k] - cc1[k + 2]) + (d0 - d2);
+            const float d = dep[ps][k];
+            out[k] = inv4[ps][k] >= 1e-6f ? -dd * d * d : 0.f;
+        }
+        if (silog) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dgt = d4[ps][k];
+                const float gt = rcpf(fmaxf(dgt, 1e-6f));
+                const float pi = inv4[ps][k] + 1e-5f;
+                const float dl = (__builtin_amdgcn_logf(pi * 10.f) - __builtin_amdgcn_logf(gt * 10.f)) * LN2;
+                out[k] += dgt > 0.f ? ksl * (dl - 0.85f * m1) * rcpf(pi) : 0.f;
+            }
+        }
+        if (og[ps].ok) *(f32x4_t*)(sc.dpred + og[ps].off) = out;
+    }
+}
+
 // ---------------- silog (stand-alone: SupervisedLoss used without the edge loss) -------------------------------------
 __global__ __launch_bounds__(256) void silog_fwd_kernel(const float* __restrict__ inv, const float* __restrict__ depth, long n, double* __restrict__ sums) {
     __shared__ double sred[4][3];
@@ -748,8 +1052,8 @@ int mte_edge_loss_multi_fwd(const void* scales, int nscales, int B, int from_inv
     a.silog_loss = silog_loss; a.silog_aux = silog_aux;
     const long r = results_elems(nscales, B);
     a.results = work; a.counter = (unsigned*)(work + r); a.records = work + r + counter_elems(nscales, B);
-    if (mte_memset_async(work, 0, sizeof(double) * (r + counter_elems(nscales, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;     // sums + tickets (the records are overwritten)
-    if (fast_config(a)) hipLaunchKernelGGL(edge_loss_fwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+    if (!g_mte_loss_prezeroed && mte_memset_async(work, 0, sizeof(double) * (r + counter_elems(nscales, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;     // sums + tickets (the records are overwritten)
+    if (fast_config(a)) hipLaunchKernelGGL(edge_fwd_fast_kernel, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(edge_loss_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
@@ -765,7 +1069,7 @@ int mte_edge_loss_multi_bwd(const void* scales, int nscales, int B, int from_inv
     if (gt_depth && !aligned16(gt_depth)) a.s[0].vec = 0;
     a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.thresh = thresh;
     a.coef = (float*)coef; a.gout = gout; a.gt_depth = gt_depth; a.silog_aux = (float*)silog_aux; a.silog_gout = silog_gout;
-    if (fast_config(a)) hipLaunchKernelGGL(edge_loss_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+    if (fast_config(a)) hipLaunchKernelGGL(edge_bwd_fast_kernel, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(edge_loss_bwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();
 }
@@ -790,7 +1094,7 @@ int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal,
     a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.finalize = 0; a.thresh = thresh;
     const long r = results_elems(1, B);
     a.results = sums; a.counter = (unsigned*)(sums + r); a.records = sums + r + counter_elems(1, B);
-    if (mte_memset_async(sums, 0, sizeof(double) * (r + counter_elems(1, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    if (!g_mte_loss_prezeroed && mte_memset_async(sums, 0, sizeof(double) * (r + counter_elems(1, B)), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     hipLaunchKernelGGL(edge_loss_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
     return mte_check_launch();
 }

@@ -1161,6 +1161,7 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
 
 int mte_set_option(int option, int value) {
     if (option == 0) { g_mte_gn_prezeroed = value ? 1 : 0; return MTE_OK; }      // MTE_OPT_GN_PREZEROED
+    if (option == 1) { g_mte_loss_prezeroed = value ? 1 : 0; return MTE_OK; }    // MTE_OPT_LOSS_PREZEROED
     return MTE_ERR_ARG;
 }
 

@@ -260,6 +260,7 @@ class _ZeroArena:
     def zeros(self, shape, dtype, device):
         if not self.enabled:             # from now on the library trusts GroupNorm accumulation buffers to arrive zeroed
             lib.set_option(0, 1)
+            lib.set_option(1, 1)         # ... and the loss workspaces (also carved from here)
             self.enabled = True
         n = 1
         for d in shape:
@@ -1455,7 +1456,7 @@ class EdgeLossFn(torch.autograd.Function):
         normal = None if normal is None else normal.contiguous().float()
         mask = None if mask is None else mask.contiguous().float()
         dev = pred.device
-        sums = torch.empty((lib.mte_edge_loss_sums_elems(B, H, W),), dtype=torch.float64, device=dev)
+        sums = _zeros((lib.mte_edge_loss_sums_elems(B, H, W),), torch.float64, dev)
         coef = torch.empty((2 * B + 1,), dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         gmap = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_gmap else None
@@ -1533,7 +1534,7 @@ class DepthLossesFn(torch.autograd.Function):
             o.pred, o.edge, o.normal, o.mask = p.data_ptr(), e.data_ptr(), _ptr(n), _ptr(mask)
             o.gmap = o.dpred = None
             o.H, o.W = p.shape[-2], p.shape[-1]
-        work = torch.empty((lib.mte_edge_loss_work_elems(ctypes.addressof(arr), S, B),), dtype=torch.float64, device=dev)
+        work = _zeros((lib.mte_edge_loss_work_elems(ctypes.addressof(arr), S, B),), torch.float64, dev)
         losses = torch.empty((S + (1 if gt is not None else 0),), dtype=torch.float32, device=dev)
         coef = torch.empty((S * (2 * B + 1),), dtype=torch.float32, device=dev)
         aux = torch.empty((2,), dtype=torch.float32, device=dev) if gt is not None else None

@@ -1,4 +1,4 @@
-"""The loss kernels' direction-bin function (csrc/edge_direction.hpp: four integer compares + a table) against the literal restatement of
+"""The loss kernels' direction-bin functions (csrc/edge_direction.hpp: four integer compares + a table; three range tests + the sign) against the literal restatement of
 GradLayer's masks (reference packnet_sfm/losses/grad_loss.py:80-93) kept in the same header: compiled for the host with g++ and compared
 over float bit patterns -- every pattern within 4096 ulps of +-k*pi/8, the special values, and every 257th pattern of all 2^32 (set
 MTE_EXHAUSTIVE=1 for all of them: ~25 s)."""
@@ -16,8 +16,8 @@ HARNESS = r"""
 static long bad = 0, n = 0;
 static void check(uint32_t v) {
     float f; std::memcpy(&f, &v, 4);
-    const int a = direction_code_literal(f), b = direction_code(f);
-    if (a != b && bad++ < 10) std::printf("mismatch %08x %g literal %d fast %d\n", v, f, a, b);
+    const int a = direction_code_literal(f), b = direction_code(f), c = code_from_masks(direction_masks(f));
+    if ((a != b || a != c) && bad++ < 10) std::printf("mismatch %08x %g literal %d fast %d masks %d\n", v, f, a, b, c);
     ++n;
 }
 int main(int argc, char** argv) {

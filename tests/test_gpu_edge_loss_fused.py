@@ -173,6 +173,17 @@ def test_full_size_384x1280_and_determinism():
         assert float(d.max()) <= 2e-2, (s_, float(d.max()))
         ok = d <= 2e-4
         assert float((a.double() - b)[ok].pow(2).mean().sqrt() / b[ok].pow(2).mean().sqrt()) <= 1e-4
-    again = _hip(invs, batch)
-    for a, b in zip(got[:3], again[:3]):                     # fp64 combination of the workgroup sums: run-to-run noise ~1e-16
-        assert a == pytest.approx(b, rel=1e-6)
+    # round 4: no floating-point atomics on the loss path any more -- one record per workgroup, image sums and loss sums added in a fixed
+    # order (forward), no accumulation at all in the backward: losses AND gradients are bit-reproducible, also with other work on the chip
+    noise = torch.cuda.Stream()
+    na = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    nb = torch.empty_like(na)
+    for rep in range(3):
+        if rep:
+            with torch.cuda.stream(noise):
+                nb.copy_(na)
+        again = _hip(invs, batch)
+        assert again[:3] == got[:3]
+        for a, b in zip(got[3], again[3]):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
