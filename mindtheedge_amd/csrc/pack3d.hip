@@ -853,6 +853,262 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) 
     }
 }
 
+// ---- conv3d data paths on the matrix cores (round 4).  The fp32-VALU stencils above run at ~23 cycles per output and SIMD on the large
+// layers (108 FMAs + the bf16 unpacking of every window, two workgroups per CU, staging and arithmetic one after the other) -- a seventh of
+// the vector peak and a fifth of the HBM rate.  The depth taps make the stencil a GEMM against a BANDED matrix: for one (feature, kh, kw)
+//     out[pixel][d0 + n] += sum_kk  X[pixel'][d0 - 8 + kk] * T[kk][n],     T[kk][n] = w[kd = n + 9 - kk] for 0 <= kd <= 2, else 0
+// i.e. one v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 depths with K = a 32-deep window of the LDS tile that starts 8 depths (one
+// 16-byte chunk: aligned ds_read_b128) below the block.  Only 3 of 32 K entries per column carry weight, and that is still 5x faster: 36
+// (feature, kh, kw) x 2 MFMAs (weights split into bf16 hi + lo parts, so the fp32 conv3d weights keep ~16 bits) = 72 MFMAs x 16 cycles per
+// 256 outputs = 4.5 cycles per output, with one LDS read per 2 MFMAs.  The banded operand is never stored: a lane's 8 entries are byte
+// permutes (v_perm_b32, selectors fixed per lane) of the two dwords {w0 w1} {w2 0} read from a 36-entry LDS table.
+// Operands are SWAPPED (weights first): an accumulator register then holds 4 consecutive DEPTHS of one pixel -> 8-byte stores.
+//
+// unpack backward data, C = 32 / 64: tile = TH x 16 pixels, the four feature planes of the pixel-shuffled gradient staged together
+// ([plane][pixel][8 zero | C depths | 8 zero] bf16, 69 KB: two workgroups per CU); a wave owns 4 (tile row, depth block) units.
+int g_p3_mfma_data = 7;                              // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower)
+
+__device__ __forceinline__ bf16x8_t banded_fragment(unsigned t0, unsigned t1, const unsigned sel[4]) {
+    u32x4_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_perm(t1, t0, sel[j]);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void unpack3d_bwd_data_mfma_kernel(P3LArgs a) {
+    constexpr int TH = C == 32 ? 8 : 4, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDR = C + 16, DB = C / 16, PLANE = NPIX * LDR;
+    constexpr int CPP = C / 32;                           // 16-byte chunks (8 channels) of one feature plane in a sub-pixel's record
+    constexpr int ITEMS = NPIX * (C / 8), NIT = (ITEMS + 255) / 256;
+    static_assert(TH * DB == 16, "four units per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* tile = (bf16_t*)smem_;
+    __shared__ __attribute__((aligned(16))) unsigned wtab[36 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b, h0, w0;
+    up_tile_coords(a, xcd_remap(blockIdx.x, gridDim.x), b, h0, w0);
+    // ---- the gradient records of the tile + halo: item = (tile pixel, chunk q of the C-channel record), q fastest: the C / 8 lanes of a
+    //      pixel read one contiguous record per sub-pixel.  Addresses clamped into the image, values selected to zero.
+    u32x4_t v[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int q = idx % (C / 8), t = idx / (C / 8);
+        const int hh = h0 - 1 + t / PW, ww = w0 - 1 + t % PW;
+        const bool ok = idx < ITEMS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        const int ch = min(max(hh, 0), a.H - 1), cw = min(max(ww, 0), a.W - 1);
+        const bf16_t* src = a.o + (((long)b * 2 * a.H + 2 * ch) * (2 * a.W) + 2 * cw) * a.ldo + q * 8;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const u32x4_t r = *(const u32x4_t*)(src + ((long)(sp >> 1) * (2 * a.W) + (sp & 1)) * a.ldo);
+            v[it][sp] = u32x4_t{ok ? r[0] : 0u, ok ? r[1] : 0u, ok ? r[2] : 0u, ok ? r[3] : 0u};
+#if defined(MTE_P3_ABLATE) && (MTE_P3_ABLATE & 1)
+            v[it][sp] = u32x4_t{(unsigned)idx, 0u, 0u, 0u};          // diagnostic: no global loads
+#endif
+        }
+    }
+    // ---- weights: {w0 w1} {w2 0} as bf16 hi parts and lo parts (w - hi) per (feature, kh, kw); zero pads of every pixel row
+    if (tid < 36) {
+        const int f = tid / 9, k9 = tid - 9 * f;
+        unsigned hi[3], lo[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const float w = a.w3[(f * 3 + kd) * 9 + k9];
+            hi[kd] = f2bf(w); lo[kd] = f2bf(w - bf2f((bf16_t)hi[kd]));
+        }
+        *(u32x4_t*)(wtab + 4 * tid) = u32x4_t{hi[0] | (hi[1] << 16), hi[2], lo[0] | (lo[1] << 16), lo[2]};
+    }
+    for (int i = tid; i < 4 * NPIX * 2; i += 256) *(u32x4_t*)(tile + (i >> 1) * LDR + ((i & 1) ? C + 8 : 0)) = u32x4_t{0u, 0u, 0u, 0u};
+    // ---- records -> planes: depth d = 4 c + s (c: channel of the plane, s: sub-pixel); see stage_packed_tile for the interleave
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < ITEMS) {
+            const int q = idx % (C / 8), t = idx / (C / 8);
+            const int f = q / CPP, cc = q % CPP;
+            bf16_t* dstp = tile + f * PLANE + t * LDR + 8 + 32 * cc;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                u32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned lo = v[it][2 * (k & 1)][qq], hi = v[it][2 * (k & 1) + 1][qq];
+                    o[k] = (k >> 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+                }
+                *(u32x4_t*)(dstp + 8 * qq) = o;
+            }
+        }
+    }
+    // ---- this lane's part of the banded operand: row n = lane % 16 (output depth), K entries 8 g .. 8 g + 7; entry kk carries w[kd = n + 9 - kk]
+    const int n = lane & 15, g = lane >> 4;
+    unsigned sel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned sv = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int kd = n + 9 - (8 * g + 2 * j + e);
+            // bytes of the pool {t1 (4..7), t0 (0..3)}: w0 = 0,1  w1 = 2,3  w2 = 4,5; 0x0c = constant zero
+            const unsigned two = kd == 0 ? 0x0100u : (kd == 1 ? 0x0302u : (kd == 2 ? 0x0504u : 0x0c0cu));
+            sv |= two << (16 * e);
+        }
+        sel[j] = sv;
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    // unit u of this wave: tile row and depth block
+    auto unit_row = [&](int u) { return C == 32 ? 2 * wave + (u >> 1) : wave; };
+    auto unit_db = [&](int u) { return C == 32 ? (u & 1) : u; };
+#pragma unroll 1
+#if defined(MTE_P3_ABLATE) && (MTE_P3_ABLATE & 2)
+    for (int f = 0; f < 1; ++f) {                                  // diagnostic: a quarter of the MFMA loop
+#else
+    for (int f = 0; f < 4; ++f) {
+#endif
+#pragma unroll
+        for (int k9 = 0; k9 < 9; ++k9) {
+            const int kh = k9 / 3, kw = k9 - 3 * kh;
+            const u32x4_t wq = *(const u32x4_t*)(wtab + 4 * (f * 9 + k9));
+            const bf16x8_t bhi = banded_fragment(wq[0], wq[1], sel), blo = banded_fragment(wq[2], wq[3], sel);
+            bf16x8_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pix = (unit_row(u) + 2 - kh) * PW + n + 2 - kw;        // source pixel p + 1 - k of output pixel (row, n), tile origin (-1, -1)
+                x[u] = *(const bf16x8_t*)(tile + f * PLANE + pix * LDR + 16 * unit_db(u) + 8 * g);
+            }
+            // the four units between the two MFMAs of one accumulator (a dependent MFMA waits out the first one's passes)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x[u], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x[u], acc[u], 0, 0, 0);
+        }
+    }
+    // ---- accumulator register j of unit u: depth 16 db + 4 g + j of pixel (row, n)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int h = h0 + unit_row(u), w = w0 + n;
+        if (h < a.H && w < a.W) {
+            unsigned* dp = (unsigned*)(a.dst + (((long)b * a.H + h) * a.W + w) * a.lddst + 16 * unit_db(u) + 4 * g);
+            dp[0] = pack2bf(acc[u][0], acc[u][1]);
+            dp[1] = pack2bf(acc[u][2], acc[u][3]);
+        }
+    }
+}
+
+// unpack backward data, C = 32, second form: the gradient records go into LDS AS THEY ARE ([tile pixel][16 chunks = 4 sub-pixels x 4 feature
+// planes] x 16 bytes, 46 KB: three workgroups per CU) by buffer_load ... lds -- no registers, no interleave, no LDS stores.  The order of the
+// K entries of an MFMA is free as long as both operands agree, so the data operand of lane (pixel, g) is simply sub-pixel g's 8 channels of
+// plane f (depths 4 t + g, t = 0..7) and the banded operand's selectors are built for that order; likewise the ROWS of the banded operand
+// are assigned to output depths so that a lane ends up with 8 consecutive depths (row 4 g' + j of block blk = depth 8 g' + 4 blk + j): one
+// 16-byte store.  With C = 32 one 32-deep window holds the whole depth range, so ONE LDS read feeds the four MFMAs of a (feature, kh, kw)
+// (two depth blocks x hi / lo) and depth padding needs no storage.  The 16 chunks of a pixel are XOR-swizzled with the pixel's column so that
+// the 16 lanes of a read phase (16 consecutive pixels, same chunk) hit 16 different bank groups.
+template <int WAVES>                                  // waves per workgroup; a wave owns RW = 8 / WAVES tile rows: the 16 v_perm of a (feature, kh, kw) are shared by 4 RW MFMAs
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 3) void unpack3d_bwd_data_dma32_kernel(P3LArgs a) {
+    constexpr int TH = 8, PW = 18, NPIX = 180, RW = TH / WAVES;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    __shared__ __attribute__((aligned(16))) unsigned wtab[36 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b, h0, w0;
+    up_tile_coords(a, xcd_remap(blockIdx.x, gridDim.x), b, h0, w0);
+    const long total = ((long)a.B * 4 * a.H * a.W - 1) * a.ldo + 32;                          // elements of the gradient tensor (launcher: < 2^30)
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.o, 0, (int)(total * 2), 0x00020000);
+#pragma unroll 1
+    for (int k = wave; k < NPIX / 4; k += WAVES) {                 // one instruction = 4 tile pixels x 16 chunks = 1 KB of LDS
+        const int t = 4 * k + (lane >> 4);
+        const int py = t / PW, px = t - PW * py;
+        const int chunk = (lane & 15) ^ (px & 15), sp = chunk >> 2, f = chunk & 3;
+        const int hh = h0 - 1 + py, ww = w0 - 1 + px;
+        const bool ok = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        const long el = (((long)b * 2 * a.H + 2 * hh + (sp >> 1)) * (2 * a.W) + 2 * ww + (sp & 1)) * a.ldo + 8 * f;
+        const unsigned off = ok ? (unsigned)(el * 2) : 0x7ffffff0u;                            // out of range: the load returns zeros
+#if defined(MTE_P3_ABLATE) && (MTE_P3_ABLATE & 1)
+        if (off == 0x12345u)                                       // diagnostic: no staging
+#endif
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem_ + k * 1024), 16, off, 0, 0, 0);
+    }
+    if (tid < 36) {
+        const int f = tid / 9, k9 = tid - 9 * f;
+        unsigned hi[3], lo[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const float w = a.w3[(f * 3 + kd) * 9 + k9];
+            hi[kd] = f2bf(w); lo[kd] = f2bf(w - bf2f((bf16_t)hi[kd]));
+        }
+        *(u32x4_t*)(wtab + 4 * tid) = u32x4_t{hi[0] | (hi[1] << 16), hi[2], lo[0] | (lo[1] << 16), lo[2]};
+    }
+    // banded operand of this lane: row m = lane % 16 <-> output depth 8 (m / 4) + 4 blk + m % 4; K entry t of group g <-> input depth 4 t + g
+    const int n = lane & 15, g = lane >> 4;
+    unsigned sel[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned sv = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kd = (8 * (n >> 2) + 4 * blk + (n & 3)) + 1 - (4 * (2 * j + e) + g);
+                const unsigned two = kd == 0 ? 0x0100u : (kd == 1 ? 0x0302u : (kd == 2 ? 0x0504u : 0x0c0cu));
+                sv |= two << (16 * e);
+            }
+            sel[blk][j] = sv;
+        }
+    f32x4_t acc[RW][2];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) acc[r][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+#if defined(MTE_P3_ABLATE) && (MTE_P3_ABLATE & 2)
+    for (int f = 0; f < 1; ++f) {                                  // diagnostic: a quarter of the MFMA loop
+#else
+    for (int f = 0; f < 4; ++f) {
+#endif
+#pragma unroll
+        for (int k9 = 0; k9 < 9; ++k9) {
+            const int kh = k9 / 3, kw = k9 - 3 * kh;
+            const u32x4_t wq = *(const u32x4_t*)(wtab + 4 * (f * 9 + k9));
+            bf16x8_t x[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {                         // rows RW wave + r of the tile; source pixel p + 1 - k, tile origin (-1, -1)
+                const int px = n + 2 - kw, t = (RW * wave + r + 2 - kh) * PW + px;
+                x[r] = *(const bf16x8_t*)(smem_ + t * 256 + (((4 * g + f) ^ (px & 15)) << 4));
+            }
+            const bf16x8_t h0f = banded_fragment(wq[0], wq[1], sel[0]), h1f = banded_fragment(wq[0], wq[1], sel[1]);
+            const bf16x8_t l0f = banded_fragment(wq[2], wq[3], sel[0]), l1f = banded_fragment(wq[2], wq[3], sel[1]);
+            // 2 RW independent accumulators between the two MFMAs of one accumulator (a dependent MFMA waits out the first one's passes)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0f, x[r], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1f, x[r], acc[r][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0f, x[r], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1f, x[r], acc[r][1], 0, 0, 0);
+            }
+        }
+    }
+    // lane (pixel n, g): register j of block blk = depth 8 g + 4 blk + j
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int h = h0 + RW * wave + r, w = w0 + n;
+#if defined(MTE_P3_ABLATE) && (MTE_P3_ABLATE & 4)
+        if (h < a.H && w < a.W && acc[r][0][0] == 123.f) {         // diagnostic: no stores
+#else
+        if (h < a.H && w < a.W) {
+#endif
+            u32x4_t o = {pack2bf(acc[r][0][0], acc[r][0][1]), pack2bf(acc[r][0][2], acc[r][0][3]), pack2bf(acc[r][1][0], acc[r][1][1]), pack2bf(acc[r][1][2], acc[r][1][3])};
+            *(u32x4_t*)(a.dst + (((long)b * a.H + h) * a.W + w) * a.lddst + 8 * g) = o;
+        }
+    }
+}
+
 // dw3/db3 for UNPACK: x tile staged directly; the 8 feature gradients of an item are gathered from the shuffled dout
 __global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -1092,7 +1348,7 @@ int g_p3_mfma = 1;                                  // development knob (mte_deb
 }  // namespace
 
 #ifdef MTE_DEV
-extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
+extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 300) { g_p3_mfma_data = value - 300; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
 #endif
 
 
@@ -1159,6 +1415,19 @@ int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx,
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
+    if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && (g_p3_mfma_data & 1) && (C == 32 || C == 64)) {
+        P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;
+        l.TH = C == 32 ? 8 : 4; l.TW = 16;
+        l.tiles_h = (H + l.TH - 1) / l.TH; l.tiles_w = (W + l.TW - 1) / l.TW; l.ntiles = l.tiles_h * l.tiles_w * B;
+        l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
+        const size_t lds = (size_t)4 * (l.TH + 2) * (l.TW + 2) * (C + 16) * 2;
+        if (C == 32 && (g_p3_mfma_data & 2) && ((long)B * 4 * H * W - 1) * ldo + 32 < (1L << 30)) {
+            if (g_p3_mfma_data & 4) return launch_p3l(unpack3d_bwd_data_dma32_kernel<4>, l, l.ntiles, stream, (size_t)180 * 256, 256);
+            return launch_p3l(unpack3d_bwd_data_dma32_kernel<2>, l, l.ntiles, stream, (size_t)180 * 256, 128);
+        }
+        if (C == 32) return launch_p3l(unpack3d_bwd_data_mfma_kernel<32>, l, l.ntiles, stream, lds);
+        return launch_p3l(unpack3d_bwd_data_mfma_kernel<64>, l, l.ntiles, stream, lds);
+    }
     if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && C % 32 == 0 && C <= 128) {
         P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;
         const P3Tile t = up4_tile(C); l.TH = t.TH; l.TW = t.TW;

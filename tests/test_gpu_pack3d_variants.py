@@ -58,3 +58,42 @@ def test_lds_unpack3d_backward_matches_gather(C, B, H, W):
         assert rel_err(a[1], r[1]) < 8e-3
         assert rel_err(a[2], r[2]) < 5e-4
         assert rel_err(a[3], r[3]) < 5e-4
+
+
+def _unpack_bwd_data(C, B, H, W, knob, seed):
+    """dx of the unpack layer's conv3d for one kernel variant (development knob 1: 300 = fp32-VALU stencil, 301 = matrix cores with interleaved
+    planes, 303 / 307 = + raw records by LDS-DMA for C = 32 with 2 / 4 waves [307 = product])"""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd._lib import dev_library
+    K.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(seed)
+    dout = K.image_to_act((torch.rand(B, C, 2 * H, 2 * W, generator=g) * 2 - 1).cuda())
+    w3 = ((torch.rand(4, 1, 3, 3, 3, generator=g) - 0.5) * 0.8).cuda()
+    dx = K.new_act(B, C, H, W)
+    dx.fill_(7.0)
+    dp, ldo = K._pl(dout)
+    xp, ldx = K._pl(dx)
+    with dev_library() as lib:
+        lib.mte_debug_set(1, knob)
+        try:
+            for _ in range(2):
+                lib.mte_unpack3d_bwd_data(dp, ldo, w3.data_ptr(), xp, ldx, B, H, W, C, K._dt(dx), K._stream())
+            torch.cuda.synchronize()
+        finally:
+            lib.mte_debug_set(1, 307)
+    return dx.float().cpu()
+
+
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 16, 32), (32, 1, 17, 33), (32, 3, 8, 16), (32, 1, 1, 1), (32, 1, 9, 47), (64, 1, 12, 48), (64, 2, 5, 19),
+                                      (64, 1, 4, 16), (32, 2, 96, 160)])
+def test_matrix_core_unpack3d_backward_data_matches_the_valu_stencil(C, B, H, W):
+    """banded-operand MFMA forms (weights as bf16 hi + lo parts: ~fp32 weights) against the fp32-VALU stencil on the same bf16 gradient:
+    the results may differ by one bf16 rounding of the output where the fp32 sums differ in the last bits"""
+    ref = _unpack_bwd_data(C, B, H, W, 300, seed=C + H)
+    for knob in (301, 303, 307):
+        got = _unpack_bwd_data(C, B, H, W, knob, seed=C + H)
+        d = (got - ref).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(ref.abs().max()), (knob, float(d.max()))         # one bf16 ulp at the largest magnitude
+        assert float((d > 0).float().mean()) < 0.05, (knob, float((d > 0).float().mean()))           # ... and rarely
+        rms = float(d.double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt())
+        assert rms < 1e-3, (knob, rms)
