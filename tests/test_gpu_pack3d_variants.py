@@ -62,7 +62,7 @@ def test_lds_unpack3d_backward_matches_gather(C, B, H, W):
 
 def _unpack_bwd_data(C, B, H, W, knob, seed):
     """dx of the unpack layer's conv3d for one kernel variant (development knob 1: 300 = fp32-VALU stencil, 301 = matrix cores with interleaved
-    planes, 303 / 307 = + raw records by LDS-DMA for C = 32 with 2 / 4 waves [307 = product])"""
+    planes, 303 / 307 = + raw records by LDS-DMA for C = 32 with 2 / 4 waves; + 8 = forward on the matrix cores [315 = product])"""
     from mindtheedge_amd import kernels as K
     from mindtheedge_amd._lib import dev_library
     K.set_compute_dtype("bf16")
@@ -80,7 +80,7 @@ def _unpack_bwd_data(C, B, H, W, knob, seed):
                 lib.mte_unpack3d_bwd_data(dp, ldo, w3.data_ptr(), xp, ldx, B, H, W, C, K._dt(dx), K._stream())
             torch.cuda.synchronize()
         finally:
-            lib.mte_debug_set(1, 307)
+            lib.mte_debug_set(1, 315)
     return dx.float().cpu()
 
 
@@ -97,3 +97,43 @@ def test_matrix_core_unpack3d_backward_data_matches_the_valu_stencil(C, B, H, W)
         assert float((d > 0).float().mean()) < 0.05, (knob, float((d > 0).float().mean()))           # ... and rarely
         rms = float(d.double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt())
         assert rms < 1e-3, (knob, rms)
+
+
+def _unpack_fwd(C, B, H, W, knob, seed, persist=1024):
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd._lib import dev_library
+    K.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(seed)
+    x = K.image_to_act((torch.rand(B, C, H, W, generator=g) * 2 - 1).cuda())
+    w3 = ((torch.rand(4, 1, 3, 3, 3, generator=g) - 0.5) * 0.8).cuda()
+    b3 = ((torch.rand(4, generator=g) - 0.5) * 0.4).cuda()
+    out = K.new_act(B, C, 2 * H, 2 * W)
+    out.fill_(7.0)
+    xp, ldx = K._pl(x)
+    op, ldo = K._pl(out)
+    with dev_library() as lib:
+        lib.mte_debug_set(1, knob)
+        lib.mte_debug_set(1, 2000 + persist)          # workgroups of the persistent kernel: few -> every workgroup walks many tiles (double-buffered LDS)
+        try:
+            for _ in range(2):
+                lib.mte_unpack3d_fwd(xp, ldx, w3.data_ptr(), b3.data_ptr(), op, ldo, B, H, W, C, K._dt(x), K._stream())
+            torch.cuda.synchronize()
+        finally:
+            lib.mte_debug_set(1, 315)
+            lib.mte_debug_set(1, 2000 + 1024)
+    return out.float().cpu()
+
+
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 16, 32), (32, 1, 17, 33), (32, 3, 8, 16), (32, 1, 1, 1), (32, 1, 9, 47), (64, 1, 12, 48), (64, 2, 5, 19),
+                                      (64, 1, 4, 16), (32, 2, 96, 160)])
+def test_matrix_core_unpack3d_forward_matches_the_valu_stencil(C, B, H, W):
+    """conv3d(1 -> 4) + pixel shuffle: banded-operand MFMA form (315) against the fp32-VALU gather kernel (307) on the same bf16 input"""
+    ref = _unpack_fwd(C, B, H, W, 307, seed=C + W)
+    got = _unpack_fwd(C, B, H, W, 315, seed=C + W)
+    for wgs in (8, 24):                                    # the same tiles dealt to 8 / 24 workgroups: bit-identical
+        assert torch.equal(_unpack_fwd(C, B, H, W, 315, seed=C + W, persist=wgs), got), wgs
+    d = (got - ref).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(ref.abs().max()), float(d.max())
+    assert float((d > 0).float().mean()) < 0.05, float((d > 0).float().mean())
+    rms = float(d.double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt())
+    assert rms < 1e-3, rms
