@@ -7,6 +7,7 @@
 //   * channel-slice copy (skip connections into concat buffers)
 //   * fused Adam step over the flat fp32 master-parameter buffer (model_wrapper.py:142-180: Adam, wd 0)
 #include "common.hpp"
+#include <atomic>
 
 namespace {
 
@@ -437,15 +438,19 @@ inline long head_strips(int B, int H, int W, int C) {               // strips of
     return (long)((W + pxw - 1) / pxw) * ((H + HEAD_ROWS - 1) / HEAD_ROWS) * B;
 }
 // workgroups the chip holds at once for kernel `f` (256 threads, `lds` dynamic bytes); queried once per kernel
-template <typename F> int head_resident(F f, size_t lds, int* cache) {
-    if (*cache == 0) {
+// (the dynamic LDS size follows the head's channel count, so the answer is cached per (kernel, C); relaxed atomics: two threads that race
+// compute the same value)
+template <typename F> int head_resident(F f, size_t lds, std::atomic<int>* cache) {
+    int v = cache->load(std::memory_order_relaxed);
+    if (v == 0) {
         int per_cu = 0, dev = 0, cus = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        *cache = per_cu * cus;
+        v = per_cu * cus;
+        cache->store(v, std::memory_order_relaxed);
     }
-    return *cache;
+    return v;
 }
 inline long head_record_stride(int C) { return ((long)C * 9 + 1 + 3) / 4 * 4; }
 constexpr int HEAD_WGRAD_MAX_BLOCKS = 1024;
@@ -497,8 +502,9 @@ int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float*
     a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
     const size_t lds = sizeof(float) * (C * 9 + 4);
     long g = head_strips(B, H, W, C);
-    static int res_b = 0, res_f = 0;
-    const long res = dtype == MTE_DT_BF16 ? head_resident(invdepth_bwd_weight_kernel<bf16_t>, lds, &res_b) : head_resident(invdepth_bwd_weight_kernel<float>, lds, &res_f);
+    static std::atomic<int> res_b[64], res_f[64];               // by C / 8 (head_ok: C is a multiple of 8, at most 504)
+    const int ci = (C >> 3) & 63;
+    const long res = dtype == MTE_DT_BF16 ? head_resident(invdepth_bwd_weight_kernel<bf16_t>, lds, &res_b[ci]) : head_resident(invdepth_bwd_weight_kernel<float>, lds, &res_f[ci]);
     if (g > res) g = res;
     if (g > HEAD_WGRAD_MAX_BLOCKS) g = HEAD_WGRAD_MAX_BLOCKS;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);

@@ -516,6 +516,7 @@ def prefetch_weight_packs():
 
 
 SPLITK_SLABS = 8
+_splitk_ws = {}
 
 
 def _splitk_workspace(M, N, device):
@@ -524,7 +525,16 @@ def _splitk_workspace(M, N, device):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 384:
         return None, 0
-    return torch.empty((SPLITK_SLABS * M * N,), dtype=torch.float32, device=device), SPLITK_SLABS * M * N
+    n = SPLITK_SLABS * M * N
+    if torch.cuda.is_current_stream_capturing():             # a graph keeps its own allocation alive (private pool)
+        return torch.empty((n,), dtype=torch.float32, device=device), n
+    # one scratch buffer per stream, grown on demand: launches of a stream run in order, so the next conv's slabs cannot overtake the
+    # previous one's finish kernel (round-3 advisor: a fresh up-to-200 MB tensor per call was allocator churn for nothing)
+    key = (str(device), _stream())
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _splitk_ws[key] = torch.empty((n,), dtype=torch.float32, device=device)
+    return ws, n
 
 
 _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30,
@@ -578,6 +588,8 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumul
     B, Cp, H, W = x.shape
     if out is None:
         out = new_act(B, cout, H, W, x.dtype, x.device)
+        if sites is not None:
+            out.zero_()                                      # the sparse form writes the active sites only: the rest must not be uninitialised memory (NaN + 0 gradients downstream)
     xp, ldx = _pl(x)
     yp, ldy = _pl(out)
     if sites is not None:
@@ -775,6 +787,8 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
     if need_dx:
         target = _fork_target(fork_slot, (B, Cp, H, W), x.dtype)
         dx = target if target is not None else new_act(B, Cp, H, W, x.dtype, x.device)
+        if target is None and sites is not None:
+            dx.zero_()                                       # (as in conv_forward: inactive sites of a sparse result are exact zeros)
         acc = 1 if target is not None else 0
         dxp, lddx = _pl(dx)
         if sites is not None:                              # sparse data gradient: the same gather-GEMM-scatter with the backward pack
