@@ -743,9 +743,15 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     # in the unpack pass measured 7 % slower)
     per = cout * kh * kw * Cp
     patch = _cfg["patch_kernels"] and x.dtype == torch.bfloat16 and lib.mte_conv2d_patch_wgrad_supported(W, Cp, cout, kh, kw, DT_BF16) == 1
+    if kh * kw == 1 and Cp >= 64:
+        patch = False                    # 1x1 with >= 64 inputs: the generic kernel with many pixel splits streams both operands at 4.5 TB/s (the patch kernel deals TAPS to its waves: 91 -> 56 us)
     # the LDS-patch kernel runs 128..512 workgroups per layer: one slab each (plain stores), combined by a two-level reduction
     # (mte_unpack_conv_wgrad) -- its slabs are 70-210 KB, so even 512 of them stay near 100 MB
-    cap = max(1, min(512, (192 << 20) // (4 * per))) if patch and _cfg["patch_wgrad_slabs"] else max(1, min(32, (96 << 20) // (4 * per)))
+    # generic kernel: <= 32 pixel splits -- except where a slab is small (1x1 shortcuts: 64 KB .. 1 MB): one output tile means the pixel splits
+    # ARE the launch's workgroups, and 32 of them streamed the two 63 MB operands of a full-resolution shortcut at 1.4 TB/s (round 4)
+    # (0.091 -> 0.035 ms for 128 -> 128 at 96x320, 0.051 -> 0.026 ms for 256 -> 256 at 48x160 with up to 256 splits; the two-level part sum takes > 32 parts)
+    wide = 256 if per <= (1 << 18) else 32
+    cap = max(1, min(512, (192 << 20) // (4 * per))) if patch and _cfg["patch_wgrad_slabs"] else max(1, min(wide, (96 << 20) // (4 * per)))
     stem = _stem_ok(W, Cp, cout, kh, kw, x.dtype)
     if stem:
         cap = 2048                       # 25 KB slabs: eight 256-thread workgroups per CU keep this bandwidth-bound stream busy
