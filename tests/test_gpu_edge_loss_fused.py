@@ -187,3 +187,40 @@ def test_full_size_384x1280_and_determinism():
         for a, b in zip(got[3], again[3]):
             assert torch.equal(a, b)
     torch.cuda.synchronize()
+
+
+def test_library_clears_its_own_workspace_unless_told_otherwise():
+    """MTE_OPT_LOSS_PREZEROED off (the C-ABI default a hand-written binding gets): `work` may hold anything -- the library fills what it needs.
+    On: the caller's zeros are trusted (kernels.py carves the workspace from its zeroed arena)."""
+    import ctypes
+    from mindtheedge_amd import kernels as K
+    invs, batch = _maps(2, 96, 160, seed=9)
+    dev = torch.device("cuda")
+    preds = [i.to(dev).contiguous() for i in invs]
+    sfx = ["", "_1", "_2", "_3"]
+    edges = [batch["edge" + s].to(dev).contiguous() for s in sfx]
+    normals = [batch["normal" + s].to(dev).contiguous() for s in sfx]
+    gt = batch["depth"].to(dev).contiguous()
+    arr = (K._EdgeScale * 4)()
+    for o, p, e, n in zip(arr, preds, edges, normals):
+        o.pred, o.edge, o.normal, o.mask, o.gmap, o.dpred = p.data_ptr(), e.data_ptr(), n.data_ptr(), None, None, None
+        o.H, o.W = p.shape[-2], p.shape[-1]
+    n = K.lib.mte_edge_loss_work_elems(ctypes.addressof(arr), 4, 2)
+    results = []
+    try:
+        for prezeroed, fill in ((0, 123.0), (0, float("nan")), (1, 0.0)):
+            K.lib.set_option(1, prezeroed)
+            work = torch.full((n,), fill, dtype=torch.float64, device=dev)
+            losses = torch.empty((5,), dtype=torch.float32, device=dev)
+            coef = torch.empty((4 * 5,), dtype=torch.float32, device=dev)
+            aux = torch.empty((2,), dtype=torch.float32, device=dev)
+            K.lib.mte_edge_loss_multi_fwd(ctypes.addressof(arr), 4, 2, 1, 1, 1, 4.0, 10.0, 1.0, gt.data_ptr(), work.data_ptr(), losses.data_ptr(),
+                                          coef.data_ptr(), losses.data_ptr() + 16, aux.data_ptr(), K._stream())
+            torch.cuda.synchronize()
+            results.append((losses.clone(), coef.clone(), aux.clone()))
+    finally:
+        K.lib.set_option(1, 1 if K._arena.enabled else 0)
+    for r in results[1:]:
+        for a, b in zip(results[0], r):
+            assert torch.equal(a, b)
+    assert bool(torch.isfinite(results[0][0]).all())
