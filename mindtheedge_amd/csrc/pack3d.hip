@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) 
 // unpack backward data, C = 32 / 64: tile = TH x 16 pixels, the four feature planes of the pixel-shuffled gradient staged together
 // ([plane][pixel][8 zero | C depths | 8 zero] bf16, 69 KB: two workgroups per CU); a wave owns 4 (tile row, depth block) units.
 int g_p3_persist_wgs = 1024;                         // development knob (mte_debug_set(1, 2000 + v)): workgroups of the persistent matrix-core conv3d kernels
-int g_p3_mfma_data = 15;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs)
+int g_p3_mfma_data = 47;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs), bit 5 = unpack forward with the spatial taps in K (third form)
 
 __device__ __forceinline__ bf16x8_t banded_fragment(unsigned t0, unsigned t1, const unsigned sel[4]) {
     u32x4_t r;
@@ -1240,6 +1240,111 @@ __global__ __launch_bounds__(256, 4) void unpack3d_fwd_mfma_kernel(P3LArgs a) {
     }
 }
 
+// unpack forward, third form (round 4, any C = 32 .. 256): the SPATIAL taps in K and the depth taps in the output rows.  Per pixel and block of
+// 16 consecutive depths
+//     Y[(f, kd)][d] = sum_{tap = (kh, kw)}  w[f][kd][tap] * x[pixel + tap][d]          one v_mfma_f32_16x16x16_bf16: rows n = 4 f + kd (12 of 16), K = 9 of 16 taps
+//     out_f[d]      = Y[(f, 0)][d - 1] + Y[(f, 1)][d] + Y[(f, 2)][d + 1] + b3[f]        two DPP row shifts (the 16 lanes of a row = the block's 16 depths)
+// 42 % of the MFMA carries weight (the banded form: 9 %) and the weight operand is CONSTANT: four registers (bf16 hi + lo parts) for the whole
+// kernel, no v_perm per tap -- 2 MFMAs + ~10 VALU per 64 outputs, so the kernel is as fast as its memory traffic.  The data operand is an im2col
+// column block [16 taps][16 depths] that is never stored: each K row is 32 contiguous bytes of the LDS tile (16 depths of one shifted pixel) and
+// ds_read_b64_tr_b16 hands lane (depth, k-group) its 4 taps -- one LDS instruction per MFMA pair.  Block edges (d - 1 of lane 0, d + 1 of lane 15)
+// come from the neighbouring blocks' accumulators by row rotates.  Results go through an LDS image laid out as the pixel-shuffled output wants
+// it ([pixel][sub-pixel d % 4][channel f C/4 + d / 4]) and leave as 16-byte chunks of whole records.
+__device__ __forceinline__ float own_vgpr(float v) { asm volatile("" : "+v"(v)); return v; }
+
+template <int C, int TH>
+__global__ __launch_bounds__(256, 2) void unpack3d_fwd_tr_kernel(P3LArgs a) {
+    constexpr int TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW, NB = C / 16, NCH = C / 8;
+    constexpr int RS = (C * 2) % 128 == 64 ? C * 2 : C * 2 + 64;   // bytes of a tile pixel: an odd multiple of 64 (the 4 rows of a transposing read fall on different bank groups)
+    constexpr int IN_BYTES = NPIX * RS, OPX = 8 * C;               // output image: 4 sub-pixel records of C channels per pixel
+    constexpr int PPW = TH * TW / 4;                               // pixels per wave
+    typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    char* tin = smem_;
+    char* tout = smem_ + IN_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b, h0, w0;
+    up_tile_coords(a, xcd_remap(blockIdx.x, gridDim.x), b, h0, w0);
+    // ---- tile + halo of x, plain [pixel][depth]; addresses clamped, values selected to zero
+    constexpr int ITEMS = NPIX * NCH, NIT = (ITEMS + 255) / 256;
+    u32x4_t v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int ch = idx % NCH, t = idx / NCH;
+        const int hh = h0 - 1 + t / PW, ww = w0 - 1 + t % PW;
+        const bool ok = idx < ITEMS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        const u32x4_t r = *(const u32x4_t*)(a.x + (((long)b * a.H + min(max(hh, 0), a.H - 1)) * a.W + min(max(ww, 0), a.W - 1)) * a.ldx + 8 * ch);
+        v[it] = u32x4_t{ok ? r[0] : 0u, ok ? r[1] : 0u, ok ? r[2] : 0u, ok ? r[3] : 0u};
+    }
+    // ---- the constant weight operand: row n = lane % 16 = 4 f + kd, K entries 4 kg .. 4 kg + 3 = taps; bf16 hi and lo parts
+    const int n = lane & 15, kg = lane >> 4;
+    s16x4_t whi, wlo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int tap = 4 * kg + e, f = n >> 2, kd = n & 3;
+        const float w = (kd < 3 && tap < 9) ? a.w3[(f * 3 + kd) * 9 + tap] : 0.f;
+        const bf16_t hi = f2bf(w);
+        whi[e] = (short)hi; wlo[e] = (short)f2bf(w - bf2f(hi));
+    }
+    const float bias = a.b3[kg];                                   // accumulator rows of this lane: feature kg
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < ITEMS) *(u32x4_t*)(tin + (idx / NCH) * RS + (idx % NCH) * 16) = v[it];
+    }
+    __syncthreads();
+    // ---- this lane's row of the transposing read: tap 4 kg + q (taps >= 9 carry zero weight: any valid row), depths 4 p .. 4 p + 3 of the block
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int tap = 4 * kg + q < 9 ? 4 * kg + q : 0;
+    const int tap_off = ((tap / 3) * PW + tap % 3) * RS + 8 * p;
+#pragma unroll 1
+    for (int pi = 0; pi < PPW; ++pi) {
+        const int pix = wave * PPW + pi, py = pix / TW, px = pix % TW;   // output pixel of the tile; its 3 x 3 window starts at tile pixel (py, px)
+        const char* row = tin + (py * PW + px) * RS + tap_off;
+        f32x4_t acc[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            const s16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(row + 32 * blk));
+            acc[blk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, x, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[blk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, x, acc[blk], 0, 0, 0);
+        }
+        // lane (m = lane % 16, f = kg): acc[blk][kd] = Y[(f, kd)][16 blk + m]
+        char* orow = tout + pix * OPX + (n & 3) * (2 * C) + (kg * (C / 4) + (n >> 2)) * 2;      // sub-pixel m % 4, channel f C/4 + 4 blk + m / 4
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            // Y[(f, 0)] of depth d - 1 and Y[(f, 2)] of depth d + 1: row shifts with zero fill; the block's end lanes take the neighbouring block's
+            // value from a row rotate.  own_vgpr: hipcc (ROCm 7.2) drops the sub-register index when a DPP move reads an element of an MFMA
+            // result directly -- element 2 was read as element 0 (tools/probe/dpp_probe.hip has the lane semantics, the kd = 0 / kd = 2 delta weights of
+            // tests/test_gpu_pack3d_variants.py catch the mix-up)
+            const float y0 = own_vgpr(acc[blk][0]), y2 = own_vgpr(acc[blk][2]);
+            float t0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y0), 0x111, 0xF, 0xF, true));             // row_shr:1: lane m <- lane m - 1
+            float t2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y2), 0x101, 0xF, 0xF, true));             // row_shl:1: lane m <- lane m + 1
+            if (blk > 0) {
+                const float p0 = own_vgpr(acc[blk - 1][0]);
+                const float e = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p0), 0x121, 0xF, 0xF, true));  // row_ror:1: lane 0 <- lane 15
+                t0 = n == 0 ? e : t0;
+            }
+            if (blk + 1 < NB) {
+                const float n2 = own_vgpr(acc[blk + 1][2]);
+                const float e = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, n2), 0x12F, 0xF, 0xF, true));  // row_ror:15: lane 15 <- lane 0
+                t2 = n == 15 ? e : t2;
+            }
+            const float o = (t0 + acc[blk][1]) + (t2 + bias);
+            *(bf16_t*)(orow + blk * 8) = f2bf(o);
+        }
+    }
+    __syncthreads();
+    // ---- output image -> the four sub-pixel records of every pixel, 16-byte chunks
+    constexpr int OCH = TH * TW * 4 * NCH;
+    for (int i = tid; i < OCH; i += 256) {
+        const int ch = i % NCH, sp = (i / NCH) & 3, pix = i / (4 * NCH);
+        const int h = h0 + pix / TW, w = w0 + pix % TW;
+        if (h < a.H && w < a.W)
+            *(u32x4_t*)(a.dst + (((long)b * 2 * a.H + 2 * h + (sp >> 1)) * (2 * a.W) + 2 * w + (sp & 1)) * a.lddst + 8 * ch) = *(const u32x4_t*)(tout + pix * OPX + sp * (2 * C) + ch * 16);
+    }
+}
+
 // dw3/db3 for UNPACK: x tile staged directly; the 8 feature gradients of an item are gathered from the shuffled dout
 __global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -1538,6 +1643,18 @@ int mte_unpack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, 
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !w3 || !b3 || !out || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
+    if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && (g_p3_mfma_data & 32) && (C == 32 || C == 64 || C == 128 || C == 256)) {
+        P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;
+        l.TH = 256 / C; l.TW = 16;
+        l.tiles_h = (H + l.TH - 1) / l.TH; l.tiles_w = (W + l.TW - 1) / l.TW; l.ntiles = l.tiles_h * l.tiles_w * B;
+        l.x = (const bf16_t*)x; l.ldx = ldx; l.dst = (bf16_t*)out; l.lddst = ldo; l.w3 = w3; l.b3 = b3;
+        const int rs = (C * 2) % 128 == 64 ? C * 2 : C * 2 + 64;
+        const size_t lds = (size_t)(l.TH + 2) * 18 * rs + (size_t)l.TH * 16 * 8 * C;
+        if (C == 32) return launch_p3l(unpack3d_fwd_tr_kernel<32, 8>, l, l.ntiles, stream, lds);
+        if (C == 64) return launch_p3l(unpack3d_fwd_tr_kernel<64, 4>, l, l.ntiles, stream, lds);
+        if (C == 128) return launch_p3l(unpack3d_fwd_tr_kernel<128, 2>, l, l.ntiles, stream, lds);
+        return launch_p3l(unpack3d_fwd_tr_kernel<256, 1>, l, l.ntiles, stream, lds);
+    }
     if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && (g_p3_mfma_data & 8) && (C == 32 || C == 64) && ((long)B * H * W - 1) * ldx + C < (1L << 30)) {
         P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;
         l.TH = C == 32 ? 8 : 4; l.TW = 16;

@@ -62,7 +62,7 @@ def test_lds_unpack3d_backward_matches_gather(C, B, H, W):
 
 def _unpack_bwd_data(C, B, H, W, knob, seed):
     """dx of the unpack layer's conv3d for one kernel variant (development knob 1: 300 = fp32-VALU stencil, 301 = matrix cores with interleaved
-    planes, 303 / 307 = + raw records by LDS-DMA for C = 32 with 2 / 4 waves; + 8 = forward on the matrix cores [315 = product])"""
+    planes, 303 / 307 = + raw records by LDS-DMA for C = 32 with 2 / 4 waves; + 8 = forward as banded GEMM, + 32 = forward with the spatial taps in K [347 = product])"""
     from mindtheedge_amd import kernels as K
     from mindtheedge_amd._lib import dev_library
     K.set_compute_dtype("bf16")
@@ -80,7 +80,7 @@ def _unpack_bwd_data(C, B, H, W, knob, seed):
                 lib.mte_unpack3d_bwd_data(dp, ldo, w3.data_ptr(), xp, ldx, B, H, W, C, K._dt(dx), K._stream())
             torch.cuda.synchronize()
         finally:
-            lib.mte_debug_set(1, 315)
+            lib.mte_debug_set(1, 347)
     return dx.float().cpu()
 
 
@@ -119,21 +119,28 @@ def _unpack_fwd(C, B, H, W, knob, seed, persist=1024):
                 lib.mte_unpack3d_fwd(xp, ldx, w3.data_ptr(), b3.data_ptr(), op, ldo, B, H, W, C, K._dt(x), K._stream())
             torch.cuda.synchronize()
         finally:
-            lib.mte_debug_set(1, 315)
+            lib.mte_debug_set(1, 347)
             lib.mte_debug_set(1, 2000 + 1024)
     return out.float().cpu()
 
 
-@pytest.mark.parametrize("C,B,H,W", [(32, 2, 16, 32), (32, 1, 17, 33), (32, 3, 8, 16), (32, 1, 1, 1), (32, 1, 9, 47), (64, 1, 12, 48), (64, 2, 5, 19),
-                                      (64, 1, 4, 16), (32, 2, 96, 160)])
-def test_matrix_core_unpack3d_forward_matches_the_valu_stencil(C, B, H, W):
-    """conv3d(1 -> 4) + pixel shuffle: banded-operand MFMA form (315) against the fp32-VALU gather kernel (307) on the same bf16 input"""
-    ref = _unpack_fwd(C, B, H, W, 307, seed=C + W)
-    got = _unpack_fwd(C, B, H, W, 315, seed=C + W)
-    for wgs in (8, 24):                                    # the same tiles dealt to 8 / 24 workgroups: bit-identical
-        assert torch.equal(_unpack_fwd(C, B, H, W, 315, seed=C + W, persist=wgs), got), wgs
+def _close_to_valu(got, ref):
     d = (got - ref).abs()
     assert float(d.max()) <= 2.0 ** -7 * float(ref.abs().max()), float(d.max())
     assert float((d > 0).float().mean()) < 0.05, float((d > 0).float().mean())
     rms = float(d.double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt())
     assert rms < 1e-3, rms
+
+
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 16, 32), (32, 1, 17, 33), (32, 3, 8, 16), (32, 1, 1, 1), (32, 1, 9, 47), (64, 1, 12, 48), (64, 2, 5, 19),
+                                      (64, 1, 4, 16), (32, 2, 96, 160), (128, 1, 7, 21), (128, 2, 8, 16), (256, 1, 5, 16), (256, 2, 3, 33)])
+def test_matrix_core_unpack3d_forward_matches_the_valu_stencil(C, B, H, W):
+    """conv3d(1 -> 4) + pixel shuffle on the same bf16 input: the fp32-VALU gather kernel (307) against the banded-operand MFMA form (315, C <= 64)
+    and the taps-in-K form with transposing LDS reads (347 = product, C <= 256)"""
+    ref = _unpack_fwd(C, B, H, W, 307, seed=C + W)
+    _close_to_valu(_unpack_fwd(C, B, H, W, 347, seed=C + W), ref)
+    if C <= 64:
+        got = _unpack_fwd(C, B, H, W, 315, seed=C + W)
+        for wgs in (8, 24):                                # the same tiles dealt to 8 / 24 workgroups: bit-identical
+            assert torch.equal(_unpack_fwd(C, B, H, W, 315, seed=C + W, persist=wgs), got), wgs
+        _close_to_valu(got, ref)
