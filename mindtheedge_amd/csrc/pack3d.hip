@@ -866,6 +866,7 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) 
 //
 // unpack backward data, C = 32 / 64: tile = TH x 16 pixels, the four feature planes of the pixel-shuffled gradient staged together
 // ([plane][pixel][8 zero | C depths | 8 zero] bf16, 69 KB: two workgroups per CU); a wave owns 4 (tile row, depth block) units.
+int g_p3_tr_passes = 4;                              // development knob (mte_debug_set(1, 3000 + v), v = 1 / 2 / 4): output passes of unpack3d_fwd_tr_kernel
 int g_p3_persist_wgs = 1024;                         // development knob (mte_debug_set(1, 2000 + v)): workgroups of the persistent matrix-core conv3d kernels
 int g_p3_mfma_data = 47;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs), bit 5 = unpack forward with the spatial taps in K (third form)
 
@@ -1252,12 +1253,13 @@ __global__ __launch_bounds__(256, 4) void unpack3d_fwd_mfma_kernel(P3LArgs a) {
 // it ([pixel][sub-pixel d % 4][channel f C/4 + d / 4]) and leave as 16-byte chunks of whole records.
 __device__ __forceinline__ float own_vgpr(float v) { asm volatile("" : "+v"(v)); return v; }
 
-template <int C, int TH>
+template <int C, int TH, int NH>                       // NH: the output image is built and stored in NH passes (a smaller image: more workgroups per CU)
 __global__ __launch_bounds__(256, 2) void unpack3d_fwd_tr_kernel(P3LArgs a) {
     constexpr int TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW, NB = C / 16, NCH = C / 8;
     constexpr int RS = (C * 2) % 128 == 64 ? C * 2 : C * 2 + 64;   // bytes of a tile pixel: an odd multiple of 64 (the 4 rows of a transposing read fall on different bank groups)
     constexpr int IN_BYTES = NPIX * RS, OPX = 8 * C;               // output image: 4 sub-pixel records of C channels per pixel
-    constexpr int PPW = TH * TW / 4;                               // pixels per wave
+    constexpr int PPW = TH * TW / 4 / NH;                          // pixels per wave and pass
+    static_assert(TH * TW % (4 * NH) == 0, "passes");
     typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     char* tin = smem_;
@@ -1299,8 +1301,11 @@ __global__ __launch_bounds__(256, 2) void unpack3d_fwd_tr_kernel(P3LArgs a) {
     const int tap = 4 * kg + q < 9 ? 4 * kg + q : 0;
     const int tap_off = ((tap / 3) * PW + tap % 3) * RS + 8 * p;
 #pragma unroll 1
+    for (int pass = 0; pass < NH; ++pass) {
+    if (pass) __syncthreads();                                     // the previous pass's image has been read out
+#pragma unroll 1
     for (int pi = 0; pi < PPW; ++pi) {
-        const int pix = wave * PPW + pi, py = pix / TW, px = pix % TW;   // output pixel of the tile; its 3 x 3 window starts at tile pixel (py, px)
+        const int lp = wave * PPW + pi, pix = pass * (TH * TW / NH) + lp, py = pix / TW, px = pix % TW;   // output pixel of the tile (lp: its slot in this pass's image); its 3 x 3 window starts at tile pixel (py, px)
         const char* row = tin + (py * PW + px) * RS + tap_off;
         f32x4_t acc[NB];
 #pragma unroll
@@ -1310,7 +1315,7 @@ __global__ __launch_bounds__(256, 2) void unpack3d_fwd_tr_kernel(P3LArgs a) {
             acc[blk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, x, acc[blk], 0, 0, 0);
         }
         // lane (m = lane % 16, f = kg): acc[blk][kd] = Y[(f, kd)][16 blk + m]
-        char* orow = tout + pix * OPX + (n & 3) * (2 * C) + (kg * (C / 4) + (n >> 2)) * 2;      // sub-pixel m % 4, channel f C/4 + 4 blk + m / 4
+        char* orow = tout + lp * OPX + (n & 3) * (2 * C) + (kg * (C / 4) + (n >> 2)) * 2;      // sub-pixel m % 4, channel f C/4 + 4 blk + m / 4
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
             // Y[(f, 0)] of depth d - 1 and Y[(f, 2)] of depth d + 1: row shifts with zero fill; the block's end lanes take the neighbouring block's
@@ -1336,13 +1341,14 @@ __global__ __launch_bounds__(256, 2) void unpack3d_fwd_tr_kernel(P3LArgs a) {
     }
     __syncthreads();
     // ---- output image -> the four sub-pixel records of every pixel, 16-byte chunks
-    constexpr int OCH = TH * TW * 4 * NCH;
+    constexpr int OCH = TH * TW / NH * 4 * NCH;
     for (int i = tid; i < OCH; i += 256) {
-        const int ch = i % NCH, sp = (i / NCH) & 3, pix = i / (4 * NCH);
+        const int ch = i % NCH, sp = (i / NCH) & 3, lp = i / (4 * NCH), pix = pass * (TH * TW / NH) + lp;
         const int h = h0 + pix / TW, w = w0 + pix % TW;
         if (h < a.H && w < a.W)
-            *(u32x4_t*)(a.dst + (((long)b * 2 * a.H + 2 * h + (sp >> 1)) * (2 * a.W) + 2 * w + (sp & 1)) * a.lddst + 8 * ch) = *(const u32x4_t*)(tout + pix * OPX + sp * (2 * C) + ch * 16);
+            *(u32x4_t*)(a.dst + (((long)b * 2 * a.H + 2 * h + (sp >> 1)) * (2 * a.W) + 2 * w + (sp & 1)) * a.lddst + 8 * ch) = *(const u32x4_t*)(tout + lp * OPX + sp * (2 * C) + ch * 16);
     }
+    }   // passes
 }
 
 // dw3/db3 for UNPACK: x tile staged directly; the 8 feature gradients of an item are gathered from the shuffled dout
@@ -1584,7 +1590,7 @@ int g_p3_mfma = 1;                                  // development knob (mte_deb
 }  // namespace
 
 #ifdef MTE_DEV
-extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 2000) { g_p3_persist_wgs = value - 2000; return MTE_OK; } if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 300) { g_p3_mfma_data = value - 300; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
+extern "C" int mtei_set_pack3d_lds(int value) { if (value >= 3000) { g_p3_tr_passes = value - 3000 == 1 ? 1 : (value - 3000 == 2 ? 2 : 4); return MTE_OK; } if (value >= 2000) { g_p3_persist_wgs = value - 2000; return MTE_OK; } if (value >= 1000) { g_p3_mfma_threads = value - 1000; return MTE_OK; } if (value >= 300) { g_p3_mfma_data = value - 300; return MTE_OK; } if (value >= 200) { g_p3_mfma = value - 200; return MTE_OK; } if (value >= 100) { g_p3_small_tiles = value - 100; return MTE_OK; } g_p3_lds = value; return MTE_OK; }
 #endif
 
 
@@ -1649,11 +1655,24 @@ int mte_unpack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, 
         l.tiles_h = (H + l.TH - 1) / l.TH; l.tiles_w = (W + l.TW - 1) / l.TW; l.ntiles = l.tiles_h * l.tiles_w * B;
         l.x = (const bf16_t*)x; l.ldx = ldx; l.dst = (bf16_t*)out; l.lddst = ldo; l.w3 = w3; l.b3 = b3;
         const int rs = (C * 2) % 128 == 64 ? C * 2 : C * 2 + 64;
-        const size_t lds = (size_t)(l.TH + 2) * 18 * rs + (size_t)l.TH * 16 * 8 * C;
-        if (C == 32) return launch_p3l(unpack3d_fwd_tr_kernel<32, 8>, l, l.ntiles, stream, lds);
-        if (C == 64) return launch_p3l(unpack3d_fwd_tr_kernel<64, 4>, l, l.ntiles, stream, lds);
-        if (C == 128) return launch_p3l(unpack3d_fwd_tr_kernel<128, 2>, l, l.ntiles, stream, lds);
-        return launch_p3l(unpack3d_fwd_tr_kernel<256, 1>, l, l.ntiles, stream, lds);
+        const int nh = g_p3_tr_passes;
+        const size_t lds = (size_t)(l.TH + 2) * 18 * rs + (size_t)l.TH * 16 * 8 * C / nh;
+        if (nh == 1) {
+            if (C == 32) return launch_p3l(unpack3d_fwd_tr_kernel<32, 8, 1>, l, l.ntiles, stream, lds);
+            if (C == 64) return launch_p3l(unpack3d_fwd_tr_kernel<64, 4, 1>, l, l.ntiles, stream, lds);
+            if (C == 128) return launch_p3l(unpack3d_fwd_tr_kernel<128, 2, 1>, l, l.ntiles, stream, lds);
+            return launch_p3l(unpack3d_fwd_tr_kernel<256, 1, 1>, l, l.ntiles, stream, lds);
+        }
+        if (nh == 2) {
+            if (C == 32) return launch_p3l(unpack3d_fwd_tr_kernel<32, 8, 2>, l, l.ntiles, stream, lds);
+            if (C == 64) return launch_p3l(unpack3d_fwd_tr_kernel<64, 4, 2>, l, l.ntiles, stream, lds);
+            if (C == 128) return launch_p3l(unpack3d_fwd_tr_kernel<128, 2, 2>, l, l.ntiles, stream, lds);
+            return launch_p3l(unpack3d_fwd_tr_kernel<256, 1, 2>, l, l.ntiles, stream, lds);
+        }
+        if (C == 32) return launch_p3l(unpack3d_fwd_tr_kernel<32, 8, 4>, l, l.ntiles, stream, lds);
+        if (C == 64) return launch_p3l(unpack3d_fwd_tr_kernel<64, 4, 4>, l, l.ntiles, stream, lds);
+        if (C == 128) return launch_p3l(unpack3d_fwd_tr_kernel<128, 2, 4>, l, l.ntiles, stream, lds);
+        return launch_p3l(unpack3d_fwd_tr_kernel<256, 1, 4>, l, l.ntiles, stream, lds);
     }
     if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && (g_p3_mfma_data & 8) && (C == 32 || C == 64) && ((long)B * H * W - 1) * ldx + C < (1L << 30)) {
         P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C;

@@ -27,6 +27,8 @@ variants = [int(v) for v in sys.argv[1:]] or [300, 347]
 B = 8
 K.set_compute_dtype("bf16")
 lib = K.lib
+for extra in os.environ.get("P3_KNOBS", "").split():             # further values for mte_debug_set(1, .) applied once (e.g. 3001 / 3002 / 3004: output passes of the taps-in-K forward)
+    lib.mte_debug_set(1, int(extra))
 # (op, C, H, W): H, W of the UN-shuffled side (unpack: input of the layer; pack: input of the layer)
 only = os.environ.get("P3_ONLY")
 shapes = [("unpack_bwd_data", 32, 192, 640), ("unpack_bwd_data", 64, 96, 320), ("unpack_bwd_data", 128, 48, 160),
