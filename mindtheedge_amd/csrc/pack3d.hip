@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) 
 // ([plane][pixel][8 zero | C depths | 8 zero] bf16, 69 KB: two workgroups per CU); a wave owns 4 (tile row, depth block) units.
 int g_p3_tr_passes = 4;                              // development knob (mte_debug_set(1, 3000 + v), v = 1 / 2 / 4): output passes of unpack3d_fwd_tr_kernel
 int g_p3_persist_wgs = 1024;                         // development knob (mte_debug_set(1, 2000 + v)): workgroups of the persistent matrix-core conv3d kernels
-int g_p3_mfma_data = 47;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs), bit 5 = unpack forward with the spatial taps in K (third form)
+int g_p3_mfma_data = 111;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs), bit 5 = unpack forward with the spatial taps in K (third form), bit 6 = pack forward in that form
 
 __device__ __forceinline__ bf16x8_t banded_fragment(unsigned t0, unsigned t1, const unsigned sel[4]) {
     u32x4_t r;
@@ -1351,6 +1351,113 @@ __global__ __launch_bounds__(256, 2) void unpack3d_fwd_tr_kernel(P3LArgs a) {
     }   // passes
 }
 
+// pack forward (space-to-depth + conv3d 1 -> 4), the same taps-in-K form for the un-folded pack layers and the border bands (round 4).  The depth
+// axis is long here (D = 4 C = 256 .. 2048), so a workgroup takes a tile of TH x 16 packed pixels AND a slab of DS = 128 depths; the tile is staged
+// with 32 more depths either side (one 8-channel chunk of each sub-pixel: aligned loads; zeros outside [0, D)), interleaved in registers to
+// d = 4 c + s as in stage_packed_tile, and one extra 16-depth block is multiplied on each side of the slab for the edge terms Y[(f,0)][d - 1] /
+// Y[(f,2)][d + 1].  Output: plain feature planes [f D + d] through an LDS image, 16-byte chunks.
+template <int TH, int NH>
+__global__ __launch_bounds__(256, 2) void pack3d_fwd_tr_kernel(P3LArgs a) {
+    constexpr int DS = 128, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW, NBX = DS / 16 + 2, QPP = (DS + 64) / 32;
+    constexpr int RS = 448;                                        // (DS + 64) * 2 = 384 bytes of depths per tile pixel -> an odd multiple of 64
+    constexpr int IN_BYTES = NPIX * RS, OPX = 4 * DS * 2;          // output image: 4 feature planes x DS depths per pixel
+    constexpr int PPW = TH * TW / 4 / NH;
+    static_assert(TH * TW % (4 * NH) == 0, "passes");
+    typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    char* tin = smem_;
+    char* tout = smem_ + IN_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = 4 * a.C, H2 = a.H >> 1, W2 = a.W >> 1, nslabs = D / DS;
+    const int slab = blockIdx.x % nslabs, S0 = slab * DS;
+    int b, h0, w0;
+    tile_coords(a, blockIdx.x / nslabs, b, h0, w0);
+    // ---- item = (tile pixel, 8 channels c0 .. c0 + 7 of the four sub-pixels) = 32 depths 4 c0 .. 4 c0 + 31
+    constexpr int ITEMS = NPIX * QPP, NIT = (ITEMS + 255) / 256;
+    u32x4_t v[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int q = idx % QPP, t = idx / QPP;
+        const int hh = h0 - 1 + t / PW, ww = w0 - 1 + t % PW, c0 = S0 / 4 - 8 + 8 * q;
+        const bool ok = idx < ITEMS && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2 && (unsigned)c0 < (unsigned)a.C;
+        const bf16_t* src = a.x + (((long)b * a.H + 2 * min(max(hh, 0), H2 - 1)) * a.W + 2 * min(max(ww, 0), W2 - 1)) * a.ldx + min(max(c0, 0), a.C - 8);
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const u32x4_t r = *(const u32x4_t*)(src + ((long)(sp >> 1) * a.W + (sp & 1)) * a.ldx);
+            v[it][sp] = u32x4_t{ok ? r[0] : 0u, ok ? r[1] : 0u, ok ? r[2] : 0u, ok ? r[3] : 0u};
+        }
+    }
+    const int n = lane & 15, kg = lane >> 4;
+    s16x4_t whi, wlo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int tap = 4 * kg + e, f = n >> 2, kd = n & 3;
+        const float w = (kd < 3 && tap < 9) ? a.w3[(f * 3 + kd) * 9 + tap] : 0.f;
+        const bf16_t hi = f2bf(w);
+        whi[e] = (short)hi; wlo[e] = (short)f2bf(w - bf2f(hi));
+    }
+    const float bias = a.b3[kg];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < ITEMS) {
+            char* dstp = tin + (idx / QPP) * RS + (idx % QPP) * 64;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {                      // depths 8 qq .. 8 qq + 7 of the item = channels 2 qq, 2 qq + 1 x 4 sub-pixels (see stage_packed_tile)
+                u32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned lo = v[it][2 * (k & 1)][qq], hi = v[it][2 * (k & 1) + 1][qq];
+                    o[k] = (k >> 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+                }
+                *(u32x4_t*)(dstp + 16 * qq) = o;
+            }
+        }
+    }
+    __syncthreads();
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int tap = 4 * kg + q < 9 ? 4 * kg + q : 0;
+    const int tap_off = ((tap / 3) * PW + tap % 3) * RS + 8 * p + 32;          // + 32 bytes: block 0 starts 16 depths below the slab (tile depth S0 - 32 at byte 0)
+#pragma unroll 1
+    for (int pass = 0; pass < NH; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll 1
+    for (int pi = 0; pi < PPW; ++pi) {
+        const int lp = wave * PPW + pi, pix = pass * (TH * TW / NH) + lp, py = pix / TW, px = pix % TW;
+        const char* row = tin + (py * PW + px) * RS + tap_off;
+        f32x4_t acc[NBX];
+#pragma unroll
+        for (int blk = 0; blk < NBX; ++blk) {
+            const s16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(row + 32 * blk));
+            acc[blk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, x, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[blk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, x, acc[blk], 0, 0, 0);
+        }
+        char* orow = tout + lp * OPX + kg * (DS * 2) + n * 2;      // plane f = kg, depth 16 (blk - 1) + m of the slab
+#pragma unroll
+        for (int blk = 1; blk + 1 < NBX; ++blk) {
+            const float y0 = own_vgpr(acc[blk][0]), y2 = own_vgpr(acc[blk][2]), p0 = own_vgpr(acc[blk - 1][0]), n2 = own_vgpr(acc[blk + 1][2]);
+            float t0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y0), 0x111, 0xF, 0xF, true));
+            float t2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y2), 0x101, 0xF, 0xF, true));
+            const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p0), 0x121, 0xF, 0xF, true));
+            const float e2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, n2), 0x12F, 0xF, 0xF, true));
+            t0 = n == 0 ? e0 : t0;
+            t2 = n == 15 ? e2 : t2;
+            const float o = (t0 + acc[blk][1]) + (t2 + bias);
+            *(bf16_t*)(orow + (blk - 1) * 32) = f2bf(o);
+        }
+    }
+    __syncthreads();
+    constexpr int OCH = TH * TW / NH * 4 * (DS / 8);
+    for (int i = tid; i < OCH; i += 256) {
+        const int ch = i % (DS / 8), f = (i / (DS / 8)) & 3, lp = i / (4 * (DS / 8)), pix = pass * (TH * TW / NH) + lp;
+        const int h = h0 + pix / TW, w = w0 + pix % TW;
+        if (h < H2 && w < W2)
+            *(u32x4_t*)(a.dst + (((long)b * H2 + h) * W2 + w) * a.lddst + (long)f * D + S0 + 8 * ch) = *(const u32x4_t*)(tout + lp * OPX + f * (DS * 2) + ch * 16);
+    }
+    }   // passes
+}
+
 // dw3/db3 for UNPACK: x tile staged directly; the 8 feature gradients of an item are gathered from the shuffled dout
 __global__ __launch_bounds__(256) void unpack3d_bwd_weight_lds_kernel(P3LArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -1603,6 +1710,13 @@ int mte_pack3d_fwd(const void* x, long ldx, const float* w3, const float* b3, vo
     if (!x || !w3 || !b3 || !out || !p3_ok(C) || (H & 1) || (W & 1)) return MTE_ERR_ARG;
     P3Args a{}; a.x = x; a.ldx = ldx; a.dst = out; a.lddst = ldo; a.w3 = w3; a.b3 = b3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && (g_p3_mfma_data & 64) && C % 32 == 0) {
+        P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C; l.TH = 2; l.TW = 16;
+        l.tiles_h = (H / 2 + l.TH - 1) / l.TH; l.tiles_w = (W / 2 + l.TW - 1) / l.TW; l.ntiles = l.tiles_h * l.tiles_w * B;
+        l.x = (const bf16_t*)x; l.ldx = ldx; l.dst = (bf16_t*)out; l.lddst = ldo; l.w3 = w3; l.b3 = b3;
+        const long grid = (long)l.ntiles * (4 * C / 128);
+        if (grid < (1L << 30)) return launch_p3l(pack3d_fwd_tr_kernel<2, 4>, l, (int)grid, stream, (size_t)4 * 18 * 448 + (size_t)8 * 1024);
+    }
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
         P3LArgs l = p3l_args(B, H, W, C); l.x = (const bf16_t*)x; l.ldx = ldx; l.dst = (bf16_t*)out; l.lddst = ldo; l.w3 = w3; l.b3 = b3;
         return launch_p3l(pack3d_fwd_lds_kernel, l, l.ntiles, stream);
