@@ -28,10 +28,12 @@ def bench(C, HW, B, has2, iters=30):
     sc = (torch.rand(B, C, device=dev) >= 0.5).float() * 2 if has2 else None
     gm, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     res = {}
+    split = int(os.environ.get("GN_BENCH_SPLIT", "1"))               # experiment: the backward in `split` batch groups, one after the other (reduce + apply of a group: its second read may stay in the Infinity Cache)
+    gs = B // split
     for name in ("fwd", "bwd"):
         stats_keep = []
         for y1, y2, dz in sets:
-            stats_keep.append(K._gn_forward(y1, y2, sc, gm, bt, 1e-5)[1])
+            stats_keep.append([K._gn_forward(y1[g * gs:(g + 1) * gs], None if y2 is None else y2[g * gs:(g + 1) * gs], None if sc is None else sc[g * gs:(g + 1) * gs], gm, bt, 1e-5)[1] for g in range(split)])
         torch.cuda.synchronize()
 
         def body():
@@ -40,7 +42,9 @@ def bench(C, HW, B, has2, iters=30):
                 if name == "fwd":
                     K._gn_forward(y1, y2, sc, gm, bt, 1e-5)
                 else:
-                    K._gn_backward(dz, y1, y2, sc, stats_keep[i % nset], gm, bt, 1e-5, has2, want_dbias=not has2)
+                    for g in range(split):
+                        K._gn_backward(dz[g * gs:(g + 1) * gs], y1[g * gs:(g + 1) * gs], None if y2 is None else y2[g * gs:(g + 1) * gs], None if sc is None else sc[g * gs:(g + 1) * gs],
+                                       stats_keep[i % nset][g], gm, bt, 1e-5, has2, want_dbias=not has2)
         # replayed from a HIP graph: the Python enqueue (~25 us per call) must not be what is measured
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
