@@ -179,6 +179,19 @@ long mte_invdepth_bwd_weight_workspace_elems(int C);
 int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float* dwb, float* records,
                             int B, int H, int W, int C, int dtype, mte_stream_t stream);
 
+/* The inverse-depth channel of the decoder's iconv inputs as a rank-1 term (round 4).  iconv3 / iconv2 / iconv1 see
+ * torch.cat((unpack, skip, nearest_up2(inv_depth)), 1) (reference PackNetSAN01.py:118-143): conv(cat(x, u)) = conv(x) + conv_1(u).  The one-channel part is a
+ * 3x3 stencil of the low-resolution map; the GEMM kernels run on the other C-1 = 64 / 96 / 192 channels and ACCUMULATE onto it.  w: channel C-1 of the OIHW
+ * weight (element (n, tap) at w[n * w_stride + tap]).  _fwd overwrites y [B,2h,2w,N]; _bwd_data: dinv [B,h,w] (+)=; _bwd_weight below. */
+int mte_rank1_conv_fwd(const float* inv, const float* w, long w_stride, void* y, long ldy, int B, int h, int wl, int N, int dtype, mte_stream_t stream);
+int mte_rank1_conv_bwd_data(const void* dy, long lddy, const float* w, long w_stride, float* dinv, int B, int h, int wl, int N, int accumulate, int dtype,
+                            mte_stream_t stream);
+int mte_upsample2_f32(const float* inv, float* out, int B, int h, int wl, mte_stream_t stream);
+/* its gradient with respect to the weight column: dw: element (n, tap) at dw[n * dw_stride + tap] (overwritten); records: mte_rank1_conv_bwd_records_elems(N)
+ * floats of scratch.  Every record of dy is read once; no floating-point atomics (fixed-order sums: bit-reproducible). */
+long mte_rank1_conv_bwd_records_elems(int N);
+int mte_rank1_conv_bwd_weight(const void* dy, long lddy, const float* inv, float* dw, long dw_stride, float* records,
+                              int B, int h, int wl, int N, int dtype, mte_stream_t stream);
 /* ---- layout / wiring helpers (networks/depth/PackNetSAN01.py:92-143 cat + Upsample; models/model_utils.py:98-117 flip) */
 int mte_nchw_to_nhwc(const float* src, void* dst, long ldd, int B, int C, int H, int W, int Cp, int flip_w, int dtype, mte_stream_t stream);
 int mte_upsample_inv_fwd(const float* inv, void* dst, long ldd, int B, int h, int w, int dtype, mte_stream_t stream);

@@ -320,6 +320,208 @@ __global__ void upsample_inv_bwd_kernel(const T* __restrict__ dsrc, long lds_, f
     }
 }
 
+// ---- the inverse-depth channel of the decoder's iconv inputs as a rank-1 term (round 4) -------------------------------------------------------
+// Reference: iconv3 / iconv2 / iconv1 see torch.cat((unpack, skip, nearest_up2(inv_depth)), 1) (PackNetSAN01.py:118-143): 193 / 97 / 65 input
+// channels.  The single extra channel costs the GEMM kernels a whole 32-channel slice (65 -> 72 -> three slices instead of two) and keeps the layers off
+// the kernels that want Cin % 32 = 0.  Convolution is linear in its input channels, so  conv(cat(x, u)) = conv_{C-1}(x) + conv_1(u):  the second term
+// is a 3x3 one-channel stencil of the LOW-resolution map (u = nearest_up2(inv)), written first; the GEMM then accumulates onto it.
+//   forward      r[p][n] = sum_tap w[n][tap] u[p + tap - 1]                              (zero outside the full-resolution image)
+//   data grad    dinv[q'] = sum over the 2x2 pixels q of q':  sum_n sum_tap w[n][tap] dy[q - tap + 1][n]  = sum over the 4x4 window of dy around
+//                q' with the 16 COMBINED weight vectors Wc[window position][n] (36 -> 16 multiply-adds per channel)
+//   weight grad  dw[n][tap] = sum_p dy[p][n] u[p + tap - 1]: mte_invdepth_bwd_weight(x = dy, dlogit = u) with the taps flipped by the caller.
+// w points at channel C-1 of an OIHW tensor: element (n, tap) at w[n * w_stride + tap].
+template <typename T>
+__global__ __launch_bounds__(256) void rank1_conv_fwd_kernel(const float* __restrict__ inv, const float* __restrict__ w, long wstride, T* __restrict__ y, long ldy,
+                                                             int B, int h, int wl, int N) {
+    // thread = (image row Y of one sample, 16-byte chunk of channels), marching along X: its 9 x P weights stay in registers, the 3 x 3 window of the
+    // up-sampled map slides (one new column = three loads of the small low-resolution map per pixel).  Branch-free: rows / columns outside the image are
+    // clamped addresses with the value selected to zero.
+    constexpr int P = Elem<T>::PER16, SEG = 64;                    // a thread marches over SEG pixels of its row
+    const int cpr = N / P, H = 2 * h, W = 2 * wl, nseg = (W + SEG - 1) / SEG;
+    const long items = (long)B * H * nseg * cpr;
+    for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(it % cpr); long t = it / cpr;
+        const int X0 = (int)(t % nseg) * SEG; t /= nseg;
+        const int Y = (int)(t % H); const int b = (int)(t / H);
+        float wr[9][P];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int e = 0; e < P; ++e) wr[tap][e] = w[(long)(cc * P + e) * wstride + tap];
+        const float* r0 = inv + ((long)b * h + (max(Y - 1, 0) >> 1)) * wl;
+        const float* r1 = inv + ((long)b * h + (Y >> 1)) * wl;
+        const float* r2 = inv + ((long)b * h + (min(Y + 1, H - 1) >> 1)) * wl;
+        const bool ok0 = Y > 0, ok2 = Y + 1 < H;
+        float c0[3], c1[3];                                        // window columns X - 1, X (X + 1 is loaded per pixel)
+        {
+            const int xm = max(X0 - 1, 0) >> 1, xc = X0 >> 1;
+            const bool okm = X0 > 0;
+            c0[0] = (ok0 && okm) ? r0[xm] : 0.f; c0[1] = okm ? r1[xm] : 0.f; c0[2] = (ok2 && okm) ? r2[xm] : 0.f;
+            c1[0] = ok0 ? r0[xc] : 0.f; c1[1] = r1[xc]; c1[2] = ok2 ? r2[xc] : 0.f;
+        }
+        T* yr = y + (((long)b * H + Y) * W) * ldy + cc * P;
+        const int X1 = min(X0 + SEG, W);
+        for (int X = X0; X < X1; ++X) {
+            const int xn = min(X + 1, W - 1) >> 1;
+            const bool okn = X + 1 < W;
+            float c2[3] = {(ok0 && okn) ? r0[xn] : 0.f, okn ? r1[xn] : 0.f, (ok2 && okn) ? r2[xn] : 0.f};
+            float v[P];
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) a = fmaf(c0[ky], wr[ky * 3][e], fmaf(c1[ky], wr[ky * 3 + 1][e], fmaf(c2[ky], wr[ky * 3 + 2][e], a)));
+                v[e] = a;
+            }
+            *(u32x4_t*)(yr + (long)X * ldy) = pack16<T>(v);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { c0[k] = c1[k]; c1[k] = c2[k]; }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rank1_conv_bwd_data_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ w, long wstride, float* __restrict__ dinv,
+                                                                  int B, int h, int wl, int N, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];     // [9][N] taps, then [16][N] combined window weights
+    float* wc = sw + 9 * N;
+    for (int i = threadIdx.x; i < 9 * N; i += blockDim.x) sw[i] = w[(long)(i % N) * wstride + i / N];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * N; i += blockDim.x) {
+        const int c = i % N, r = i / N, ry = r >> 2, rx = r & 3;
+        float s = 0.f;
+        for (int qy = 0; qy < 2; ++qy)
+            for (int qx = 0; qx < 2; ++qx) {
+                const int ky = qy + 2 - ry, kx = qx + 2 - rx;       // window pixel (ry, rx) reaches block pixel (qy, qx) through tap (ky, kx)
+                if ((unsigned)ky < 3u && (unsigned)kx < 3u) s += sw[(ky * 3 + kx) * N + c];
+            }
+        wc[i] = s;
+    }
+    __syncthreads();
+    constexpr int P = Elem<T>::PER16;
+    const int cpr = N / P, H = 2 * h, W = 2 * wl;                  // cpr: a power of two <= 32 (launcher), a pixel's chunks sit in consecutive lanes
+    const long n = (long)B * h * wl * cpr;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i0 = blockIdx.x * (long)blockDim.x; i0 < n; i0 += step) {
+        const long i = min(i0 + (long)threadIdx.x, n - 1);         // (tail lanes redo the last item and do not store)
+        const bool live = i0 + threadIdx.x < n;
+        const int cc = (int)(i % cpr); const long pq = i / cpr;
+        const int x = (int)(pq % wl); const long t = pq / wl; const int yl = (int)(t % h); const int b = (int)(t / h);
+        // the 4 x 4 window of dy around the 2 x 2 block: clamped addresses, all 16 loads in flight, values outside the image selected to zero
+        u32x4_t raw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int Y = 2 * yl - 1 + (r >> 2), X = 2 * x - 1 + (r & 3);
+            raw[r] = *(const u32x4_t*)(dy + (((long)b * H + min(max(Y, 0), H - 1)) * W + min(max(X, 0), W - 1)) * lddy + cc * P);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int Y = 2 * yl - 1 + (r >> 2), X = 2 * x - 1 + (r & 3);
+            const bool ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+            float g[P];
+            unpack16<T>(raw[r], g);
+            const float* wr = wc + r * N + cc * P;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < P; ++e) s = fmaf(g[e], wr[e], s);
+            acc += ok ? s : 0.f;
+        }
+        for (int off = 1; off < cpr; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (live && cc == 0) dinv[pq] = accumulate ? dinv[pq] + acc : acc;
+    }
+}
+
+// weight gradient of the rank-1 term: dw[n][tap] = sum_p dy[p][n] u[p + tap - 1], u = nearest_up2(inv) (0 outside the image).  Thread = (low-resolution row,
+// segment of 16 low-resolution pixels, channel chunk): per item the four dy records of its 2 x 2 block (every record of dy is read exactly once) against the
+// 3 x 3 window of the low-resolution map sliding in registers; 9 x P register accumulators.  A workgroup leaves one record of N x 9 partial sums (fixed-order
+// shuffles + LDS tree); rank1_wgrad_reduce_kernel adds the records in a fixed order: bit-reproducible, no floating-point atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void rank1_conv_bwd_weight_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ inv, float* __restrict__ records,
+                                                                    int B, int h, int wl, int N) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];   // [4][N * 9] per-wave partial sums
+    constexpr int P = Elem<T>::PER16, SEG = 16;
+    const int cpr = N / P, W = 2 * wl, nseg = (wl + SEG - 1) / SEG;
+    const long items = (long)B * h * nseg * cpr;
+    float dacc[9][P];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int e = 0; e < P; ++e) dacc[tp][e] = 0.f;
+    const int cc = threadIdx.x % cpr;                              // (256 and the grid stride are multiples of cpr: a thread keeps its chunk)
+    for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        long t = it / cpr;
+        const int x0 = (int)(t % nseg) * SEG; t /= nseg;
+        const int yl = (int)(t % h); const int b = (int)(t / h);
+        const T* base = dy + (((long)b * 2 * h + 2 * yl) * W) * lddy + cc * P;
+        const float* ir[3]; bool iok[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int yy = yl - 1 + r; iok[r] = (unsigned)yy < (unsigned)h; ir[r] = inv + ((long)b * h + min(max(yy, 0), h - 1)) * wl; }
+        float uw[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int xx = x0 - 1 + k; const bool ok = (unsigned)xx < (unsigned)wl; const int xc = min(max(xx, 0), wl - 1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) uw[r][k] = (ok && iok[r]) ? ir[r][xc] : 0.f;
+        }
+        const int x1 = min(x0 + SEG, wl);
+        for (int x = x0; x < x1; ++x) {
+            u32x4_t raw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw[q] = *(const u32x4_t*)(base + ((long)(q >> 1) * W + 2 * x + (q & 1)) * lddy);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float g[P];
+                unpack16<T>(raw[q], g);
+                const int qy = q >> 1, qx = q & 1;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        // u at full-resolution (2 yl + qy + ky - 1, 2 x + qx + kx - 1) = map (yl + ((qy + ky - 1) >> 1), x + ((qx + kx - 1) >> 1))
+                        const float uu = uw[(qy + ky + 1) >> 1][(qx + kx + 1) >> 1];
+#pragma unroll
+                        for (int e = 0; e < P; ++e) dacc[ky * 3 + kx][e] = fmaf(g[e], uu, dacc[ky * 3 + kx][e]);
+                    }
+            }
+            if (x + 1 < x1) {
+                const int xx = x + 2; const bool ok = xx < wl; const int xc = min(xx, wl - 1);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { uw[r][0] = uw[r][1]; uw[r][1] = uw[r][2]; uw[r][2] = (ok && iok[r]) ? ir[r][xc] : 0.f; }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int e = 0; e < P; ++e) {
+            float v = dacc[tp][e];
+            for (int off = cpr; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (lane < cpr) sred[wave * (N * 9) + (lane * P + e) * 9 + tp] = v;       // lane = chunk (lane % cpr = cc)
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * 9; i += blockDim.x)
+        records[(long)blockIdx.x * (N * 9) + i] = (sred[i] + sred[N * 9 + i]) + (sred[2 * N * 9 + i] + sred[3 * N * 9 + i]);
+}
+// dw[n * dst_stride + tap] = sum of the workgroup records: one wave per output, lane l adds records l, l + 64, ... in order, then a fixed shuffle tree
+__global__ __launch_bounds__(256) void rank1_wgrad_reduce_kernel(const float* __restrict__ records, int nrec, int N, float* __restrict__ dst, long dst_stride) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N * 9) return;
+    float s = 0.f;
+    for (int r = lane; r < nrec; r += 64) s += records[(long)r * (N * 9) + i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) dst[(long)(i / 9) * dst_stride + i % 9] = s;
+}
+
+__global__ void upsample2_f32_kernel(const float* __restrict__ inv, float* __restrict__ out, int B, int h, int w) {
+    const long n = (long)B * 4 * h * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % (2 * w)); const long t = i / (2 * w); const int Y = (int)(t % (2 * h)); const int b = (int)(t / (2 * h));
+        out[i] = inv[((long)b * h + (Y >> 1)) * w + (X >> 1)];
+    }
+}
+
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long npix, int C) {
     constexpr int P = Elem<T>::PER16;
@@ -537,6 +739,54 @@ int mte_upsample_inv_bwd(const void* dsrc, long lds_, float* dinv, int B, int h,
     const int grid = stream_grid((long)B * h * w);
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(upsample_inv_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dsrc, lds_, dinv, B, h, w, accumulate);
     else hipLaunchKernelGGL(upsample_inv_bwd_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)dsrc, lds_, dinv, B, h, w, accumulate);
+    return mte_check_launch();
+}
+
+// conv3x3 of the nearest-up-sampled one-channel map `inv` [B,h,w] with channel C-1 of an OIHW weight (element (n, tap) at w[n * w_stride + tap]) ->
+// y [B,2h,2w,N] (overwritten; the caller's GEMM then accumulates the other channels' convolution onto it).  N: a multiple of 32, at most 256.
+int mte_rank1_conv_fwd(const float* inv, const float* w, long w_stride, void* y, long ldy, int B, int h, int wl, int N, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!inv || !w || !y || N % 32 != 0 || N > 256 || B < 1 || h < 1 || wl < 1) return MTE_ERR_ARG;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    const int grid = stream_grid((long)B * 2 * h * ((2 * wl + 63) / 64) * (N / per16));      // one thread per (image row, 64-pixel segment, channel chunk)
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(rank1_conv_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, inv, w, w_stride, (bf16_t*)y, ldy, B, h, wl, N);
+    else hipLaunchKernelGGL(rank1_conv_fwd_kernel<float>, dim3(grid), dim3(256), 0, stream, inv, w, w_stride, (float*)y, ldy, B, h, wl, N);
+    return mte_check_launch();
+}
+// its gradient with respect to `inv`: dinv [B,h,w] (+)= ... of dy [B,2h,2w,N].  N: 32, 64 or 128 (a pixel's 16-byte chunks must fit one wave)
+int mte_rank1_conv_bwd_data(const void* dy, long lddy, const float* w, long w_stride, float* dinv, int B, int h, int wl, int N, int accumulate, int dtype,
+                            hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!dy || !w || !dinv || (N != 32 && N != 64 && N != 128) || B < 1 || h < 1 || wl < 1) return MTE_ERR_ARG;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    const int grid = stream_grid((long)B * h * wl * (N / per16));
+    const size_t lds = sizeof(float) * 25 * N;
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(rank1_conv_bwd_data_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, (const bf16_t*)dy, lddy, w, w_stride, dinv, B, h, wl, N, accumulate);
+    else hipLaunchKernelGGL(rank1_conv_bwd_data_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)dy, lddy, w, w_stride, dinv, B, h, wl, N, accumulate);
+    return mte_check_launch();
+}
+// ... and with respect to the weight column: dw (element (n, tap) at dw[n * dw_stride + tap], overwritten) = sum_p dy[p][n] up2(inv)[p + tap - 1].
+// records: mte_rank1_conv_bwd_records_elems(N) floats of scratch (one N x 9 record per workgroup, summed in a fixed order: bit-reproducible).
+constexpr int RANK1_BWD_WGS = 1024;
+long mte_rank1_conv_bwd_records_elems(int N) { return (long)RANK1_BWD_WGS * N * 9; }
+int mte_rank1_conv_bwd_weight(const void* dy, long lddy, const float* inv, float* dw, long dw_stride, float* records,
+                              int B, int h, int wl, int N, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!dy || !inv || !dw || !records || (N != 32 && N != 64 && N != 128) || B < 1 || h < 1 || wl < 1) return MTE_ERR_ARG;
+    const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
+    const long items = (long)B * h * ((wl + 15) / 16) * (N / per16);
+    long g = (items + 255) / 256; if (g > RANK1_BWD_WGS) g = RANK1_BWD_WGS; if (g < 1) g = 1;
+    const size_t lds = sizeof(float) * 4 * N * 9;
+    if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(rank1_conv_bwd_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, (const bf16_t*)dy, lddy, inv, records, B, h, wl, N);
+    else hipLaunchKernelGGL(rank1_conv_bwd_weight_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, (const float*)dy, lddy, inv, records, B, h, wl, N);
+    hipLaunchKernelGGL(rank1_wgrad_reduce_kernel, dim3((N * 9 + 3) / 4), dim3(256), 0, stream, records, (int)g, N, dw, dw_stride);
+    return mte_check_launch();
+}
+// out [B,2h,2w] = nearest_up2(inv [B,h,w]), fp32 (the dense map the rank-1 weight gradient multiplies dy with)
+int mte_upsample2_f32(const float* inv, float* out, int B, int h, int wl, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!inv || !out || B < 1 || h < 1 || wl < 1) return MTE_ERR_ARG;
+    hipLaunchKernelGGL(upsample2_f32_kernel, dim3(stream_grid((long)B * 4 * h * wl)), dim3(256), 0, stream, inv, out, B, h, wl);
     return mte_check_launch();
 }
 

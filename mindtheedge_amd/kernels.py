@@ -539,7 +539,10 @@ def _splitk_workspace(M, N, device):
 
 _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0.30,
         "no_fork_accumulate": bool(os.environ.get("MTE_NO_FORK_ACCUM")),
-        "patch_wgrad_slabs": not os.environ.get("MTE_PATCH_WGRAD_ATOMICS")}
+        "patch_wgrad_slabs": not os.environ.get("MTE_PATCH_WGRAD_ATOMICS"),
+        # decoder iconv3 / iconv2 / iconv1: the up-sampled inverse-depth input channel as a rank-1 term beside a GEMM over the other 192 / 96 / 64
+        # channels (ConvGnEluInvFn) instead of a 65th channel that costs the GEMM kernels a whole 32-channel slice
+        "split_inv_channel": os.environ.get("MTE_SPLIT_INV", "1") == "1"}
 
 
 def use_pack_folding(flag):
@@ -915,6 +918,89 @@ class ConvGnEluFn(torch.autograd.Function):
                                                 dgamma=gg, dbeta=gb, dbias=gbias)
         dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw)
         return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None, None
+
+
+def _main_weight(pack, w, cm):
+    """contiguous copy of w[:, :cm] (the channels the GEMM kernels see), refreshed in place when the parameter changed -- the weight packs key on
+    this tensor's version, so a refresh re-packs and nothing else does"""
+    key = (w.data_ptr(), w._version, weights_epoch())
+    wm = getattr(pack, "_main_w", None)
+    if wm is None or tuple(wm.shape) != (w.shape[0], cm, w.shape[2], w.shape[3]) or wm.device != w.device:
+        wm = pack._main_w = torch.empty((w.shape[0], cm, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device)
+        pack._main_key = None
+    if pack._main_key != key:
+        wm.copy_(w.detach()[:, :cm])
+        pack._main_key = key
+    return wm
+
+
+class ConvGnEluInvFn(torch.autograd.Function):
+    """ELU(GroupNorm16(conv_3(zero_pad(cat(x, nearest_up2(inv)))) + b)) -- the decoder's iconv3 / iconv2 / iconv1 (reference PackNetSAN01.py:118-143 +
+    Conv2D.forward) with the inverse-depth channel as a rank-1 term: mte_rank1_conv_fwd writes conv_1(up2(inv)) into y, the GEMM kernels accumulate
+    the convolution of the other C - 1 channels (x) onto it.  inv: [B,1,H/2,W/2] fp32 (the InvDepth head's output)."""
+
+    @staticmethod
+    def forward(ctx, x, inv, w, b, gamma, beta, pack, out=None):
+        ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
+        cout, cin, kh, kw = w.shape
+        cm = cin - 1
+        B, Cp, H, W = x.shape
+        if (kh, kw) != (3, 3) or Cp != cm or tuple(inv.shape) != (B, 1, H // 2, W // 2):
+            raise MteError("rank-1 inverse-depth term: expected a 3x3 layer over %d + 1 channels and a [B,1,H/2,W/2] map, got %s / %s / %s"
+                           % (Cp, tuple(w.shape), tuple(x.shape), tuple(inv.shape)))
+        wm = _main_weight(pack, w, cm)
+        wf, _ = pack.get(wm, x.dtype, bool(ctx.needs_input_grad[0]))
+        invc = inv.detach().contiguous().float()
+        y = new_act(B, cout, H, W, x.dtype, x.device)
+        yp, ldy = _pl(y)
+        lib.mte_rank1_conv_fwd(invc.data_ptr(), w.detach().data_ptr() + 4 * cm * 9, cin * 9, yp, ldy, B, H // 2, W // 2, cout, _dt(y), _stream())
+        conv_forward(x, wf, b, cout, kh, kw, out=y, pack=pack, w=wm, accumulate=True)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out))
+        ctx.save_for_backward(x, invc, w, wm, y, stats, gamma, beta)
+        ctx.pack = pack
+        ctx.bias = b
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, invc, w, wm, y, stats, gamma, beta = ctx.saved_tensors
+        b = ctx.bias
+        cout, cin, kh, kw = w.shape
+        cm = cin - 1
+        B, Cp, H, W = x.shape
+        gg, sg = _grad_dst(gamma, zero=True)
+        gb, sb = _grad_dst(beta, zero=True)
+        gbias, sbias = _grad_dst(b, zero=True)
+        gw, sw = _grad_dst(w)
+        dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
+                                                dgamma=gg, dbeta=gb, dbias=gbias)
+        dyp, lddy = _pl(dy)
+
+        # channel C-1 (the map): its data gradient on the main stream (it feeds the head's backward) ...
+        dinv = torch.empty((B, 1, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        wl = w.detach()
+        lib.mte_rank1_conv_bwd_data(dyp, lddy, wl.data_ptr() + 4 * cm * 9, cin * 9, dinv.data_ptr(), B, H // 2, W // 2, cout, 0, _dt(dy), _stream())
+
+        def weight_gradients():
+            # ... channels 0 .. C-2: the GEMM weight gradient over x; channel C-1: one pass over dy against the map, straight into column C-1 of gw
+            dwm, _ = _conv_wgrad(x, dy, wm, False, None, None)
+            gw[:, :cm].copy_(dwm)
+            rec = torch.empty((int(lib.mte_rank1_conv_bwd_records_elems(cout)),), dtype=torch.float32, device=x.device)
+            lib.mte_rank1_conv_bwd_weight(dyp, lddy, invc.data_ptr(), gw.data_ptr() + 4 * cm * 9, cin * 9, rec.data_ptr(), B, H // 2, W // 2, cout, _dt(dy), _stream())
+
+        if sw and _side["enabled"]:
+            if _side["keep_bytes"] > _SIDE_KEEP_LIMIT:
+                join_side_stream()
+            with torch.cuda.stream(_side_stream_for(x, dy, invc)):
+                weight_gradients()
+        else:
+            weight_gradients()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_backward(x, dy, wm, ctx.pack, True, need_dw=False, need_dbias=False, fork_slot=ctx.fork_slot)[0]
+        if not ctx.needs_input_grad[1]:
+            dinv = None
+        return dx, dinv, _grad_ret(w, gw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None, None
 
 
 class ConvFn(torch.autograd.Function):

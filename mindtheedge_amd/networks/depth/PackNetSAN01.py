@@ -80,10 +80,22 @@ class Decoder(nn.Module):
             cu = unp.conv.conv_base.out_channels                       # unpack output channels (out * r^2 / d == out)
             with_inv = lvl < 3
             cs = ico.conv_base.in_channels - cu - (1 if with_inv else 0)
-            buf = K.new_concat_buffer(B, [cu, cs], with_inv, H >> lvl, W >> lvl, device=device)
+            buf = K.new_concat_buffer(B, [cu, cs], with_inv and not self._split_inv(cu + cs), H >> lvl, W >> lvl, device=device)
             bufs.append(buf)
             skip_dst.append(K.channel_slice(buf, cu, cu + cs))
         return bufs, skip_dst
+
+    @staticmethod
+    def _split_inv(c_main):
+        """the up-sampled inverse-depth input of iconv3 / iconv2 / iconv1 as a rank-1 term beside the GEMM (kernels.ConvGnEluInvFn) instead of a
+        65th / 97th / 193rd channel of the concat buffer: when enabled and the other channels are a multiple of 32"""
+        return K._cfg["split_inv_channel"] and c_main % 32 == 0 and K.compute_dtype() in (torch.bfloat16, torch.float32)
+
+    def _iconv(self, layer, inv, buf, up, skip):
+        """iconv(cat(unpack output, skip[, nearest_up2(inv)]))"""
+        if inv is not None and self._split_inv(up.shape[1] + skip.shape[1]) and (buf is None or buf.shape[1] == up.shape[1] + skip.shape[1]):
+            return layer(K.ConcatFn.apply(None, buf, up, skip), inv=inv)
+        return layer(K.ConcatFn.apply(inv, buf, up, skip))
 
     def forward(self, x5p, skips, bufs=None):
         skip1, skip2, skip3, skip4, skip5 = skips
@@ -95,11 +107,11 @@ class Decoder(nn.Module):
         iconv5 = self.iconv5(K.ConcatFn.apply(None, b5, self.unpack5(x5p, out=up_dst(b5, self.unpack5)), skip5))
         iconv4, f4 = K.fork(self.iconv4(K.ConcatFn.apply(None, b4, self.unpack4(iconv5, out=up_dst(b4, self.unpack4)), skip4)))
         inv_depth4 = self.disp4_layer(f4)
-        iconv3, f3 = K.fork(self.iconv3(K.ConcatFn.apply(inv_depth4, b3, self.unpack3(iconv4, out=up_dst(b3, self.unpack3)), skip3)))
+        iconv3, f3 = K.fork(self._iconv(self.iconv3, inv_depth4, b3, self.unpack3(iconv4, out=up_dst(b3, self.unpack3)), skip3))
         inv_depth3 = self.disp3_layer(f3)
-        iconv2, f2 = K.fork(self.iconv2(K.ConcatFn.apply(inv_depth3, b2, self.unpack2(iconv3, out=up_dst(b2, self.unpack2)), skip2)))
+        iconv2, f2 = K.fork(self._iconv(self.iconv2, inv_depth3, b2, self.unpack2(iconv3, out=up_dst(b2, self.unpack2)), skip2))
         inv_depth2 = self.disp2_layer(f2)
-        iconv1 = self.iconv1(K.ConcatFn.apply(inv_depth2, b1, self.unpack1(iconv2, out=up_dst(b1, self.unpack1)), skip1))
+        iconv1 = self._iconv(self.iconv1, inv_depth2, b1, self.unpack1(iconv2, out=up_dst(b1, self.unpack1)), skip1)
         inv_depth1 = self.disp1_layer(iconv1)
         return [inv_depth1, inv_depth2, inv_depth3, inv_depth4]
 

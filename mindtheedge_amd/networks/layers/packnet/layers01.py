@@ -75,8 +75,13 @@ class Conv2D(nn.Module):
         self.conv_base = _ConvParams(in_channels, out_channels, kernel_size)
         self.normalize = _GroupNormParams(out_channels)
 
-    def forward(self, x, out=None):
-        """`out`: optional destination (e.g. K.channel_slice of a decoder concat buffer) for the result"""
+    def forward(self, x, out=None, inv=None):
+        """`out`: optional destination (e.g. K.channel_slice of a decoder concat buffer) for the result.  `inv`: the LAST input channel given as a
+        half-resolution one-channel map to be nearest-up-sampled (decoder iconv layers): x then holds the other in_channels - 1 channels"""
+        if inv is not None:
+            x = _enter(x, self.conv_base.in_channels - 1)
+            return K.ConvGnEluInvFn.apply(x, inv, self.conv_base.weight, self.conv_base.bias, self.normalize.weight, self.normalize.bias,
+                                          self.conv_base.pack, out)
         x = _enter(x, self.conv_base.in_channels)
         return K.ConvGnEluFn.apply(x, self.conv_base.weight, self.conv_base.bias, self.normalize.weight, self.normalize.bias,
                                    self.conv_base.pack, out)
