@@ -383,6 +383,8 @@ __global__ __launch_bounds__(256) void rank1_conv_fwd_kernel(const float* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void rank1_conv_bwd_data_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ w, long wstride, float* __restrict__ dinv,
                                                                   int B, int h, int wl, int N, int accumulate) {
+    // thread = (low-resolution row, segment of 16 low-resolution pixels, channel chunk), marching along x: the 4 x 4 window of dy records around the item's
+    // 2 x 2 block slides in registers (packed; two new columns = 8 loads per item instead of 16); clamped addresses, values outside the image selected to zero
     extern __shared__ __attribute__((aligned(16))) float sw[];     // [9][N] taps, then [16][N] combined window weights
     float* wc = sw + 9 * N;
     for (int i = threadIdx.x; i < 9 * N; i += blockDim.x) sw[i] = w[(long)(i % N) * wstride + i / N];
@@ -398,37 +400,58 @@ __global__ __launch_bounds__(256) void rank1_conv_bwd_data_kernel(const T* __res
         wc[i] = s;
     }
     __syncthreads();
-    constexpr int P = Elem<T>::PER16;
-    const int cpr = N / P, H = 2 * h, W = 2 * wl;                  // cpr: a power of two <= 32 (launcher), a pixel's chunks sit in consecutive lanes
-    const long n = (long)B * h * wl * cpr;
+    constexpr int P = Elem<T>::PER16, SEG = 16;
+    const int cpr = N / P, H = 2 * h, W = 2 * wl, nseg = (wl + SEG - 1) / SEG;   // cpr: a power of two <= 32 (launcher), a pixel's chunks sit in consecutive lanes
+    const long items = (long)B * h * nseg * cpr;
+    const int cc = threadIdx.x % cpr;
     const long step = (long)gridDim.x * blockDim.x;
-    for (long i0 = blockIdx.x * (long)blockDim.x; i0 < n; i0 += step) {
-        const long i = min(i0 + (long)threadIdx.x, n - 1);         // (tail lanes redo the last item and do not store)
-        const bool live = i0 + threadIdx.x < n;
-        const int cc = (int)(i % cpr); const long pq = i / cpr;
-        const int x = (int)(pq % wl); const long t = pq / wl; const int yl = (int)(t % h); const int b = (int)(t / h);
-        // the 4 x 4 window of dy around the 2 x 2 block: clamped addresses, all 16 loads in flight, values outside the image selected to zero
-        u32x4_t raw[16];
+    for (long i0 = blockIdx.x * (long)blockDim.x; i0 < items; i0 += step) {
+        const long it = min(i0 + (long)threadIdx.x, items - 1);   // (tail lanes redo the last item and do not store: the chunk lanes of a pixel reduce together)
+        const bool live = i0 + threadIdx.x < items;
+        long t = it / cpr;
+        const int x0 = (int)(t % nseg) * SEG; t /= nseg;
+        const int yl = (int)(t % h); const int b = (int)(t / h);
+        const T* base = dy + (long)b * H * W * lddy + cc * P;
+        long rowoff[4]; bool Yok[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int Y = 2 * yl - 1 + (r >> 2), X = 2 * x - 1 + (r & 3);
-            raw[r] = *(const u32x4_t*)(dy + (((long)b * H + min(max(Y, 0), H - 1)) * W + min(max(X, 0), W - 1)) * lddy + cc * P);
+        for (int r = 0; r < 4; ++r) { const int Y = 2 * yl - 1 + r; Yok[r] = (unsigned)Y < (unsigned)H; rowoff[r] = (long)min(max(Y, 0), H - 1) * W; }
+        u32x4_t win[4][4];
+        auto load_col = [&](int X, int k) __attribute__((always_inline)) {
+            const int Xc = min(max(X, 0), W - 1);
+            const bool ok = (unsigned)X < (unsigned)W;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const u32x4_t v = *(const u32x4_t*)(base + (rowoff[r] + Xc) * lddy);
+                const bool kk = ok && Yok[r];
+                win[r][k] = u32x4_t{kk ? v[0] : 0u, kk ? v[1] : 0u, kk ? v[2] : 0u, kk ? v[3] : 0u};
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_col(2 * x0 - 1 + k, k);
+        const int x1 = min(x0 + SEG, wl);
+        for (int x = x0; x < x1; ++x) {
+            float acc = 0.f;
+            const int woff = cc * P;                                // (the compiler hoists these 128 combined weights into registers: 253 VGPRs, one wave per SIMD -- and faster than re-reading them: 106 vs 129 us)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float g[P];
+                    unpack16<T>(win[r][k], g);
+                    const float* wr = wc + (r * 4 + k) * N + woff;
+#pragma unroll
+                    for (int e = 0; e < P; ++e) acc = fmaf(g[e], wr[e], acc);
+                }
+            for (int off = 1; off < cpr; off <<= 1) acc += __shfl_xor(acc, off, 64);
+            const long pq = ((long)b * h + yl) * wl + x;
+            if (live && cc == 0) dinv[pq] = accumulate ? dinv[pq] + acc : acc;
+            if (x + 1 < x1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { win[r][0] = win[r][2]; win[r][1] = win[r][3]; }
+                load_col(2 * x + 3, 2);
+                load_col(2 * x + 4, 3);
+            }
         }
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int Y = 2 * yl - 1 + (r >> 2), X = 2 * x - 1 + (r & 3);
-            const bool ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
-            float g[P];
-            unpack16<T>(raw[r], g);
-            const float* wr = wc + r * N + cc * P;
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < P; ++e) s = fmaf(g[e], wr[e], s);
-            acc += ok ? s : 0.f;
-        }
-        for (int off = 1; off < cpr; off <<= 1) acc += __shfl_xor(acc, off, 64);
-        if (live && cc == 0) dinv[pq] = accumulate ? dinv[pq] + acc : acc;
     }
 }
 
@@ -759,7 +782,7 @@ int mte_rank1_conv_bwd_data(const void* dy, long lddy, const float* w, long w_st
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dy || !w || !dinv || (N != 32 && N != 64 && N != 128) || B < 1 || h < 1 || wl < 1) return MTE_ERR_ARG;
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
-    const int grid = stream_grid((long)B * h * wl * (N / per16));
+    const int grid = stream_grid((long)B * h * ((wl + 15) / 16) * (N / per16));     // one thread per (low-resolution row, 16-pixel segment, channel chunk)
     const size_t lds = sizeof(float) * 25 * N;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(rank1_conv_bwd_data_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, (const bf16_t*)dy, lddy, w, w_stride, dinv, B, h, wl, N, accumulate);
     else hipLaunchKernelGGL(rank1_conv_bwd_data_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)dy, lddy, w, w_stride, dinv, B, h, wl, N, accumulate);
