@@ -665,7 +665,7 @@ launched:
 }
 
 int g_igemm_big_min_tiles = 224;
-int g_igemm8 = 3;                                    // development knob (mte_debug_set(23, v)): bit 0 = 8-phase 256 x 256 kernel, bit 1 = its 256 x 128 form
+int g_igemm8 = 19;                                   // development knob (mte_debug_set(23, v)): bit 0 = 8-phase 256 x 256 kernel, bit 1 = its 256 x 128 form, bit 2 every eligible launch, bit 3 force the tile-walking form, bit 4 never pick it by itself (round 4: on launches of more than one wave of tiles it measured 15-20 % SLOWER than one WG per tile -- profiles/r04_igemm8_ab_v1.txt)
 int g_igemm8_min_tiles = 200;                        // development knob (mte_debug_set(24, v))
 int g_igemm_pp = 1;                                  // development knob (mte_debug_set(21, v)): 0 = the 16-wave one-barrier loop on the 256 x 256 tile
 int g_igemm_big = 3;                                 // development knob (mte_debug_set(6, v)): 0 128x128 only, 1 + 256x128, 2 + 256x256, 3 + 192x96
@@ -715,7 +715,8 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
             if (bn) {
                 ConvArgs b = a;
                 b.splits = splits;
-                // several rounds of tiles: the tile-walking form (the stream of half-tiles runs on across tiles: +1-2 % on the 480- / 960-tile launches)
+                // several rounds of tiles: the tile-walking form keeps the stream of half-tiles running across tiles.  Off by default since round 4 (bit 4 of the knob):
+                // +1-2 % in the round-3 step A/B, but 15-20 % slower per launch in isolation on the 480- / 960-tile shapes; tests still force it (knob 15)
                 const int persistent = ((g_igemm8 >> 3) & 1) | (bn == 256 && splits == 1 && t256 > 256 && !(g_igemm8 & 16) ? 1 : 0);
                 const int rc = igemm8_launch(b, bn, persistent, st);
                 if (rc == MTE_OK) {

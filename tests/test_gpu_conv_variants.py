@@ -129,7 +129,7 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape, devlib):
             return y.float().cpu(), None if dx is None else dx.float().cpu()
         finally:
             K._splitk_workspace = orig
-            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
+            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
             K.lib.mte_debug_set(7, 224)
 
     K.use_patch_kernels(False)
@@ -176,7 +176,7 @@ def test_igemm_pingpong_loop_matches_one_barrier_loop(shape, devlib):
     finally:
         K._splitk_workspace = orig
         K.use_patch_kernels(True)
-        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
+        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
         K.lib.mte_debug_set(7, 224)
         K.lib.mte_debug_set(21, 1)
 
@@ -203,7 +203,7 @@ def test_big_tile_split_k_matches_small_tiles(shape, devlib):
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
         assert float(outs[0].abs().mean()) > 0.1                 # (not trivially zero)
     finally:
-        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
+        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
         K.use_patch_kernels(True)
 
 
@@ -231,7 +231,7 @@ def test_igemm_192x96_tiles_match_128x128_tiles(shape, devlib):
             return y.float().cpu(), acc.float().cpu()
         finally:
             K._splitk_workspace = orig
-            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 3)
+            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
             K.lib.mte_debug_set(7, 224)
 
     K.use_patch_kernels(False)
@@ -297,5 +297,5 @@ def test_eight_phase_igemm_equals_the_128x128_tile_bit_for_bit(devlib, shape, pe
         assert float((d - ref.float().abs() * 2.0 ** -7).max()) <= 1e-3
     finally:
         K._splitk_workspace = saved
-        devlib.mte_debug_set(23, 3); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
+        devlib.mte_debug_set(23, 19); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
         K.use_patch_kernels(True)

@@ -54,6 +54,6 @@ for cin, cout, k, B, H, W in shapes:
                     print("   first mismatch at rep %d: %d elements differ, max |d| %.3e" % (r, int((d > 0).sum()), float(d.max())))
         bad += miss
         print("%4d -> %-4d k%d B%d %dx%-4d %-20s %d / %d repetitions differ" % (cin, cout, k, B, H, W, name, miss, reps))
-K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(7, 224); K.lib.mte_debug_set(21, 1); K.lib.mte_debug_set(23, 3); K.lib.mte_debug_set(24, 200)
+K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(7, 224); K.lib.mte_debug_set(21, 1); K.lib.mte_debug_set(23, 19); K.lib.mte_debug_set(24, 200)
 print("MISMATCHES:", bad)
 sys.exit(1 if bad else 0)
