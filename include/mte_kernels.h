@@ -187,6 +187,12 @@ int mte_rank1_conv_fwd(const float* inv, const float* w, long w_stride, void* y,
 int mte_rank1_conv_bwd_data(const void* dy, long lddy, const float* w, long w_stride, float* dinv, int B, int h, int wl, int N, int accumulate, int dtype,
                             mte_stream_t stream);
 int mte_upsample2_f32(const float* inv, float* out, int B, int h, int wl, mte_stream_t stream);
+/* _fwd fused into the LDS-patch 3x3 forward (bf16, N <= 64): y = conv_3(x, wpatch) + bias + conv_1(nearest_up2(inv), w1) in ONE launch -- the store loop of a
+ * tile adds the term from two small LDS tables (the map under the tile + halo, the 9 x N weights), so y is neither written first nor read back.  inv [B,H/2,W/2];
+ * w1 / w1_stride as w / w_stride above.  _ok(...) = 1 when this form exists for the shape (otherwise: mte_rank1_conv_fwd, then the conv with accumulate = 1). */
+int mte_conv2d_patch_fwd_rank1_ok(const float* bias, long ldx, int B, int H, int W, int Cin_p, int N);
+int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
+                               const float* inv, const float* w1, long w1_stride, mte_stream_t stream);
 /* its gradient with respect to the weight column: dw: element (n, tap) at dw[n * dw_stride + tap] (overwritten); records: mte_rank1_conv_bwd_records_elems(N)
  * floats of scratch.  Every record of dy is read once; no floating-point atomics (fixed-order sums: bit-reproducible). */
 long mte_rank1_conv_bwd_records_elems(int N);

@@ -49,6 +49,9 @@ struct PatchArgs {
     bf16_t* y; long ldy;
     int B, H, W, Cin_p, N;
     int accum;                                     // 1: y += conv (fp32 sum, rounded once)
+    // rank-1 term (3x3 second form only, mte_conv2d_patch_fwd_rank1): y += conv_1(nearest_up2(r1_inv)) with one more input channel's weights
+    const float* r1_inv;                           // [B][H/2][W/2] fp32, or nullptr
+    const float* r1_w; long r1_ws;                 // element (n, tap) at r1_w[n * r1_ws + tap]
 };
 
 // ---- forward / dgrad --------------------------------------------------------------------------------------
@@ -216,9 +219,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
 //     the tile is staged with 16 ds_write_b64 per thread instead of 64 two-byte writes that all fell on two LDS banks.
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
-template <int K, int NT, bool TALL>
+template <int K, int NT, bool TALL, bool R1 = false, bool ACC = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
+    static_assert(!R1 || K == 3, "the rank-1 term is a 3x3 stencil");
     constexpr int TH = TALL ? 16 : 8;
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int PCH = PH * PW * 4;                               // 16-B chunks of one patch slice
@@ -283,6 +287,64 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
+    // ---- rank-1 term (R1): one more input channel given as a LOW-resolution map (the decoder's up-sampled inverse depth), as ONE 16-deep MFMA step that
+    // initialises the accumulators.  The 3x3 window of the up-sampled map around a pixel covers only 2 x 2 pixels of the low-resolution map: for an even row
+    // the window rows (Y-1, Y, Y+1) are low rows (k-1, k, k), for an odd row (k, k, k+1), and the same along x -- so the term is
+    //     sum over a, b in {0, 1} of  Wc[row parity][column parity][a][b][n] * map[base row + a][base column + b]
+    // with COMBINED weights Wc = the sum of the 1, 2 or 4 taps that fall on low pixel (a, b) (the zero padding of the full-resolution image is a zero border
+    // of the low-resolution one: H and W are even).  As a GEMM step: K index = (parity class) * 4 + (a * 2 + b) -- exactly 16 -- with the map's four values
+    // in the slots of the pixel's own class and zeros elsewhere.  Loaded beside the first patch, consumed before the main loop: no register lives across it.
+    constexpr int LR = MM / 2 + 2;                                  // low-resolution rows under the wave's MM pixel rows (y0 + mrow0 is even)
+    float r1t[R1 ? 9 : 1], r1m[R1 ? LR : 1][2];
+    if constexpr (R1) {
+        const int n = nsel * 32 + r;
+        const float* wc = a.r1_w + (n < a.N ? (long)n * a.r1_ws : 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) r1t[t] = wc[t];
+        const int hl = a.H >> 1, wl_ = a.W >> 1;
+        const int ly0 = ((y0 + mrow0) >> 1) - 1, lx0 = ((x0 + r + 1) >> 1) - 1;   // low pixel of window row / column -1 of the wave's first row / the lane's pixel
+#pragma unroll
+        for (int i = 0; i < LR; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ly = ly0 + i, lx = lx0 + j;
+                const bool ok = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl_;
+                const float v = a.r1_inv[ok ? ((long)b * hl + ly) * wl_ + lx : 0];
+                r1m[i][j] = ok ? v : 0.f;
+            }
+    }
+    auto rank1_step = [&]() {
+        if constexpr (R1) {
+            // weights operand: lane (r, h) holds channel n, K slots 8 h .. 8 h + 7 = row parity h, column parity px = slot >> 2, (a, b) = slot & 3
+            float R[2][3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                R[0][kx] = r1t[kx] + (h ? r1t[3 + kx] : 0.f);          // low row a = 0: tap row 0 (+ tap row 1 on odd rows)
+                R[1][kx] = r1t[6 + kx] + (h ? 0.f : r1t[3 + kx]);      // low row a = 1: tap row 2 (+ tap row 1 on even rows)
+            }
+            const bool nok = nsel * 32 + r < a.N;
+            u32x4_t wf;
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) {
+                    const float c0 = px ? R[aa][0] + R[aa][1] : R[aa][0], c1 = px ? R[aa][2] : R[aa][1] + R[aa][2];
+                    wf[px * 2 + aa] = nok ? pack2bf(c0, c1) : 0u;
+                }
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const int la = (m + 1) >> 1;
+                const unsigned w01 = pack2bf(r1m[la][0], r1m[la][1]), w23 = pack2bf(r1m[la + 1][0], r1m[la + 1][1]);
+                const bool mine = h == (m & 1);                      // the pixel row's parity class sits in this half of the K slots
+                const bool odd = r & 1;
+                u32x4_t uf;
+                uf[0] = (mine && !odd) ? w01 : 0u; uf[1] = (mine && !odd) ? w23 : 0u;
+                uf[2] = (mine && odd) ? w01 : 0u;  uf[3] = (mine && odd) ? w23 : 0u;
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, uf), acc[m], 0, 0, 0);
+            }
+        }
+    };
+
     PATCH_STAMP_DECL;
     PATCH_STAMP();
     dma_patch(0, 0);
@@ -304,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WHOLE ? 0 : 2 * K) : "memory");     // the patch of slice 0 (the ring may still be in flight)
     __syncthreads();
     PATCH_STAMP();
+    rank1_step();
 
     constexpr int WR = MM + 1;                                     // window rows in registers
     u32x4_t win[WR][2];
@@ -360,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
                     }                                                                                                  \
             if (MORE) dma_patch((S) + 1, ((S) + 1) & 1);                                                               \
             PF2_COLUMN(0, MORE) PF2_COLUMN(1, MORE) PF2_COLUMN(2, MORE)                                                \
-            if (!(MORE)) load_bias();                                                                                  \
+            if (!(MORE)) load_bias();                                                                                   \
             PATCH_STAMP();                                                                                             \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* the next slice's patch has landed */            \
             __syncthreads();                                                                                           \
@@ -423,21 +486,42 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
     const int c = tid % (NT * 4);
+    if constexpr (ACC) {
+        // accumulating (a consumer's gradient added onto another's, or onto a term written first; an instantiation of its own: as a run-time branch beside
+        // the plain loop it cost the tall plain kernels 2 %): branch-free, with the LDS and global reads of all of the
+        // thread's NI pixels issued before the first use.  As a loop of guarded read -> wait -> add -> store bodies the epilogue was NI dependent round trips to
+        // memory (same-box A/B, 64 -> 32 at 384 x 1280: 283 -> 256 us; 96 -> 64 at 192 x 640: 141 -> 131 us).  The plain store loop below keeps its guarded form:
+        // hoisting its LDS reads the same way cost the tall 3 x 3 kernel 8 % (230 -> 250 us) -- the stores then leave in one burst at the end of the tile
+        constexpr int NI = OCH / 256;
+        u32x4_t v16[NI], vold[NI];
+        long off[NI];
+        bool ok[NI];
 #pragma unroll
-    for (int i = 0; i < OCH / 256; ++i) {
-        const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
-        const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
-        if (yy < a.H && c < cpp) {
-            u32x4_t v16 = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
-            if (a.accum) {
-                float vn[8], vo[8];
-                unpack16<bf16_t>(v16, vn);
-                unpack16<bf16_t>(*(const u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8), vo);
+        for (int i = 0; i < NI; ++i) {
+            const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
+            const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
+            ok[i] = yy < a.H && c < cpp;
+            off[i] = (((long)b * a.H + (yy < a.H ? yy : a.H - 1)) * a.W + xx) * a.ldy + (c < cpp ? c : 0) * 8;
+            v16[i] = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
+        }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) vn[k] += vo[k];
-                v16 = pack16<bf16_t>(vn);
-            }
-            *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
+        for (int i = 0; i < NI; ++i) vold[i] = *(const u32x4_t*)(a.y + off[i]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float vn[8], vo[8];
+            unpack16<bf16_t>(v16[i], vn);
+            unpack16<bf16_t>(vold[i], vo);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vn[k] += vo[k];
+            if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pack16<bf16_t>(vn);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < OCH / 256; ++i) {
+            const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
+            const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
+            if (yy < a.H && c < cpp)
+                *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
         }
     }
     PATCH_STAMP();
@@ -641,13 +725,15 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
     if constexpr (NT == 1) {
         if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
-            if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             return mte_check_launch();
         }
     }
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
-    if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     return mte_check_launch();
 }
@@ -773,8 +859,39 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
                          int B, int H, int W, int Cin_p, int N, int KH, int KW, int accumulate, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0};
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, nullptr, nullptr, 0};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
+}
+
+// The 3x3 forward with ONE MORE input channel given as a low-resolution map: y = conv_3(x, wpatch) + bias + conv_1(nearest_up2(inv), w1).  inv [B][H/2][W/2] fp32;
+// element (n, tap) of the extra channel's weights at w1[n * w1_stride + tap] (channel C-1 of an OIHW tensor: w1 = w + (C-1)*9, w1_stride = C*9).
+// The term is formed in the store loop of the tile from LDS tables (the map under the tile + halo, the 9 x N weights): no pass over y before, no read of y.
+// _ok: 1 when this launch form exists for the shape (the caller otherwise writes the term with mte_rank1_conv_fwd and accumulates onto it).
+int mte_conv2d_patch_fwd_rank1_ok(const float* bias, long ldx, int B, int H, int W, int Cin_p, int N) {
+    if (!patch_shape_ok(W, Cin_p, N, 3, 3) || !g_patch_fwd2 || (H & 1) || (W & 1)) return 0;
+    if (N > 32 && Cin_p <= 64) return 0;                            // (those shapes run the first form of the kernel)
+    if ((((long)B * H * W - 1) * ldx + Cin_p) * 2 >= 0x7ff00000L || ((uintptr_t)bias & 15) != 0) return 0;
+    return 1;
+}
+int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
+                               const float* inv, const float* w1, long w1_stride, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpatch || !y || !inv || !w1) return MTE_ERR_ARG;
+    if (!mte_conv2d_patch_fwd_rank1_ok(bias, ldx, B, H, W, Cin_p, N)) return MTE_ERR_UNSUPPORTED;
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, inv, w1, w1_stride};
+    if (N <= 32) {
+        if (g_patch_tall && H >= 16) {
+            const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
+            hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        } else {
+            const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
+            hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        }
+    } else {
+        const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
+        hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    }
+    return mte_check_launch();
 }
 
 // dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) for C_out <= 64; bf16 only.

@@ -542,7 +542,9 @@ _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0
         "patch_wgrad_slabs": not os.environ.get("MTE_PATCH_WGRAD_ATOMICS"),
         # decoder iconv3 / iconv2 / iconv1: the up-sampled inverse-depth input channel as a rank-1 term beside a GEMM over the other 192 / 96 / 64
         # channels (ConvGnEluInvFn) instead of a 65th channel that costs the GEMM kernels a whole 32-channel slice
-        "split_inv_channel": os.environ.get("MTE_SPLIT_INV", "1") == "1"}
+        "split_inv_channel": os.environ.get("MTE_SPLIT_INV", "1") == "1",
+        # ... and that term formed inside the LDS-patch forward's store loop where the layer runs on it (iconv1, iconv2): MTE_FUSE_INV=0 = written first, accumulated onto
+        "fuse_inv_term": os.environ.get("MTE_FUSE_INV", "1") == "1"}
 
 
 def use_pack_folding(flag):
@@ -953,8 +955,16 @@ class ConvGnEluInvFn(torch.autograd.Function):
         invc = inv.detach().contiguous().float()
         y = new_act(B, cout, H, W, x.dtype, x.device)
         yp, ldy = _pl(y)
-        lib.mte_rank1_conv_fwd(invc.data_ptr(), w.detach().data_ptr() + 4 * cm * 9, cin * 9, yp, ldy, B, H // 2, W // 2, cout, _dt(y), _stream())
-        conv_forward(x, wf, b, cout, kh, kw, out=y, pack=pack, w=wm, accumulate=True)
+        w1 = w.detach().data_ptr() + 4 * cm * 9
+        xp, ldx = _pl(x)
+        if (_cfg["fuse_inv_term"] and pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype)
+                and lib.mte_conv2d_patch_fwd_rank1_ok(_ptr(b), ldx, B, H, W, Cp, cout) == 1):
+            # one launch: the tile's store loop adds the map's term (no pass over y before the conv, no read of y in it)
+            lib.mte_conv2d_patch_fwd_rank1(xp, ldx, pack.get_patch(wm, 'f').data_ptr(), _ptr(b), yp, ldy, B, H, W, Cp, cout,
+                                           invc.data_ptr(), w1, cin * 9, _stream())
+        else:
+            lib.mte_rank1_conv_fwd(invc.data_ptr(), w1, cin * 9, yp, ldy, B, H // 2, W // 2, cout, _dt(y), _stream())
+            conv_forward(x, wf, b, cout, kh, kw, out=y, pack=pack, w=wm, accumulate=True)
         z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out))
         ctx.save_for_backward(x, invc, w, wm, y, stats, gamma, beta)
         ctx.pack = pack

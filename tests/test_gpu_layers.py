@@ -262,7 +262,8 @@ def test_shared_conv_weight_without_suspend_is_race_free_or_refused():
         K.set_compute_dtype("bf16")
 
 
-@pytest.mark.parametrize("cu,cs,cout,B,H,W", [(32, 32, 32, 2, 16, 32), (64, 32, 64, 1, 12, 36), (128, 64, 128, 2, 6, 10), (32, 32, 32, 1, 32, 64)])
+@pytest.mark.parametrize("cu,cs,cout,B,H,W", [(32, 32, 32, 2, 16, 32), (64, 32, 64, 1, 12, 36), (128, 64, 128, 2, 6, 10), (32, 32, 32, 1, 32, 64),
+                                              (64, 32, 64, 1, 16, 64), (32, 32, 32, 1, 24, 32), (32, 32, 32, 2, 8, 32)])
 def test_iconv_with_the_inverse_depth_channel_as_a_rank1_term(cu, cs, cout, B, H, W, mode):
     """Decoder iconv layers (reference PackNetSAN01.py:118-143: Conv2D over cat(unpack, skip, nearest_up2(inv_depth))): the form that keeps the
     inverse-depth map out of the concat buffer and adds its convolution as a rank-1 term (kernels.ConvGnEluInvFn) must agree with the plain
@@ -295,3 +296,38 @@ def test_iconv_with_the_inverse_depth_channel_as_a_rank1_term(cu, cs, cout, B, H
     assert rel_err(got[0], ref[0]) < ty
     for k, (a, b) in enumerate(zip(got[1:], ref[1:])):
         assert rel_err(a, b) < tg, k
+
+
+@pytest.mark.parametrize("cm,cout,B,H,W", [(64, 32, 2, 32, 64), (64, 32, 1, 24, 32), (64, 32, 1, 8, 64), (96, 64, 2, 16, 64), (96, 64, 1, 20, 32), (32, 32, 1, 16, 32)])
+def test_rank1_term_inside_the_patch_forward_matches_the_two_launch_form(cm, cout, B, H, W):
+    """mte_conv2d_patch_fwd_rank1 (the map's 3x3 term as one more MFMA step of the tile: bf16 map values against bf16 combined weights, like every other input
+    channel of the layer) against mte_rank1_conv_fwd + the accumulating patch forward (the term in fp32, rounded into y first) and against the fp32 convolution over
+    all C + 1 channels; borders of the image and of the tiles included (maps with a strong gradient: a wrong halo column or row shows at once)."""
+    from mindtheedge_amd import kernels as K
+    g = torch.Generator().manual_seed(cm + cout + H + W)
+    w = ((torch.rand(cout, cm + 1, 3, 3, generator=g) * 2 - 1) * (3.0 / ((cm + 1) * 9)) ** 0.5).cuda()
+    b = (torch.rand(cout, generator=g) - 0.5).cuda()
+    x = K.image_to_act((torch.rand(B, cm, H, W, generator=g) * 2 - 1).cuda())
+    inv = (torch.rand(B, 1, H // 2, W // 2, generator=g) * 4 - 1).cuda().contiguous()
+    pack = K.WeightPack()
+    wm = w[:, :cm].contiguous()
+    pack.get(wm, x.dtype, False)
+    xp, ldx = K._pl(x)
+    assert K.lib.mte_conv2d_patch_fwd_rank1_ok(b.data_ptr(), ldx, B, H, W, cm, cout) == 1
+    w1 = w.data_ptr() + 4 * cm * 9
+    st = torch.cuda.current_stream().cuda_stream
+    y2 = K.new_act(B, cout, H, W, x.dtype, x.device)
+    yp, ldy = K._pl(y2)
+    K.lib.mte_rank1_conv_fwd(inv.data_ptr(), w1, (cm + 1) * 9, yp, ldy, B, H // 2, W // 2, cout, K.DT_BF16, st)
+    K.lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(wm, 'f').data_ptr(), b.data_ptr(), yp, ldy, B, H, W, cm, cout, 3, 3, 1, st)
+    y1 = K.new_act(B, cout, H, W, x.dtype, x.device)
+    y1.fill_(float("nan"))
+    yp1, ldy1 = K._pl(y1)
+    K.lib.mte_conv2d_patch_fwd_rank1(xp, ldx, pack.get_patch(wm, 'f').data_ptr(), b.data_ptr(), yp1, ldy1, B, H, W, cm, cout, inv.data_ptr(), w1, (cm + 1) * 9, st)
+    torch.cuda.synchronize()
+    a, r = y1.float().contiguous(), y2.float().contiguous()
+    ref = torch.nn.functional.conv2d(torch.cat((x.float().contiguous(), torch.nn.functional.interpolate(inv, scale_factor=2, mode="nearest")), 1), w, b, padding=1)
+    assert torch.isfinite(a).all()
+    assert float((a - r).abs().max()) <= 2.0 ** -6 * float(r.abs().max())           # two ulps of bf16 at the largest magnitude
+    assert rel_err(a, ref) < 6e-3 and rel_err(a, ref) <= rel_err(r, ref) * 1.5 + 1e-4    # and about as close to the fp32 convolution as the two-launch form
+

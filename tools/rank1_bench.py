@@ -30,3 +30,33 @@ for N, h, w in ((32, 192, 640), (64, 96, 320), (128, 48, 160)):
         us = e0.elapsed_time(e1) * 100
         line += "  %s %6.1f us %4.2f TB/s" % (name, us, mb / us)
     print(line)
+
+# the forward term inside the LDS-patch conv (mte_conv2d_patch_fwd_rank1) against the two-launch form (mte_rank1_conv_fwd, then the accumulating conv), and the plain conv
+print("forward of the layer: map term written first + accumulating conv | term in the conv's store loop | (the conv alone)")
+for cm, N, H, W in ((64, 32, 384, 1280), (96, 64, 192, 640)):
+    x = K.new_act(B, cm, H, W).normal_()
+    inv = torch.rand(B, 1, H // 2, W // 2, device="cuda")
+    wt = torch.randn(N, cm + 1, 3, 3, device="cuda") * 0.05
+    bias = torch.zeros(N, device="cuda")
+    wm = wt[:, :cm].contiguous()
+    pack = K.WeightPack(); pack.get(wm, x.dtype, False)
+    pf = pack.get_patch(wm, 'f').data_ptr()
+    y = K.new_act(B, N, H, W)
+    xp, ldx = K._pl(x); yp, ldy = K._pl(y)
+    w1 = wt.data_ptr() + 4 * cm * 9
+
+    def two():
+        lib.mte_rank1_conv_fwd(inv.data_ptr(), w1, (cm + 1) * 9, yp, ldy, B, H // 2, W // 2, N, K._dt(y), K._stream())
+        lib.mte_conv2d_patch_fwd(xp, ldx, pf, bias.data_ptr(), yp, ldy, B, H, W, cm, N, 3, 3, 1, K._stream())
+    fns = {"two launches": two,
+           "fused": lambda: lib.mte_conv2d_patch_fwd_rank1(xp, ldx, pf, bias.data_ptr(), yp, ldy, B, H, W, cm, N, inv.data_ptr(), w1, (cm + 1) * 9, K._stream()),
+           "conv alone": lambda: lib.mte_conv2d_patch_fwd(xp, ldx, pf, bias.data_ptr(), yp, ldy, B, H, W, cm, N, 3, 3, 0, K._stream())}
+    line = "%3d -> %2d @%dx%d" % (cm, N, H, W)
+    for name, f in fns.items():
+        for _ in range(3): f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        line += "  %s %6.1f us" % (name, e0.elapsed_time(e1) * 100)
+    print(line)
