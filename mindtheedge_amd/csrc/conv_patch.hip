@@ -58,7 +58,7 @@ struct PatchArgs {
 // TALL (NT = 1, one 32-channel input slice): 16 x 32-pixel tile, four pixel rows per wave -- every weight fragment fetched
 // from L2 feeds twice the MFMAs (with two rows per wave the 7x7 full-resolution layers pulled 6 GB of weight fragments
 // per launch, ~10 TB/s of L2 bandwidth); the single slice needs only one patch buffer, so two workgroups still fit a CU.
-template <int K, int NT, bool TALL>
+template <int K, int NT, bool TALL, bool ACC = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
     constexpr int TH = TALL ? 16 : 8;                               // (shadows the file-level 8-row tile of the wgrad kernels)
@@ -186,21 +186,40 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
     const int c = tid % (NT * 4);
+    if constexpr (ACC) {
+        // accumulating: branch-free, every LDS and global read of the thread's pixels issued before the first use (see the second form's epilogue;
+        // same-box A/B, 32 -> 64 at 384 x 1280: the guarded read -> wait -> add -> store loop cost 100 us over the plain store)
+        constexpr int NI = OCH / 256;
+        u32x4_t v16[NI], vold[NI];
+        long off[NI];
+        bool ok[NI];
 #pragma unroll
-    for (int i = 0; i < OCH / 256; ++i) {
-        const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
-        const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
-        if (yy < a.H && c < cpp) {
-            u32x4_t v16 = *(const u32x4_t*)(smem + pix * NB + c * 16);
-            if (a.accum) {
-                float vn[8], vo[8];
-                unpack16<bf16_t>(v16, vn);
-                unpack16<bf16_t>(*(const u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8), vo);
+        for (int i = 0; i < NI; ++i) {
+            const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
+            const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
+            ok[i] = yy < a.H && c < cpp;
+            off[i] = (((long)b * a.H + (yy < a.H ? yy : a.H - 1)) * a.W + xx) * a.ldy + (c < cpp ? c : 0) * 8;
+            v16[i] = *(const u32x4_t*)(smem + pix * NB + c * 16);
+        }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) vn[k] += vo[k];
-                v16 = pack16<bf16_t>(vn);
-            }
-            *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = v16;
+        for (int i = 0; i < NI; ++i) vold[i] = *(const u32x4_t*)(a.y + off[i]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float vn[8], vo[8];
+            unpack16<bf16_t>(v16[i], vn);
+            unpack16<bf16_t>(vold[i], vo);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vn[k] += vo[k];
+            if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pack16<bf16_t>(vn);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < OCH / 256; ++i) {
+            const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
+            const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
+            if (yy < a.H && c < cpp)
+                *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * NB + c * 16);
+            asm volatile("" ::: "memory");                         // one read -> store per iteration: with the reads hoisted the stores leave in one burst (2-4 % slower)
         }
     }
     PATCH_STAMP();
@@ -522,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
             const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
             if (yy < a.H && c < cpp)
                 *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
+            asm volatile("" ::: "memory");                         // one read -> store per iteration (see the first form)
         }
     }
     PATCH_STAMP();
@@ -727,6 +747,7 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
             if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             return mte_check_launch();
         }
@@ -734,6 +755,7 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
     if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     return mte_check_launch();
 }

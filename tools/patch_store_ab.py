@@ -13,7 +13,7 @@ for f in (fo,):
     f.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 8 + [ctypes.c_void_p]
     f.restype = ctypes.c_int
 B = 8
-for cm, N, H, W, k in ((64, 32, 384, 1280, 3), (96, 64, 192, 640, 3), (32, 32, 384, 1280, 7), (64, 64, 192, 640, 3), (128, 64, 96, 320, 3), (64, 32, 192, 640, 5)):
+for cm, N, H, W, k in ((64, 32, 384, 1280, 3), (96, 64, 192, 640, 3), (32, 32, 384, 1280, 7), (64, 64, 192, 640, 3), (32, 64, 384, 1280, 3), (64, 64, 192, 640, 1), (32, 64, 192, 640, 1), (128, 64, 96, 320, 3), (64, 32, 192, 640, 5)):
     x = K.new_act(B, cm, H, W).normal_()
     wt = torch.randn(N, cm, k, k, device="cuda") * 0.05
     bias = torch.zeros(N, device="cuda")
