@@ -1383,6 +1383,9 @@ template <> __device__ __forceinline__ void store8<float>(float* dst, const floa
     *(u32x4_t*)dst = pack16<float>(v); *(u32x4_t*)(dst + 4) = pack16<float>(v + 4);
 }
 
+// output channels per block of the forward-pack phase: what fits the 64 x 65 floats of LDS beside 64 input channels x taps, at most 16
+__host__ __device__ inline int pack_fn(int taps) { const int f = (64 * 65) / (64 * taps); return f < 1 ? 1 : (f > 16 ? 16 : f); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb) {
     __shared__ float s_w[64 * 65];                                   // phase f: [64 channels][taps <= 49]; phase b: [64][65] tile
@@ -1394,18 +1397,29 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb) {
     const int Cout = J.Cout, Cin = J.Cin, taps = J.taps, Cin_p = J.Cin_p;
     const float* __restrict__ w = J.w;
     if (bid < J.end_f) {
-        // ---- forward pack: block = (n, 64-channel chunk); OIHW run of 64*taps floats -> LDS -> [tap][64 channels] runs
+        // ---- forward pack: block = (FN output channels, 64-channel chunk); OIHW runs of 64*taps floats -> LDS -> one 16-byte store of 8 channels per
+        // (n, tap, chunk).  (Round 4: one n per block and 2-byte stores ran the ~1 GB of pack traffic of a step at 1.8 TB/s.)
+        const int fn = pack_fn(taps);
         const int cchunks = (Cin_p + 63) >> 6;
-        const int lb = bid - start, n = lb / cchunks, c0 = (lb - n * cchunks) * 64;
-        const int nc = min(64, Cin - c0);
-        const float* src = w + ((long)n * Cin + c0) * taps;
-        for (int i = threadIdx.x; i < nc * taps; i += 256) s_w[i] = src[i];
+        const int lb = bid - start, n0 = (lb / cchunks) * fn, c0 = (lb - (lb / cchunks) * cchunks) * 64;
+        const int nc = min(64, Cin - c0), nn = min(fn, Cout - n0);
+        const int run = nc > 0 ? nc * taps : 0, rs = 64 * taps;     // floats of one n in global memory (contiguous) / in LDS
+        for (int i = threadIdx.x; i < nn * run; i += 256) {
+            const int ni = i / run, r = i - ni * run;
+            s_w[ni * rs + r] = w[((long)(n0 + ni) * Cin + c0) * taps + r];
+        }
         __syncthreads();
-        const int ncp = min(64, Cin_p - c0);
+        const int ncp = min(64, Cin_p - c0), nch = ncp >> 3;        // channels incl. zero padding (a multiple of 8), 16-byte chunks of them
         T* wf = (T*)J.wf;
-        for (int i = threadIdx.x; i < taps * ncp; i += 256) {
-            const int tap = i / ncp, cl = i - tap * ncp;
-            Elem<T>::st(wf + ((long)n * taps + tap) * Cin_p + c0 + cl, cl < nc ? s_w[cl * taps + tap] : 0.f);
+        for (int i = threadIdx.x; i < nn * taps * nch; i += 256) {
+            const int ch8 = i % nch, t2 = i / nch, tap = t2 % taps, ni = t2 / taps;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cl = ch8 * 8 + j;
+                v[j] = cl < nc ? s_w[ni * rs + cl * taps + tap] : 0.f;
+            }
+            store8<T>(wf + ((long)(n0 + ni) * taps + tap) * Cin_p + c0 + ch8 * 8, v);
         }
         return;
     }
@@ -1421,6 +1435,20 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb) {
         }
         __syncthreads();
         T* wb = (T*)J.wb;
+        if (Cout % 8 == 0) {                                         // 16-byte stores of 8 output channels
+            for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+                const int kk = i >> 3, n8 = i & 7;
+                const int k = k0 + kk, n = n0 + n8 * 8;
+                if (k < Kp && n < Cout) {
+                    const int c = k / taps, tap = k - c * taps;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = s_w[(n8 * 8 + j) * 65 + kk];
+                    store8<T>(wb + ((long)c * taps + (taps - 1 - tap)) * Cout + n, v);
+                }
+            }
+            return;
+        }
         for (int i = threadIdx.x; i < 64 * 64; i += 256) {
             const int kk = i >> 6, nn = i & 63;
             const int k = k0 + kk, n = n0 + nn;
@@ -1659,7 +1687,7 @@ int mte_pack_conv_weights_multi(const void* jobs_host, int njobs, int dtype, hip
             if (!J.w || !J.wf || J.taps < 1 || J.taps > 49 || J.Cin_p % 8 != 0 || J.Cin > J.Cin_p) return MTE_ERR_ARG;
             if ((J.pf || J.pb) && dtype != MTE_DT_BF16) return MTE_ERR_ARG;
             if (J.pb && !J.wb) return MTE_ERR_ARG;
-            blocks += (long)J.Cout * ((J.Cin_p + 63) / 64);
+            blocks += (long)((J.Cout + pack_fn(J.taps) - 1) / pack_fn(J.taps)) * ((J.Cin_p + 63) / 64);
             J.end_f = (int)blocks;
             if (J.wb) blocks += (long)((J.Cout + 63) / 64) * ((J.taps * J.Cin_p + 63) / 64);
             J.end_b = (int)blocks;
