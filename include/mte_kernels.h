@@ -193,6 +193,12 @@ int mte_upsample2_f32(const float* inv, float* out, int B, int h, int wl, mte_st
 int mte_conv2d_patch_fwd_rank1_ok(const float* bias, long ldx, int B, int H, int W, int Cin_p, int N);
 int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
                                const float* inv, const float* w1, long w1_stride, mte_stream_t stream);
+/* y = conv_3x3(x, wpatch) + conv_1x1(x2, wpatch2) + bias in one launch of the LDS-patch kernel (bf16, N <= 64, W % 32 == 0): the second source's C2 channels are
+ * further K-steps of every tile at the centre tap; wpatch2 = fragment-block pack of the 1x1 weights for the same N (mte_conv2d_patch_pack_elems(C2, N, 1, 1)).
+ * The data gradient of a residual block's input (reference layers01.py:55-73: conv1 and the 1x1 shortcut read the same x): dx = conv3x3^T(dy1) + conv1x1^T(dy3)
+ * without a stand-alone 1x1 launch and without an accumulating pass over dx. */
+int mte_conv2d_patch_fwd_plus1x1(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
+                                 const void* x2, long ldx2, const void* wpatch2, int C2, mte_stream_t stream);
 /* its gradient with respect to the weight column: dw: element (n, tap) at dw[n * dw_stride + tap] (overwritten); records: mte_rank1_conv_bwd_records_elems(N)
  * floats of scratch.  Every record of dy is read once; no floating-point atomics (fixed-order sums: bit-reproducible). */
 long mte_rank1_conv_bwd_records_elems(int N);

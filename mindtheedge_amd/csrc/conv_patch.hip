@@ -52,15 +52,18 @@ struct PatchArgs {
     // rank-1 term (3x3 second form only, mte_conv2d_patch_fwd_rank1): y += conv_1(nearest_up2(r1_inv)) with one more input channel's weights
     const float* r1_inv;                           // [B][H/2][W/2] fp32, or nullptr
     const float* r1_w; long r1_ws;                 // element (n, tap) at r1_w[n * r1_ws + tap]
+    // second K source (first form, mte_conv2d_patch_fwd_plus1x1): y += conv_1x1(x2, wp2) -- more K-steps of the same tile at the centre tap only
+    const bf16_t* x2; long ldx2; const bf16_t* wp2; int C2;
 };
 
 // ---- forward / dgrad --------------------------------------------------------------------------------------
 // TALL (NT = 1, one 32-channel input slice): 16 x 32-pixel tile, four pixel rows per wave -- every weight fragment fetched
 // from L2 feeds twice the MFMAs (with two rows per wave the 7x7 full-resolution layers pulled 6 GB of weight fragments
 // per launch, ~10 TB/s of L2 bandwidth); the single slice needs only one patch buffer, so two workgroups still fit a CU.
-template <int K, int NT, bool TALL, bool ACC = false>
+template <int K, int NT, bool TALL, bool ACC = false, bool EXTRA = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
+    static_assert(!EXTRA || K == 3, "the 1x1 second source rides the 3x3 kernels");
     constexpr int TH = TALL ? 16 : 8;                               // (shadows the file-level 8-row tile of the wgrad kernels)
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int PCH = PH * PW * 4;                               // 16-B chunks per patch slice
@@ -83,19 +86,26 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     const int x0 = tx_ * TW, y0 = ty_ * TH;
     const int cpt = a.Cin_p >> 3;                                  // 16-B chunks per pixel
     const int nslices = (a.Cin_p + 31) >> 5;
+    // (EXTRA) slices nslices .. nall-1 come from the second source x2 (C2 channels) and meet the 1x1 weights wp2 at the centre tap only: the data gradient
+    // of a residual block's input, dx = conv3x3^T(dy1) + conv1x1^T(dy3), in one launch instead of a 1x1 launch and an accumulating 3x3 launch
+    const int nall = EXTRA ? nslices + ((a.C2 + 31) >> 5) : nslices;
 
     u32x4_t st[NCH];
     auto load_patch = [&](int s) {
+        const bool second = EXTRA && s >= nslices;
+        const bf16_t* src = second ? a.x2 : a.x;
+        const long ld = second ? a.ldx2 : a.ldx;
+        const int cp = second ? a.C2 >> 3 : cpt, s0 = second ? s - nslices : s;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int idc = tid + i * 256;
             const int p = idc >> 2, kc = idc & 3;
             const int py = p / PW, px = p - py * PW;
             const int iy = y0 + py - PAD, ix = x0 + px - PAD;
-            const int cc = s * 4 + kc;
+            const int cc = s0 * 4 + kc;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if ((PCH % 256 == 0 || idc < PCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cpt)
-                v = *(const u32x4_t*)(a.x + (((long)b * a.H + iy) * a.W + ix) * a.ldx + cc * 8);
+            if ((PCH % 256 == 0 || idc < PCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cp)
+                v = *(const u32x4_t*)(src + (((long)b * a.H + iy) * a.W + ix) * ld + cc * 8);
             st[i] = v;
         }
     };
@@ -126,9 +136,31 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     __syncthreads();
     PATCH_STAMP();
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane;               // fragment block = 64 lanes x 16 B
-    for (int s = 0; s < nslices; ++s) {
+    for (int s = 0; s < nall; ++s) {
         const char* P = smem + (s & 1) * PBYTES;
-        if (s + 1 < nslices) load_patch(s + 1);
+        if (s + 1 < nall) load_patch(s + 1);
+        if (EXTRA && s >= nslices) {                               // a slice of the second source: the centre tap against the 1x1 fragments
+            const u32x4_t* w2 = (const u32x4_t*)a.wp2 + lane + (long)(s - nslices) * 2 * NT * 64;
+            u32x4_t b2[2], fa[MM][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) b2[kk] = w2[(kk * NT + nsel) * 64];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const int p = (mrow0 + m + PAD) * PW + PAD + r;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
+            }
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]), __builtin_bit_cast(bf16x8_t, b2[kk]), acc[m], 0, 0, 0);
+            PATCH_STAMP();
+            if (s + 1 < nall) store_patch((s + 1) & 1);
+            __syncthreads();
+            PATCH_STAMP();
+            continue;
+        }
         const u32x4_t* wsl = wl + (long)s * TAPS * 2 * NT * 64;
         // weight fragments come straight from L2 (hundreds of cycles): keep PD taps in flight in a register ring
         constexpr int PD = TAPS < 4 ? TAPS : 4;
@@ -165,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
             }
         }
         PATCH_STAMP();
-        if (s + 1 < nslices) store_patch((s + 1) & 1);
+        if (s + 1 < nall) store_patch((s + 1) & 1);
         __syncthreads();
         PATCH_STAMP();
     }
@@ -881,7 +913,7 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
                          int B, int H, int W, int Cin_p, int N, int KH, int KW, int accumulate, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, nullptr, nullptr, 0};
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
 }
 
@@ -900,7 +932,7 @@ int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, cons
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !inv || !w1) return MTE_ERR_ARG;
     if (!mte_conv2d_patch_fwd_rank1_ok(bias, ldx, B, H, W, Cin_p, N)) return MTE_ERR_UNSUPPORTED;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, inv, w1, w1_stride};
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, inv, w1, w1_stride, nullptr, 0, nullptr, 0};
     if (N <= 32) {
         if (g_patch_tall && H >= 16) {
             const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
@@ -912,6 +944,29 @@ int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, cons
     } else {
         const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
         hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    }
+    return mte_check_launch();
+}
+
+// y = conv_3x3(x, wpatch) + conv_1x1(x2, wpatch2) + bias in ONE launch: the second term's C2 channels are further K-steps of every tile at the centre tap
+// (wpatch2: the fragment-block pack of the 1x1 weights for the same N).  Written for the data gradient of a residual block's input (reference layers01.py:55-73:
+// conv1 (3x3) and the 1x1 shortcut conv3 read the same x), dx = conv3x3^T(dy1) + conv1x1^T(dy3): instead of a 1x1 launch and an ACCUMULATING 3x3 launch.
+int mte_conv2d_patch_fwd_plus1x1(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
+                                 const void* x2, long ldx2, const void* wpatch2, int C2, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpatch || !y || !x2 || !wpatch2 || C2 < 8 || C2 % 8 != 0 || !patch_shape_ok(W, Cin_p, N, 3, 3)) return MTE_ERR_ARG;
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, nullptr, nullptr, 0, (const bf16_t*)x2, ldx2, (const bf16_t*)wpatch2, C2};
+    if (N <= 32) {
+        if (g_patch_tall && H >= 16) {
+            const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
+            hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        } else {
+            const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
+            hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        }
+    } else {
+        const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
+        hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
     }
     return mte_check_launch();
 }

@@ -544,7 +544,10 @@ _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0
         # channels (ConvGnEluInvFn) instead of a 65th channel that costs the GEMM kernels a whole 32-channel slice
         "split_inv_channel": os.environ.get("MTE_SPLIT_INV", "1") == "1",
         # ... and that term formed inside the LDS-patch forward's store loop where the layer runs on it (iconv1, iconv2): MTE_FUSE_INV=0 = written first, accumulated onto
-        "fuse_inv_term": os.environ.get("MTE_FUSE_INV", "1") == "1"}
+        "fuse_inv_term": os.environ.get("MTE_FUSE_INV", "1") == "1",
+        # residual blocks: the 1x1 shortcut's data gradient rides the 3x3 conv1's data-gradient launch as extra K-steps (mte_conv2d_patch_fwd_plus1x1) where
+        # that launch runs on the LDS-patch kernel -- no stand-alone 1x1 launch, no accumulating pass over dx.  MTE_FOLD_SHORTCUT=0: two launches
+        "fold_shortcut_dgrad": os.environ.get("MTE_FOLD_SHORTCUT", "1") == "1"}
 
 
 def use_pack_folding(flag):
@@ -796,7 +799,28 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
         else:
             dw, dbias = _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
     if need_dx:
-        target = _fork_target(fork_slot, (B, Cp, H, W), x.dtype)
+        target = _fork_target(fork_slot, (B, Cp, H, W), x.dtype, keep_pending=True)
+        if (target is None and fork_slot is not None and (kh, kw) == (1, 1) and sites is None and _cfg["fold_shortcut_dgrad"]
+                and not _cfg.get("no_fork_accumulate") and _patch_ok(W, cout, Cp, 1, 1, x.dtype) and _patch_ok(W, 32, Cp, 3, 3, x.dtype)):
+            # a 1x1 whose input has another consumer that has not produced its data gradient yet (a residual block's shortcut: autograd runs it before
+            # the block's conv1): hand out the buffer, leave the launch to that consumer's 3x3 data gradient (below) -- or to whoever touches the slot first
+            dx = new_act(B, Cp, H, W, x.dtype, x.device)
+            fork_slot["buf"] = dx
+            fork_slot["pending"] = (dy, w, pack)
+            return dx, dw, dbias
+        pend = _pending_slot(fork_slot) if target is not None else None
+        if pend is not None:
+            dy3, w3, pack3 = pend["pending"]
+            if ((kh, kw) == (3, 3) and sites is None and target is pend["buf"] and _patch_ok(W, cout, Cp, 3, 3, x.dtype)
+                    and tuple(dy3.shape[2:]) == (H, W) and dy3.dtype == x.dtype):
+                del pend["pending"]
+                d3p, ldd3 = _pl(dy3)
+                dxp, lddx = _pl(target)
+                lib.mte_conv2d_patch_fwd_plus1x1(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
+                                                 d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1], st)
+                fork_slot["buf"] = target
+                return target, dw, dbias
+            _flush_pending(pend)
         dx = target if target is not None else new_act(B, Cp, H, W, x.dtype, x.device)
         if target is None and sites is not None:
             dx.zero_()                                       # (as in conv_forward: inactive sites of a sparse result are exact zeros)
@@ -1418,14 +1442,38 @@ class InvDepthFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def _fork_target(slot, shape, dtype):
+def _pending_slot(slot):
+    """the slot (this one or an ancestor) whose buffer is still waiting for a deferred 1x1 data gradient (conv_backward), or None"""
+    while slot is not None:
+        if slot["buf"] is not None:
+            return slot if "pending" in slot else None
+        slot = slot["parent"]
+    return None
+
+
+def _flush_pending(slot):
+    """launch the deferred 1x1 data gradient of `slot` on its own (plain store into the slot's buffer): whoever needs the buffer's contents before the
+    3x3 consumer that would have carried it came along"""
+    dy3, w3, pack3 = slot.pop("pending")
+    dx = slot["buf"]
+    B, Cp, H, W = dx.shape
+    cout = w3.shape[0]
+    d3p, ldd3 = _pl(dy3)
+    dxp, lddx = _pl(dx)
+    lib.mte_conv2d_patch_fwd(d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, 1, 1, 0, _stream())
+
+
+def _fork_target(slot, shape, dtype, keep_pending=False):
     """The buffer a data gradient should be ACCUMULATED into: the gradient that another consumer of the same forked
-    activation (or, for a fork of a fork, of its parent) has already produced.  None = this consumer is the first."""
+    activation (or, for a fork of a fork, of its parent) has already produced.  None = this consumer is the first.
+    keep_pending: the caller deals with a deferred 1x1 term of that buffer itself (conv_backward); everybody else gets it flushed first."""
     if _cfg.get("no_fork_accumulate"):
         return None
     while slot is not None:
         buf = slot["buf"]
         if buf is not None:
+            if "pending" in slot and not keep_pending:
+                _flush_pending(slot)
             return buf if (tuple(buf.shape) == tuple(shape) and buf.dtype == dtype and is_act(buf)) else None
         slot = slot["parent"]
     return None
@@ -1447,6 +1495,8 @@ class ForkFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g1, g2):
         slot = ctx.slot
+        if "pending" in slot:                                # nobody carried the deferred 1x1 term: its buffer is one of g1 / g2
+            _flush_pending(slot)
         if g1 is None or g2 is None:
             out = g1 if g2 is None else g2
         elif g1.data_ptr() == g2.data_ptr() and g1.shape == g2.shape and g1.stride() == g2.stride():

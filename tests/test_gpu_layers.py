@@ -331,3 +331,87 @@ def test_rank1_term_inside_the_patch_forward_matches_the_two_launch_form(cm, cou
     assert float((a - r).abs().max()) <= 2.0 ** -6 * float(r.abs().max())           # two ulps of bf16 at the largest magnitude
     assert rel_err(a, ref) < 6e-3 and rel_err(a, ref) <= rel_err(r, ref) * 1.5 + 1e-4    # and about as close to the fp32 convolution as the two-launch form
 
+
+
+@pytest.mark.parametrize("c1,cp,c2,B,H,W", [(64, 64, 64, 2, 16, 64), (64, 32, 64, 1, 24, 32), (64, 32, 64, 2, 8, 32), (32, 64, 32, 1, 20, 64), (96, 64, 40, 1, 8, 32)])
+def test_patch_dgrad_with_the_1x1_shortcut_as_extra_k_steps(c1, cp, c2, B, H, W):
+    """mte_conv2d_patch_fwd_plus1x1: dx = conv3x3^T(dy1) + conv1x1^T(dy3) of a residual block's input (reference layers01.py:55-73) in one launch, against the
+    1x1 launch followed by the accumulating 3x3 launch (same fp32 sums but for one rounding of the 1x1 term to bf16) and against the fp32 convolutions."""
+    from mindtheedge_amd import kernels as K
+    g = torch.Generator().manual_seed(c1 + cp + c2 + H)
+    w1 = ((torch.rand(c1, cp, 3, 3, generator=g) * 2 - 1) * (3.0 / (c1 * 9)) ** 0.5).cuda()     # conv1: cp -> c1 (its data gradient maps c1 -> cp)
+    w3 = ((torch.rand(c2, cp, 1, 1, generator=g) * 2 - 1) * (3.0 / c2) ** 0.5).cuda()             # shortcut: cp -> c2
+    dy1 = K.image_to_act((torch.rand(B, c1, H, W, generator=g) * 2 - 1).cuda())
+    dy3 = K.image_to_act((torch.rand(B, c2, H, W, generator=g) * 2 - 1).cuda())
+    p1, p3 = K.WeightPack(), K.WeightPack()
+    st = torch.cuda.current_stream().cuda_stream
+    a1, l1 = K._pl(dy1)
+    a3, l3 = K._pl(dy3)
+    two = K.new_act(B, cp, H, W, dy1.dtype, dy1.device)
+    tp, tl = K._pl(two)
+    K.lib.mte_conv2d_patch_fwd(a3, l3, p3.get_patch(w3, 'b').data_ptr(), 0, tp, tl, B, H, W, c2, cp, 1, 1, 0, st)
+    K.lib.mte_conv2d_patch_fwd(a1, l1, p1.get_patch(w1, 'b').data_ptr(), 0, tp, tl, B, H, W, c1, cp, 3, 3, 1, st)
+    one = K.new_act(B, cp, H, W, dy1.dtype, dy1.device)
+    one.fill_(float("nan"))
+    op, ol = K._pl(one)
+    K.lib.mte_conv2d_patch_fwd_plus1x1(a1, l1, p1.get_patch(w1, 'b').data_ptr(), 0, op, ol, B, H, W, c1, cp, a3, l3, p3.get_patch(w3, 'b').data_ptr(), c2, st)
+    torch.cuda.synchronize()
+    F = torch.nn.functional
+    ref = F.conv_transpose2d(dy1.float().contiguous(), w1, padding=1) + F.conv_transpose2d(dy3.float().contiguous(), w3)
+    a, r = one.float().contiguous(), two.float().contiguous()
+    assert torch.isfinite(a).all()
+    assert float((a - r).abs().max()) <= 2.0 ** -7 * float(r.abs().max())
+    assert rel_err(a, ref) < 6e-3 and rel_err(a, ref) <= rel_err(r, ref) * 1.05 + 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(32, 64, 2, 16, 64), (64, 64, 1, 24, 32)])
+def test_residual_conv_with_the_shortcut_gradient_folded_into_conv1s(cin, cout, B, H, W):
+    """ResidualConv backward with the 1x1 shortcut's data gradient deferred to conv1's data-gradient launch (kernels._cfg['fold_shortcut_dgrad']) against the
+    two-launch schedule: same output, same gradients (bf16: the input gradient differs by one rounding of the 1x1 term)."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.layers.packnet.layers01 import ResidualConv
+    g = torch.Generator().manual_seed(cin + cout + H)
+    m = ResidualConv(cin, cout, 1, dropout=None).cuda()
+    x0 = (torch.rand(B, cin, H, W, generator=g) * 2 - 1).cuda()
+    G = (torch.rand(B, cout, H, W, generator=g) * 2 - 1).cuda()
+
+    def run(fold):
+        K._cfg["fold_shortcut_dgrad"] = fold
+        try:
+            m.zero_grad()
+            xa = K.image_to_act(x0).detach().requires_grad_(True)
+            y = m(xa)
+            (y.float() * G).sum().backward()
+            K.join_side_stream()
+            torch.cuda.synchronize()
+            return [y.float().detach().cpu(), xa.grad.float().cpu()] + [p.grad.detach().clone().cpu() for p in m.parameters()]
+        finally:
+            K._cfg["fold_shortcut_dgrad"] = True
+
+    ref, got = run(False), run(True)
+    assert torch.equal(got[0], ref[0])
+    assert rel_err(got[1], ref[1]) < 1e-2                     # (bf16: one rounding of the 1x1 term fewer)
+    for a, b in zip(got[2:], ref[2:]):                          # (GroupNorm's dgamma / dbeta add per-sample parts with fp32 atomics: equal to rounding, not bitwise)
+        assert rel_err(a, b) < 1e-5
+
+
+def test_deferred_shortcut_gradient_is_flushed_when_no_conv_carries_it():
+    """The deferred 1x1 data gradient of a forked activation whose OTHER consumer is not an LDS-patch 3x3 conv: the fork's backward launches it on its own
+    (kernels._flush_pending) before the two gradients are added."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd.networks.layers.packnet.layers01 import _ConvParams
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 1, 32, 8, 32
+    sc = _ConvParams(C, 64, 1).cuda()
+    x0 = (torch.rand(B, C, H, W, generator=g) * 2 - 1).cuda()
+    G = (torch.rand(B, 64, H, W, generator=g) * 2 - 1).cuda()
+    xa = K.image_to_act(x0).detach().requires_grad_(True)
+    a, b = K.fork(xa)
+    s = K.ConvFn.apply(b, sc.weight, sc.bias, sc.pack, True)
+    ((s.float() * G).sum() + (a.float() * 0.5).sum()).backward()
+    K.join_side_stream()
+    torch.cuda.synchronize()
+    xr = x0.clone().requires_grad_(True)
+    wq = sc.weight.detach().to(torch.bfloat16).float()
+    (torch.nn.functional.conv2d(xr.to(torch.bfloat16).float(), wq, sc.bias.detach()) * G).sum().backward()
+    assert rel_err(xa.grad.float().cpu(), (xr.grad + 0.5).cpu()) < 2e-2
