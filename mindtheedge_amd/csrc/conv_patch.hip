@@ -56,6 +56,37 @@ struct PatchArgs {
     const bf16_t* x2; long ldx2; const bf16_t* wp2; int C2;
 };
 
+
+// ---- second K source at the centre tap (EXTRA; mte_conv2d_patch_fwd_plus1x1) ---------------------------------------------------------------------------------
+// y += conv_1x1(x2, wp2): for a 1x1 every input element meets the MFMA exactly once per 32-column tile, so its fragments need no LDS patch -- lane (r, h) of
+// pixel row m loads the 16 bytes [channels 32 s + 16 kk + 8 h ..] of pixel (y0 + mrow0 + m, x0 + r) straight from global memory.  Issued in the PROLOGUE, beside the
+// first patch of the 3x3 (one exposed memory latency serves both), two slices at a time; consumed before the main loop, whose register peak is unchanged.
+// (First try: the second source as further slices of the LDS patch loop -- each 1-tap slice exposed its own patch load: +36..44 us on an 84 us launch.)
+template <int MM, int Q> struct ExtraFrags { u32x4_t px[Q][MM][2], w[Q][2]; };   // Q slices of 32 channels in flight
+template <int MM, int NT, int Q>
+__device__ __forceinline__ void extra_load(ExtraFrags<MM, Q>& f, const PatchArgs& a, int s2, int b, int yrow0, int xcol, int h, int nsel, int lane) {
+    const int cp2 = a.C2 >> 3, n2 = (a.C2 + 31) >> 5;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int sl = s2 + q;
+        const bool sok = sl < n2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const u32x4_t wv = *((const u32x4_t*)a.wp2 + lane + ((long)((sok ? sl : 0) * 2 + kk) * NT + nsel) * 64);
+            f.w[q][kk] = sok ? wv : u32x4_t{0u, 0u, 0u, 0u};
+            const int cc = sl * 4 + kk * 2 + h;
+            const bool cok = sok && cc < cp2;
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const int yy = yrow0 + m;
+                const bool ok = cok && yy < a.H;
+                const u32x4_t v = *(const u32x4_t*)(a.x2 + (((long)b * a.H + (yy < a.H ? yy : a.H - 1)) * a.W + xcol) * a.ldx2 + (cok ? cc : 0) * 8);
+                f.px[q][m][kk] = ok ? v : u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+}
+
 // ---- forward / dgrad --------------------------------------------------------------------------------------
 // TALL (NT = 1, one 32-channel input slice): 16 x 32-pixel tile, four pixel rows per wave -- every weight fragment fetched
 // from L2 feeds twice the MFMAs (with two rows per wave the 7x7 full-resolution layers pulled 6 GB of weight fragments
@@ -86,26 +117,19 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     const int x0 = tx_ * TW, y0 = ty_ * TH;
     const int cpt = a.Cin_p >> 3;                                  // 16-B chunks per pixel
     const int nslices = (a.Cin_p + 31) >> 5;
-    // (EXTRA) slices nslices .. nall-1 come from the second source x2 (C2 channels) and meet the 1x1 weights wp2 at the centre tap only: the data gradient
-    // of a residual block's input, dx = conv3x3^T(dy1) + conv1x1^T(dy3), in one launch instead of a 1x1 launch and an accumulating 3x3 launch
-    const int nall = EXTRA ? nslices + ((a.C2 + 31) >> 5) : nslices;
 
     u32x4_t st[NCH];
     auto load_patch = [&](int s) {
-        const bool second = EXTRA && s >= nslices;
-        const bf16_t* src = second ? a.x2 : a.x;
-        const long ld = second ? a.ldx2 : a.ldx;
-        const int cp = second ? a.C2 >> 3 : cpt, s0 = second ? s - nslices : s;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int idc = tid + i * 256;
             const int p = idc >> 2, kc = idc & 3;
             const int py = p / PW, px = p - py * PW;
             const int iy = y0 + py - PAD, ix = x0 + px - PAD;
-            const int cc = s0 * 4 + kc;
+            const int cc = s * 4 + kc;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if ((PCH % 256 == 0 || idc < PCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cp)
-                v = *(const u32x4_t*)(src + (((long)b * a.H + iy) * a.W + ix) * ld + cc * 8);
+            if ((PCH % 256 == 0 || idc < PCH) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc < cpt)
+                v = *(const u32x4_t*)(a.x + (((long)b * a.H + iy) * a.W + ix) * a.ldx + cc * 8);
             st[i] = v;
         }
     };
@@ -131,36 +155,30 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
 
     PATCH_STAMP_DECL;
     PATCH_STAMP();
+    if constexpr (EXTRA) {                                         // second K source: all of its MFMAs before the main loop (see extra_load)
+        // one slice in flight: with two, this form (167 VGPRs, three workgroups per CU) drops to two workgroups per CU
+        const int n2 = (a.C2 + 31) >> 5;
+        ExtraFrags<MM, 1> ef;
+        extra_load<MM, NT, 1>(ef, a, 0, b, y0 + mrow0, x0 + r, h, nsel, lane);
+        for (int s2 = 0; s2 < n2; ++s2) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ef.px[0][m][kk]), __builtin_bit_cast(bf16x8_t, ef.w[0][kk]), acc[m], 0, 0, 0);
+            asm volatile("" ::: "memory");                         // (the next slice's loads stay behind these MFMAs: one set of fragment registers)
+            if (s2 + 1 < n2) extra_load<MM, NT, 1>(ef, a, s2 + 1, b, y0 + mrow0, x0 + r, h, nsel, lane);
+        }
+        asm volatile("" ::: "memory");                             // (the patch staging registers are not live beside the fragment set)
+    }
     load_patch(0);
     store_patch(0);
     __syncthreads();
     PATCH_STAMP();
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane;               // fragment block = 64 lanes x 16 B
-    for (int s = 0; s < nall; ++s) {
+    for (int s = 0; s < nslices; ++s) {
         const char* P = smem + (s & 1) * PBYTES;
-        if (s + 1 < nall) load_patch(s + 1);
-        if (EXTRA && s >= nslices) {                               // a slice of the second source: the centre tap against the 1x1 fragments
-            const u32x4_t* w2 = (const u32x4_t*)a.wp2 + lane + (long)(s - nslices) * 2 * NT * 64;
-            u32x4_t b2[2], fa[MM][2];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) b2[kk] = w2[(kk * NT + nsel) * 64];
-#pragma unroll
-            for (int m = 0; m < MM; ++m) {
-                const int p = (mrow0 + m + PAD) * PW + PAD + r;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
-            }
-#pragma unroll
-            for (int m = 0; m < MM; ++m)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]), __builtin_bit_cast(bf16x8_t, b2[kk]), acc[m], 0, 0, 0);
-            PATCH_STAMP();
-            if (s + 1 < nall) store_patch((s + 1) & 1);
-            __syncthreads();
-            PATCH_STAMP();
-            continue;
-        }
+        if (s + 1 < nslices) load_patch(s + 1);
         const u32x4_t* wsl = wl + (long)s * TAPS * 2 * NT * 64;
         // weight fragments come straight from L2 (hundreds of cycles): keep PD taps in flight in a register ring
         constexpr int PD = TAPS < 4 ? TAPS : 4;
@@ -197,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
             }
         }
         PATCH_STAMP();
-        if (s + 1 < nall) store_patch((s + 1) & 1);
+        if (s + 1 < nslices) store_patch((s + 1) & 1);
         __syncthreads();
         PATCH_STAMP();
     }
@@ -270,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
 //     the tile is staged with 16 ds_write_b64 per thread instead of 64 two-byte writes that all fell on two LDS banks.
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
-template <int K, int NT, bool TALL, bool R1 = false, bool ACC = false>
+template <int K, int NT, bool TALL, bool R1 = false, bool ACC = false, bool EXTRA = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
     static_assert(!R1 || K == 3, "the rank-1 term is a 3x3 stencil");
@@ -398,6 +416,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 
     PATCH_STAMP_DECL;
     PATCH_STAMP();
+    ExtraFrags<EXTRA ? MM : 1, 2> ef;
+    if constexpr (EXTRA) extra_load<MM, NT, 2>(ef, a, 0, b, y0 + mrow0, x0 + r, h, nsel, lane);
     dma_patch(0, 0);
     // weight fragments: block (slice, tap, kk, nt) of 64 lanes x 16 B, straight from L2
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane + nsel * 64;
@@ -418,6 +438,19 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     __syncthreads();
     PATCH_STAMP();
     rank1_step();
+    if constexpr (EXTRA) {                                         // second K source (see extra_load; this form's MFMA takes the weights first)
+        const int n2 = (a.C2 + 31) >> 5;
+        for (int s2 = 0; s2 < n2; s2 += 2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int m = 0; m < MM; ++m)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ef.w[q][kk]), __builtin_bit_cast(bf16x8_t, ef.px[q][m][kk]), acc[m], 0, 0, 0);
+            if (s2 + 2 < n2) extra_load<MM, NT, 2>(ef, a, s2 + 2, b, y0 + mrow0, x0 + r, h, nsel, lane);
+        }
+    }
 
     constexpr int WR = MM + 1;                                     // window rows in registers
     u32x4_t win[WR][2];
@@ -956,17 +989,21 @@ int mte_conv2d_patch_fwd_plus1x1(const void* x, long ldx, const void* wpatch, co
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!x || !wpatch || !y || !x2 || !wpatch2 || C2 < 8 || C2 % 8 != 0 || !patch_shape_ok(W, Cin_p, N, 3, 3)) return MTE_ERR_ARG;
     PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, nullptr, nullptr, 0, (const bf16_t*)x2, ldx2, (const bf16_t*)wpatch2, C2};
+    const bool v2 = g_patch_fwd2 && (N <= 32 || Cin_p > 64) && (((long)B * H * W - 1) * ldx + Cin_p) * 2 < 0x7ff00000L && ((uintptr_t)bias & 15) == 0;   // (as launch_fwd)
     if (N <= 32) {
         if (g_patch_tall && H >= 16) {
             const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
-            hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         } else {
             const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-            hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         }
     } else {
         const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-        hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
     }
     return mte_check_launch();
 }

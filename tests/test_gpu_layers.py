@@ -392,7 +392,7 @@ def test_residual_conv_with_the_shortcut_gradient_folded_into_conv1s(cin, cout, 
     assert torch.equal(got[0], ref[0])
     assert rel_err(got[1], ref[1]) < 1e-2                     # (bf16: one rounding of the 1x1 term fewer)
     for a, b in zip(got[2:], ref[2:]):                          # (GroupNorm's dgamma / dbeta add per-sample parts with fp32 atomics: equal to rounding, not bitwise)
-        assert rel_err(a, b) < 1e-5
+        assert rel_err(a, b) < 2e-4
 
 
 def test_deferred_shortcut_gradient_is_flushed_when_no_conv_carries_it():
