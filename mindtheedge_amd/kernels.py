@@ -1204,6 +1204,31 @@ def _deliver(p, t):
     return t
 
 
+def _claim_adjacent(*params):
+    """ONE flat fp32 destination over the sink views of `params` when they lie back to back in the flat gradient buffer (a layer's weight and bias do), else
+    None.  A kernel that produces [dW; db] as one record then writes it in place: a `_deliver` copy is a hipMemcpyAsync = one or two blit kernels of ~4 us
+    each, and a training step issued ~90 of them (0.4 ms of queue time; round 4, tools/copy_neighbours.sh).  The caller announces them with _announce()."""
+    sk = _sink["active"]
+    if sk is None:
+        return None
+    views = [sk.lookup(p) for p in params]
+    if any(v is None or not v.is_contiguous() or v.dtype != torch.float32 for v in views):
+        return None
+    ptr = views[0].data_ptr()
+    for v in views:
+        if v.data_ptr() != ptr:
+            return None
+        ptr += 4 * v.numel()
+    for p in params:
+        sk.claim(p)
+    return views[0].as_strided((sum(v.numel() for v in views),), (1,))
+
+
+def _announce(*params):
+    for p in params:
+        _sink["active"].ready(p)
+
+
 def _all_sunk(*params):
     sk = _sink["active"]
     return sk is not None and all(sk.lookup(p) is not None for p in params)
@@ -1216,8 +1241,12 @@ def _conv3d_weight_grads(kernel, x, dout, w3, b3):
     def run():
         dop, ldo = _pl(dout)
         xp, ldx = _pl(x)
-        dwb = torch.empty((112,), dtype=torch.float32, device=x.device)
+        dst = _claim_adjacent(w3, b3)                       # (the record [dW3 (108); db3 (4)] straight into the flat gradient buffer when the two views are adjacent)
+        dwb = dst if dst is not None else torch.empty((112,), dtype=torch.float32, device=x.device)
         kernel(xp, ldx, dop, ldo, dwb.data_ptr(), B, H, W, C, _dt(x), _stream())
+        if dst is not None:
+            _announce(w3, b3)
+            return None, None
         return _deliver(w3, dwb[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dwb[108:112])
 
     if _side["enabled"] and _all_sunk(w3, b3):
@@ -1337,7 +1366,9 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         B, C, H, W, co, k = ctx.geom
         H2, W2, pad, hb = H // 2, W // 2, k // 2, 2 * (k // 2) + 1
         dt, dev = _dt(P), P.device
-        dy, _, dgamma, dbeta = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False)
+        gg, sg = _grad_dst(gamma, zero=True)
+        gbt, sbt = _grad_dst(beta, zero=True)
+        dy, _, dgamma, dbeta = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, dgamma=gg, dbeta=gbt)
         # ---- band paths (unfolded, exact), beside the interior path
         bands = _BandChain()
         with bands:
@@ -1366,9 +1397,14 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
             bands.join()                                       # (on the stream that runs the weight gradients: they read dTs / dyb)
             sw = _stream()
             dw_band = db_band = None
-            dk3b = torch.zeros((112,), dtype=torch.float32, device=dev)
+            # (round 4) the parameter gradients are formed IN their places in the flat gradient buffer where the sink hands them out (zero after zero_grad):
+            # the four `_deliver` copies of this layer were eight ~4 us blit kernels
+            dst3 = _claim_adjacent(w3, b3)
+            dk3b = dst3 if dst3 is not None else torch.zeros((112,), dtype=torch.float32, device=dev)
+            gw_dst, gw_sunk = _grad_dst(w)
+            gb_dst, gb_sunk = _grad_dst(b)
             for xb, T, dyb, dT in ((xb1, T1, dyb1, dTs[0]), (xb2, T2, dyb2, dTs[1])):
-                dwi, dbi = _conv_wgrad(T, dyb, w, True, None, None)
+                dwi, dbi = _conv_wgrad(T, dyb, w, True, gw_dst if dw_band is None else None, None)
                 dw_band = dwi if dw_band is None else dw_band.add_(dwi)
                 db_band = dbi if db_band is None else db_band.add_(dbi)
                 Bb, _, hx, wx = xb.shape
@@ -1380,8 +1416,13 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
             dWf, dbf = _conv_wgrad(P, dy, Wf, True, None, None)
             lib.mte_unfold_pack_wgrad(dWf.data_ptr(), dbf.data_ptr(), w.detach().data_ptr(), w3c.data_ptr(), b3c.data_ptr(),
                                       dw_band.data_ptr(), dk3b.data_ptr(), co, 4 * C, k, 1, sw)
-            db = dbf.add_(db_band)
-            return (_deliver(w3, dk3b[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dk3b[108:112]), _deliver(w, dw_band), _deliver(b, db))
+            db = torch.add(dbf, db_band, out=gb_dst)
+            if dst3 is not None:
+                _announce(w3, b3)
+                g3 = gb3 = None
+            else:
+                g3, gb3 = _deliver(w3, dk3b[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dk3b[108:112])
+            return (g3, gb3, _grad_ret(w, dw_band, gw_sunk), _grad_ret(b, db, gb_sunk))
 
         if _side["enabled"] and _all_sunk(w3, b3, w, b):
             with torch.cuda.stream(_side_stream_for(P, dy, T1, T2, dyb1, dyb2, dTs[0], dTs[1], xb1, xb2, Wf)):
@@ -1397,7 +1438,7 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
         # (the four bands overlap in the corners: two launches so that no element is read-modified by two operations at once)
         _rects([(dxb[0][:B], 0, 0, dx, 0, 0, 2 * hb, W, 1), (dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, 1)])
         _rects([(dxb[1][:B], 0, 0, dx, 0, 0, H, 2 * hb, 1), (dxb[1][B:], 0, 0, dx, 0, W - 2 * hb, H, 2 * hb, 1)])
-        return (dx, g3, gb3, gw, gb, _deliver(gamma, dgamma), _deliver(beta, dbeta), None, None, None)
+        return (dx, g3, gb3, gw, gb, _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sbt), None, None, None)
 
 
 class InvDepthFn(torch.autograd.Function):
@@ -1429,9 +1470,13 @@ class InvDepthFn(torch.autograd.Function):
 
         def weight_grads():
             xp, ldx = _pl(x)
-            dwb = torch.empty((C * 9 + 1,), dtype=torch.float32, device=x.device)
+            dst = _claim_adjacent(w, b) if tuple(w.shape) == (1, C, 3, 3) and b.numel() == 1 else None
+            dwb = dst if dst is not None else torch.empty((C * 9 + 1,), dtype=torch.float32, device=x.device)
             rec = torch.empty((int(lib.mte_invdepth_bwd_weight_workspace_elems(C)),), dtype=torch.float32, device=x.device)
             lib.mte_invdepth_bwd_weight(xp, ldx, dlogit.data_ptr(), dwb.data_ptr(), rec.data_ptr(), B, H, W, C, _dt(x), _stream())
+            if dst is not None:
+                _announce(w, b)
+                return None, None
             return _deliver(w, dwb[:C * 9].view(1, C, 3, 3)), _deliver(b, dwb[C * 9:])
 
         if _side["enabled"] and _all_sunk(w, b):
