@@ -1586,7 +1586,9 @@ extern "C" {
 extern "C" int mtei_set_pack3d_lds(int value);
 extern "C" int mtei_set_gn(int which, int value);
 extern "C" int mtei_set_patch_tall(int v);
+extern "C" int mtei_set_head_mfma(int v);
 int mte_debug_set(int key, int value) {
+    if (key == 30) return mtei_set_head_mfma(value);
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
     if (key == 1) return mtei_set_pack3d_lds(value);
     if (key == 2 || key == 3) return mtei_set_gn(key - 2, value);

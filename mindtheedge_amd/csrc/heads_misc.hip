@@ -134,6 +134,95 @@ __global__ __launch_bounds__(256) void invdepth_fwd_kernel(HeadArgs a) {
     }
 }
 
+
+// ---- InvDepth head forward on the matrix cores (round 4, bf16 activations, C % 32 == 0) -----------------------------------------------------------
+// The row-marching kernel above spends C * 9 fp32 multiply-adds per pixel on the VALU (2.3 TB/s on the full-resolution head).  As a GEMM the head is 9 rows
+// (taps) x C x pixels: too few rows for a tile, but per INPUT row r and tap column kx
+//     D[ky][x] += sum_c w[c][ky][kx] * in[r][x + kx - 1][c]          (one v_mfma_f32_16x16x32_bf16 per 32 channels: 3 of its 16 rows used)
+// is the contribution of input row r to output row r + 1 - ky at column x: three accumulating MFMAs (kx = 0, 1, 2) whose pixel operand is the SAME 16-byte
+// chunk of global memory at a shifted pixel -- a 1x1-like operand: lane (pixel, 8-channel block) loads it straight from global memory, no LDS.  A wave owns a
+// 16-pixel column group and marches down its rows: lanes 0..15 hold D[0..2] of their pixel, out[y] = D_{y-1}[2] + D_y[1] + D_{y+1}[0] slides through three
+// registers.  Weights as bf16 hi + lo pairs (two MFMAs per step): the head's weights stay fp32-accurate as in the VALU kernel.
+template <int CS, bool PF>                                          // CS = C / 32; PF: an input row's chunks are loaded one row ahead of their MFMAs
+__global__ __launch_bounds__(256) void invdepth_fwd_mfma_kernel(HeadArgs a, int rows_per_wg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, kb = lane >> 4;                      // operand column / row index, 8-channel block of the 32-channel K-step
+    const int gx = (a.W + 63) >> 6, gy = (a.H + rows_per_wg - 1) / rows_per_wg;
+    int id = blockIdx.x;
+    const int tx = id % gx; id /= gx;
+    const int ty = id % gy; const int b = id / gy;
+    const int x = tx * 64 + wave * 16 + px;                        // this lane's pixel column (as the pixel operand's column and as the result's column)
+    const int y0 = ty * rows_per_wg, y1 = min(a.H, y0 + rows_per_wg);
+    // weight operand: lane (row i = px -> ky = i (i < 3), K block kb): w[c][ky][kx] for c = 32 s + 8 kb + j, as bf16 hi / lo.  The workgroup converts the
+    // 9 C weights once into fragment order in LDS (as 24 CS strided loads + conversions per LANE the prologue cost more than the rows of a short workgroup)
+    __shared__ __attribute__((aligned(16))) bf16_t s_w[3 * CS * 2 * 64 * 8];
+    for (int e = threadIdx.x; e < 9 * 32 * CS; e += 256) {
+        const int c = e / 9, tap = e - c * 9, ky = tap / 3, kx = tap - ky * 3;
+        const float f = a.w[e];
+        const bf16_t hi = f2bf(f);
+        const bf16_t lo = f2bf(f - bf2f(hi));
+        const int sl = c >> 5, kbl = (c >> 3) & 3, j = c & 7;
+        const int at = (((kx * CS + sl) * 2) * 64 + kbl * 16 + ky) * 8 + j;
+        s_w[at] = hi; s_w[at + 64 * 8] = lo;
+    }
+    __syncthreads();
+    if (tx * 64 + wave * 16 >= a.W) return;
+    u32x4_t wh[3][CS], wl[3][CS];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            const u32x4_t vh = *(const u32x4_t*)(s_w + (((kx * CS + s) * 2) * 64 + lane) * 8);
+            const u32x4_t vl = *(const u32x4_t*)(s_w + (((kx * CS + s) * 2 + 1) * 64 + lane) * 8);
+            wh[kx][s] = px < 3 ? vh : u32x4_t{0u, 0u, 0u, 0u};
+            wl[kx][s] = px < 3 ? vl : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    const float bias = a.bias[0];
+    const bf16_t* img = (const bf16_t*)a.x + (long)b * a.H * a.W * a.ldx + 8 * kb;
+    float* out = a.out + (long)b * a.H * a.W;
+    float o_prev = 0.f, o_cur = 0.f;                               // partial sums of output rows r - 1 and r while input row r is being added
+    // the three shifted chunks of an input row, loaded one row AHEAD of their MFMAs (clamped addresses, values outside the image selected to zero)
+    const int xs[3] = {x - 1, x, x + 1};
+    const bool xok[3] = {(unsigned)(x - 1) < (unsigned)a.W, (unsigned)x < (unsigned)a.W, (unsigned)(x + 1) < (unsigned)a.W};
+    u32x4_t nxt[3][CS];
+    auto load_row = [&](int r) {
+        const bool rok = (unsigned)r < (unsigned)a.H;
+        const long row = (long)(rok ? r : 0) * a.W;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const bf16_t* q = img + (row + (xok[kx] ? xs[kx] : 0)) * a.ldx;
+#pragma unroll
+            for (int s = 0; s < CS; ++s) {
+                const u32x4_t v = *(const u32x4_t*)(q + 32 * s);
+                nxt[kx][s] = (rok && xok[kx]) ? v : u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    if constexpr (PF) load_row(y0 - 1);
+    for (int r = y0 - 1; r <= y1; ++r) {
+        if constexpr (!PF) load_row(r);
+        u32x4_t in[3][CS];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int s = 0; s < CS; ++s) in[kx][s] = nxt[kx][s];
+        if constexpr (PF) { if (r < y1) load_row(r + 1); }
+        f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int s = 0; s < CS; ++s) {
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wh[kx][s]), __builtin_bit_cast(bf16x8_t, in[kx][s]), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wl[kx][s]), __builtin_bit_cast(bf16x8_t, in[kx][s]), d, 0, 0, 0);
+            }
+        // lanes 0..15 (kb = 0): d[ky] = contribution of input row r to output row r + 1 - ky at their pixel
+        const float done = o_prev + d[2];                          // output row r - 1 is complete
+        if (kb == 0 && r - 1 >= y0 && r - 1 < y1 && x < a.W) out[(long)(r - 1) * a.W + x] = a.inv_min_depth / (1.f + __expf(-(done + bias)));
+        o_prev = o_cur + d[1];
+        o_cur = d[0];
+    }
+}
+
 // dlogit = dout * d(inv)/d(logit), inv = s/(1+e^-z) with s = 1/min_depth: d inv / dz = inv * (1 - inv/s)
 __global__ void invdepth_dlogit_kernel(const float* __restrict__ dout, const float* __restrict__ inv, float* __restrict__ dl, long n, float s) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -657,6 +746,7 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __res
 }
 
 inline int stream_grid(long n, int per = 256) { long g = (n + per - 1) / per; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+int g_head_mfma = 1;                                 // development knob (mte_debug_set(30, v)): 0 = the VALU row-marching head forward
 inline bool head_ok(int C) { const int cb = C >> 3; return C % 8 == 0 && cb >= 1 && cb <= 64 && (cb & (cb - 1)) == 0; }
 inline long head_strips(int B, int H, int W, int C) {               // strips of the row-marching head kernels (see HEAD_MAP)
     const int pxw = 256 / (C >> 3);
@@ -682,6 +772,10 @@ constexpr int HEAD_WGRAD_MAX_BLOCKS = 1024;
 
 }  // namespace
 
+#ifdef MTE_DEV
+extern "C" int mtei_set_head_mfma(int v) { g_head_mfma = v; return MTE_OK; }
+#endif
+
 extern "C" {
 
 int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias, float* out,
@@ -693,6 +787,31 @@ int mte_invdepth_fwd(const void* x, long ldx, const float* w, const float* bias,
     // one workgroup per strip: workgroups are dispatched in order, so the ones running together walk down horizontally ADJACENT strips and
     // DRAM sees whole image rows requested at once (balanced strip ranges over the resident workgroups -- kept for the weight gradient, whose
     // per-workgroup record must stay small in number -- measured 6 % slower here: 118 vs 111 us on the full-resolution head)
+    // matrix-core form for 32 / 64 / 128 channels (same-box: 102 -> 54 us, 57 -> 48 us, 40 -> 28 us; with 256 channels the weight fragments alone are 384 VGPRs and the
+    // VALU kernel wins 25 vs 36 us).  Workgroup = 64 pixel columns x `rows` rows (4 waves of 16 columns); rows per workgroup and the row prefetch by measurement
+    // (tools/head_bench.py): 32 rows, no prefetch for one K-step per tap column; prefetch from two K-steps on; 16 rows at 128 channels (240 workgroups at 96 x 320)
+    if (dtype == MTE_DT_BF16 && g_head_mfma && C % 32 == 0 && C <= ((g_head_mfma & 2) ? 256 : 128) && ldx % 8 == 0) {
+        int rows = C >= 128 ? 16 : 32;
+        bool pf = C >= 64;
+        if (g_head_mfma != 1) {                                     // (development: bit 2 = prefetch, bits 8.. = rows per workgroup)
+            pf = (g_head_mfma & 4) != 0;
+            if (g_head_mfma >> 8) rows = g_head_mfma >> 8;
+        }
+        const long g2 = (long)((W + 63) / 64) * ((H + rows - 1) / rows) * B;
+        if (g2 <= 0x7fffffffL) {
+#define MTE_HEAD_LAUNCH(CS_)                                                                                                              \
+            if (pf) hipLaunchKernelGGL((invdepth_fwd_mfma_kernel<CS_, true>), dim3((unsigned)g2), dim3(256), 0, stream, a, rows);       \
+            else hipLaunchKernelGGL((invdepth_fwd_mfma_kernel<CS_, false>), dim3((unsigned)g2), dim3(256), 0, stream, a, rows);         \
+            return mte_check_launch();
+            switch (C / 32) {
+                case 1: { MTE_HEAD_LAUNCH(1) }
+                case 2: { MTE_HEAD_LAUNCH(2) }
+                case 4: { MTE_HEAD_LAUNCH(4) }
+                case 8: { MTE_HEAD_LAUNCH(8) }
+            }
+#undef MTE_HEAD_LAUNCH
+        }
+    }
     const long grid = head_strips(B, H, W, C);
     if (grid > 0x7fffffffL) return MTE_ERR_UNSUPPORTED;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_fwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, a);

@@ -415,3 +415,35 @@ def test_deferred_shortcut_gradient_is_flushed_when_no_conv_carries_it():
     wq = sc.weight.detach().to(torch.bfloat16).float()
     (torch.nn.functional.conv2d(xr.to(torch.bfloat16).float(), wq, sc.bias.detach()) * G).sum().backward()
     assert rel_err(xa.grad.float().cpu(), (xr.grad + 0.5).cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 20, 80), (32, 1, 9, 50), (64, 1, 12, 36), (128, 2, 6, 16), (256, 1, 5, 24), (32, 1, 40, 130)])
+def test_inv_depth_head_forward_on_mfma_matches_the_valu_kernel(C, B, H, W):
+    """mte_invdepth_fwd (reference layers01.py:99-123: sigmoid(conv3x3(x)) / min_depth): the matrix-core form (three accumulating 16x16x32 MFMAs per input row,
+    bf16 hi + lo weights, operands straight from global memory) against the fp32-VALU row-marching kernel on the same bf16 activations, and against torch;
+    widths that are not multiples of 16 / 64, heights that are not multiples of the row block, image borders."""
+    from conftest import kernel_variant
+    from mindtheedge_amd import kernels as K
+    g = torch.Generator().manual_seed(C + H + W)
+    x = K.image_to_act((torch.rand(B, C, H, W, generator=g) * 2 - 1).cuda())
+    w = ((torch.rand(1, C, 3, 3, generator=g) * 2 - 1) * (3.0 / (C * 9)) ** 0.5 * 4).cuda()
+    b = (torch.rand(1, generator=g) - 0.5).cuda()
+    xp, ldx = K._pl(x)
+
+    def run():
+        out = torch.full((B, H, W), float("nan"), device="cuda")
+        K.lib.mte_invdepth_fwd(xp, ldx, w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, C, 0.5, K.DT_BF16, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    got = run()
+    with kernel_variant(30, 0, 1):
+        ref = run()
+    tor = (torch.sigmoid(torch.nn.functional.conv2d(x.float().contiguous(), w, b, padding=1)) / 0.5)[:, 0].cpu()
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < 2e-5                      # fp32 sums of the same products (weights split exactly into bf16 hi + lo up to 2^-17), other order
+    assert rel_err(got, tor) < 2e-5 + rel_err(ref, tor)
+    for knob in (2 + (8 << 8), 6 + (4 << 8)):            # every channel count on the matrix cores, without / with the row prefetch, short row blocks
+        with kernel_variant(30, knob, 1):
+            v = run()
+        assert torch.isfinite(v).all() and rel_err(v, ref) < 2e-5, knob
