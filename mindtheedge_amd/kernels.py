@@ -1205,9 +1205,10 @@ def _deliver(p, t):
 
 
 def _claim_adjacent(*params):
-    """ONE flat fp32 destination over the sink views of `params` when they lie back to back in the flat gradient buffer (a layer's weight and bias do), else
-    None.  A kernel that produces [dW; db] as one record then writes it in place: a `_deliver` copy is a hipMemcpyAsync = one or two blit kernels of ~4 us
-    each, and a training step issued ~90 of them (0.4 ms of queue time; round 4, tools/copy_neighbours.sh).  The caller announces them with _announce()."""
+    """ONE flat fp32 destination over the sink views of `params` when they lie back to back in the flat gradient buffer, else None.  A kernel that produces
+    [dW; db] as one record then writes it in place instead of two `_deliver` copies (hipMemcpyAsync = a blit kernel of ~4 us each).  NOTE: FlatParameters' default
+    layout (64-element alignment, reverse registration order) does not put a layer's weight and bias back to back, so with the shipped trainer this returns None and
+    the records are delivered by copies (profiles/r04_late_steps.txt, 9); a flat buffer built with align=1, reverse=False qualifies.  The caller announces with _announce()."""
     sk = _sink["active"]
     if sk is None:
         return None

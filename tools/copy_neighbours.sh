@@ -12,13 +12,20 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 byq = collections.defaultdict(list)
 for r in rows:
     byq[r["Queue_Id"]].append(r)
-pairs = collections.Counter()
+bursts = collections.Counter()
 for q, rs in byq.items():
-    for i, r in enumerate(rs):
-        if "copyBuffer" in r["Kernel_Name"]:
-            prev = rs[i - 1]["Kernel_Name"][:60] if i else "-"
-            nxt = rs[i + 1]["Kernel_Name"][:60] if i + 1 < len(rs) else "-"
-            pairs[(prev, nxt)] += 1
-for (p, n), c in pairs.most_common(40):
-    print("%5.1f/step  after %-62s before %s" % (c / 7.0, p, n))
+    i = 0
+    while i < len(rs):
+        if "copyBuffer" in rs[i]["Kernel_Name"]:
+            j = i
+            while j < len(rs) and "copyBuffer" in rs[j]["Kernel_Name"]:
+                j += 1
+            prev = rs[i - 1]["Kernel_Name"][:70] if i else "-"
+            nxt = rs[j]["Kernel_Name"][:70] if j < len(rs) else "-"
+            bursts[(q, prev, j - i, nxt)] += 1
+            i = j
+        else:
+            i += 1
+for (q, p, n, nx), c in sorted(bursts.items(), key=lambda kv: -kv[1] * kv[0][2])[:40]:
+    print("queue %s  %4.1f x/step  burst of %2d  after %-72s before %s" % (q, c / 7.0, n, p, nx))
 PY
