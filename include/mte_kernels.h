@@ -209,6 +209,9 @@ int mte_nchw_to_nhwc(const float* src, void* dst, long ldd, int B, int C, int H,
 int mte_upsample_inv_fwd(const float* inv, void* dst, long ldd, int B, int h, int w, int dtype, mte_stream_t stream);
 int mte_upsample_inv_bwd(const void* dsrc, long lds_, float* dinv, int B, int h, int w, int accumulate, int dtype, mte_stream_t stream);
 int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix, int C, int dtype, mte_stream_t stream);
+/* a [dW; db] record (conv3d weight gradients, the heads' weight gradients) into its two places of a flat gradient buffer in one launch:
+ * dst0[0..n0) = src[0..n0), dst1[0..n1) = src[n0..n0+n1) */
+int mte_split_record(const float* src, float* dst0, int n0, float* dst1, int n1, mte_stream_t stream);
 /* out = a + b over NHWC channel-slice views: the summed gradient of an activation with two consumers (what autograd's
  * implicit accumulation does in the reference), one 16-byte-vectorised pass whatever the strides */
 int mte_add_channels(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long npix, int C, int dtype, mte_stream_t stream);

@@ -645,6 +645,14 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, long lds_, T* __
     }
 }
 
+// a [dW; db] record delivered to its two places in the flat gradient buffer by ONE launch (two hipMemcpyAsync = two blit kernels of ~4 us each and two runtime calls)
+__global__ void split_record_kernel(const float* __restrict__ src, float* __restrict__ d0, int n0, float* __restrict__ d1, int n1) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += gridDim.x * blockDim.x) {
+        const float v = src[i];
+        if (i < n0) d0[i] = v; else d1[i - n0] = v;
+    }
+}
+
 // out = a + b on channel-slice views (fp32 sum, rounded once): the gradient of a tensor with two consumers
 template <typename T>
 __global__ void add_channels_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, T* __restrict__ out, long ldo,
@@ -939,6 +947,16 @@ int mte_copy_channels(const void* src, long lds_, void* dst, long ldd, long npix
     const int grid = stream_grid(npix * (C / per16));
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, npix, C);
     else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)src, lds_, (float*)dst, ldd, npix, C);
+    return mte_check_launch();
+}
+
+// dst0[0..n0) = src[0..n0), dst1[0..n1) = src[n0..n0+n1): a layer's (weight gradient, bias gradient) record into the two views of a flat gradient buffer
+int mte_split_record(const float* src, float* dst0, int n0, float* dst1, int n1, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!src || !dst0 || !dst1 || n0 < 0 || n1 < 0) return MTE_ERR_ARG;
+    if (n0 + n1 == 0) return MTE_OK;
+    const int grid = (n0 + n1 + 255) / 256 < 64 ? (n0 + n1 + 255) / 256 : 64;
+    hipLaunchKernelGGL(split_record_kernel, dim3(grid), dim3(256), 0, stream, src, dst0, n0, dst1, n1);
     return mte_check_launch();
 }
 

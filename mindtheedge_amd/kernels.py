@@ -1204,6 +1204,21 @@ def _deliver(p, t):
     return t
 
 
+def _deliver_pair(w, b, rec, nw):
+    """(dW, db) = (rec[:nw], rec[nw:]) handed to the sink by ONE launch when both parameters have a view there (mte_split_record), else by _deliver"""
+    sk = _sink["active"]
+    if sk is not None:
+        vw, vb = sk.lookup(w), sk.lookup(b)
+        if vw is not None and vb is not None and vw.is_contiguous() and vb.is_contiguous() and vw.numel() == nw and vb.numel() == rec.numel() - nw:
+            sk.claim(w)
+            sk.claim(b)
+            lib.mte_split_record(rec.data_ptr(), vw.data_ptr(), nw, vb.data_ptr(), rec.numel() - nw, _stream())
+            sk.ready(w)
+            sk.ready(b)
+            return None, None
+    return _deliver(w, rec[:nw].view(w.shape)), _deliver(b, rec[nw:])
+
+
 def _claim_adjacent(*params):
     """ONE flat fp32 destination over the sink views of `params` when they lie back to back in the flat gradient buffer, else None.  A kernel that produces
     [dW; db] as one record then writes it in place instead of two `_deliver` copies (hipMemcpyAsync = a blit kernel of ~4 us each).  NOTE: FlatParameters' default
@@ -1248,7 +1263,7 @@ def _conv3d_weight_grads(kernel, x, dout, w3, b3):
         if dst is not None:
             _announce(w3, b3)
             return None, None
-        return _deliver(w3, dwb[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dwb[108:112])
+        return _deliver_pair(w3, b3, dwb, 108)
 
     if _side["enabled"] and _all_sunk(w3, b3):
         with torch.cuda.stream(_side_stream_for(x, dout)):
@@ -1422,7 +1437,7 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
                 _announce(w3, b3)
                 g3 = gb3 = None
             else:
-                g3, gb3 = _deliver(w3, dk3b[:108].view(4, 1, 3, 3, 3)), _deliver(b3, dk3b[108:112])
+                g3, gb3 = _deliver_pair(w3, b3, dk3b, 108)
             return (g3, gb3, _grad_ret(w, dw_band, gw_sunk), _grad_ret(b, db, gb_sunk))
 
         if _side["enabled"] and _all_sunk(w3, b3, w, b):
@@ -1478,7 +1493,7 @@ class InvDepthFn(torch.autograd.Function):
             if dst is not None:
                 _announce(w, b)
                 return None, None
-            return _deliver(w, dwb[:C * 9].view(1, C, 3, 3)), _deliver(b, dwb[C * 9:])
+            return _deliver_pair(w, b, dwb, C * 9)
 
         if _side["enabled"] and _all_sunk(w, b):
             with torch.cuda.stream(_side_stream_for(x, dlogit)):
