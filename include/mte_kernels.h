@@ -55,7 +55,21 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
 /* MTE_OPT_LOSS_PREZEROED (1): when 1, `work` of mte_edge_loss_multi_fwd and `sums` of mte_edge_loss_fwd are zero on entry (first
  * mte_edge_loss_work_elems / _sums_elems doubles; same arena) and the launch's own fill is skipped. */
 #define MTE_OPT_LOSS_PREZEROED 1
+/* MTE_OPT_HANDOFF_FENCES (2), round 5: when 1, the last-arriver hand-offs of the read-only reduction kernels (mte_gn_stats, the fused loss
+ * forward) draw their arrival ticket behind an agent-scope RELEASE fence and the last arriver issues an agent-scope ACQUIRE before it reads
+ * the other workgroups' records.  Off, the protocol is the one MI355X_MICROARCH.md's visibility table lists as measured-valid: records by
+ * returning atomic exchanges (performed at the memory side), a drained wait, a relaxed agent-scope ticket, agent-scope atomic loads. */
+#define MTE_OPT_HANDOFF_FENCES 2
 int mte_set_option(int option, int value);
+/* Device error word, round 5.  Kernels whose workgroups wait for each other inside a launch (the GroupNorm cluster kernels) bound that wait;
+ * a wait that gives up sets a flag in one word of pinned host memory instead of going on silently with incomplete statistics.
+ * mte_device_error_init: allocate the word (once, outside stream capture).  mte_device_error_poll: -> flags set since the last poll
+ * (MTE_DEVERR_*; 0 = none) and clears them; no synchronisation -- the host polls once per training step and raises.
+ * (No reference counterpart: the reference's GroupNorm is one cuDNN call, layers01.py:32.) */
+#define MTE_DEVERR_GN_CLUSTER_FWD 1
+#define MTE_DEVERR_GN_CLUSTER_BWD 2
+int mte_device_error_init(void);
+int mte_device_error_poll(void);
 /* weight gradient of the same conv into dw_stage = `stage_parts` x [N][KH*KW][Cin_p] fp32 (overwritten).  The reduction over
  * pixels is split over at most stage_parts workgroup groups; each one stores its PARTIAL gradient in its own part (plain stores;
  * *parts_out = parts written, mte_unpack_conv_wgrad adds them in part order: round 4 -- no floating-point atomics on the conv weight
@@ -133,10 +147,24 @@ int mte_gn_fwd_is_single_pass_b(int B, int HW, int C, int has_y2, int dtype);
 int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats, int stats_ready,
                    const float* gamma, const float* beta, void* z, long ldz,
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
+/* mte_gn_elu_bwd: y2 = NULL with scale2 and d2 given (round 5, the backward of mte_gn_tail_fwd's outer norm): ONE input tensor, but the
+ * gradient leaves twice -- d1 = dv and d2 = scale2[b,c] * dv -- and dbias, if asked, is the column sum of d2. */
 int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
                    const double* stats, const float* gamma, const float* beta, float* red,
                    void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
+/* Round 5 -- the tail of a residual block in two launches: ResidualConv.forward's `self.activ(self.normalize(x_out + shortcut))` with
+ * x_out = conv2's GroupNorm + ELU applied on the fly (layers01.py:35-38 and :69-73).
+ *   y1 = conv2's CONVOLUTION output (+ bias), stats1 = its sums (mte_gn_stats), gamma1 / beta1 = conv2.normalize;
+ *   y2 = the 1x1 shortcut's output, scale2 = Dropout2d's keep / (1 - p) per (sample, channel) or NULL;
+ *   t  = ELU(GN(y1)) + scale2 * y2 -- an OUTPUT in the activation type, the tensor both backward norms need -- with its statistics in stats_t
+ *        (a statistics buffer, tickets zero at entry; bit-reproducible like mte_gn_stats);  z = ELU(GN_t(t)) with gamma_t / beta_t = the block's normalize.
+ * Against the four launches it replaces (mte_gn_elu_fwd of conv2, mte_gn_stats and mte_gn_elu_fwd over two tensors): 6 tensor passes instead of 8, and the
+ * backward of the outer norm reads one tensor instead of two in both of its passes. */
+int mte_gn_tail_fwd(const void* y1, long ld1, const double* stats1, const float* gamma1, const float* beta1,
+                    const void* y2, long ld2, const float* scale2, void* t, long ldt, double* stats_t,
+                    const float* gamma_t, const float* beta_t, void* z, long ldz,
+                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
 
 /* ---- 3-D packing / unpacking stencils: packing + nn.Conv3d(1,4,3,pad 1) (+ view / PixelShuffle)
  *      (layers01.py:127-149, 214-248 PackLayerConv3d; 251-287 UnpackLayerConv3d).  H,W,C describe x. */

@@ -25,7 +25,7 @@ RETURNS = {}
 # entry points that return a value (capability / size queries) instead of an error code
 QUERIES = ("mte_conv2d_patch_supported", "mte_conv2d_stem_supported", "mte_conv2d_patch_wgrad_supported", "mte_conv2d_patch_pack_elems", "mte_depth_metrics_workspace_bytes",
            "mte_chamfer_workspace_bytes", "mte_edge_loss_sums_elems", "mte_gn_fwd_is_single_pass", "mte_gn_fwd_is_single_pass_b",
-           "mte_edge_loss_work_elems", "mte_rank1_conv_bwd_records_elems", "mte_conv2d_patch_fwd_rank1_ok", "mte_gn_stats_elems", "mte_invdepth_bwd_weight_workspace_elems", "mte_sparse_site_list_workspace_elems")
+           "mte_edge_loss_work_elems", "mte_rank1_conv_bwd_records_elems", "mte_conv2d_patch_fwd_rank1_ok", "mte_gn_stats_elems", "mte_device_error_poll", "mte_invdepth_bwd_weight_workspace_elems", "mte_sparse_site_list_workspace_elems")
 
 
 def parse_header(path=HEADER, dev=False):
@@ -39,7 +39,7 @@ def parse_header(path=HEADER, dev=False):
     for m in re.finditer(r"\b(int|long)\s+(mte_\w+)\s*\(([^)]*)\)\s*;", text):
         RETURNS[m.group(2)] = ctypes.c_long if m.group(1) == "long" else ctypes.c_int
         args = []
-        for a in m.group(3).split(","):
+        for a in ([] if m.group(3).strip() in ("", "void") else m.group(3).split(",")):
             a = " ".join(a.split())
             if "*" in a:
                 args.append((ctypes.c_void_p, a.split("*")[-1].strip()))

@@ -98,6 +98,25 @@ extern int g_mte_gn_prezeroed;
 // the launch's own fill kernel is skipped.  Defined in edge_loss.hip.
 extern int g_mte_loss_prezeroed;
 
+// Device error word (mte_device_error_init / mte_device_error_poll, norm_act.hip): one 32-bit word of host-coherent pinned memory that every
+// kernel with a bounded inter-workgroup wait receives as an argument.  A wait that gives up ORs its code into the word (system scope) instead
+// of publishing numbers computed from records that never arrived; the host polls the word once per step and raises.  Null = not initialised
+// (the kernels then only give up).  Codes are bit flags so that several kernels of a step can report.
+#define MTE_DEVERR_GN_CLUSTER_FWD 1u
+#define MTE_DEVERR_GN_CLUSTER_BWD 2u
+#define MTE_DEVERR_GN_TAIL_FWD 4u
+extern unsigned* g_mte_err_dev;
+__device__ __forceinline__ void mte_report_device_error(unsigned* err, unsigned code) {
+    // (load | store rather than an atomic OR: the word lives in host memory and a lost flag of a second, simultaneous reporter does not matter --
+    //  any non-zero value fails the step)
+    if (err) __hip_atomic_store(err, __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// mte_set_option(MTE_OPT_HANDOFF_FENCES, v): the last-arriver hand-offs of the read-only kernels (GroupNorm statistics, loss sums) draw their
+// ticket with an agent-scope RELEASE and the last arriver issues an agent-scope ACQUIRE before it reads the records.  The records themselves
+// are returning atomic exchanges / agent-scope atomic loads (performed at the memory side, never served from a CU's L1), which is the form
+// MI355X_MICROARCH.md's visibility table lists as measured-valid; the fences make the protocol independent of that table.  Defined in norm_act.hip.
+extern int g_mte_handoff_fences;
+
 // GroupNorm statistics buffer of a batch of B samples, in doubles (mte_gn_stats_elems(B)):
 //   [0, 32 B)                       final (sum, sum of squares) per (sample, group): what every consumer reads
 //   [32 B, 32 B + round16(B))       arrival tickets of the statistics pass (one 32-bit counter per sample, 8 bytes apart; must be 0)

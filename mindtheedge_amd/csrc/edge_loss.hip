@@ -62,6 +62,7 @@ struct EdgeMulti {
     const float* gt_depth;              // optional fused silog on scale 0: metric depth, 0 = invalid
     float* silog_loss; float* silog_aux;          // forward out: loss, (mean, 10/sqrt(S)/n)
     const float* silog_gout;            // backward: upstream gradient of the silog loss (device, nullable = 1)
+    int fences;                         // MTE_OPT_HANDOFF_FENCES (common.hpp): release before each ticket, acquire in the last arriver
 };
 
 // 1 / x as v_rcp_f32 (1 ulp) + one Newton step: r' = r + r (1 - x r), the two fmas of the IEEE division sequence without its scaling and
@@ -232,7 +233,12 @@ __device__ __forceinline__ void forward_tail(const EdgeMulti& a, const BlockId& 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int per_image = sc.groups;                               // records (= workgroups) of this image
-    if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter + 1 + id.s * a.B + id.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(per_image - 1);
+    if (tid == 0) {
+        // (the kernel stores nothing but its records: a release fence here writes back no output lines of its own)
+        if (a.fences) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        s_last = __hip_atomic_fetch_add(a.counter + 1 + id.s * a.B + id.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(per_image - 1);
+        if (s_last && a.fences) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
     __syncthreads();
     if (!s_last) return;
     // ---- last workgroup of this (scale, sample): value v = tid % 16 of records k, k + 16, ... (k = tid / 16), then the 16 part sums in order
@@ -256,7 +262,11 @@ __device__ __forceinline__ void forward_tail(const EdgeMulti& a, const BlockId& 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) s_last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.nscales * a.B - 1);
+        if (tid == 0) {
+            if (a.fences) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            s_last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.nscales * a.B - 1);
+            if (s_last && a.fences) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
         __syncthreads();
         if (!s_last) return;
     }
@@ -1032,6 +1042,7 @@ extern "C" {
 // doubles of workspace for a forward launch over these scales: [nscales][B][13] sums + the arrival tickets + one 16-double record per workgroup
 long mte_edge_loss_work_elems(const void* scales, int nscales, int B) {
     EdgeMulti a{};
+    a.fences = g_mte_handoff_fences;
     const int blocks = setup_scales(a, (const mte_edge_scale_t*)scales, nscales, B, false);
     if (blocks < 0) return -1;
     return results_elems(nscales, B) + counter_elems(nscales, B) + (long)blocks * REC;
@@ -1044,6 +1055,7 @@ int mte_edge_loss_multi_fwd(const void* scales, int nscales, int B, int from_inv
                             float* silog_loss, float* silog_aux, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     EdgeMulti a{};
+    a.fences = g_mte_handoff_fences;
     const int blocks = setup_scales(a, (const mte_edge_scale_t*)scales, nscales, B, false);
     if (blocks < 0 || !work || !losses || !coef || (gt_depth && (!silog_loss || !silog_aux))) return MTE_ERR_ARG;
     if (gt_depth && !aligned16(gt_depth)) a.s[0].vec = 0;
@@ -1064,6 +1076,7 @@ int mte_edge_loss_multi_bwd(const void* scales, int nscales, int B, int from_inv
                             hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     EdgeMulti a{};
+    a.fences = g_mte_handoff_fences;
     const int blocks = setup_scales(a, (const mte_edge_scale_t*)scales, nscales, B, true);
     if (blocks < 0 || !coef || (gt_depth && !silog_aux)) return MTE_ERR_ARG;
     if (gt_depth && !aligned16(gt_depth)) a.s[0].vec = 0;
@@ -1089,6 +1102,7 @@ int mte_edge_loss_fwd(const float* pred, const float* edge, const float* normal,
     if (!pred || !edge || !sums) return MTE_ERR_ARG;
     mte_edge_scale_t one{pred, edge, normal, mask, gmap, nullptr, H, W};
     EdgeMulti a{};
+    a.fences = g_mte_handoff_fences;
     const int blocks = setup_scales(a, &one, 1, B, false);
     if (blocks < 0) return MTE_ERR_ARG;
     a.from_inv = from_inv; a.is_grad = is_grad; a.is_sigmoid = is_sigmoid; a.finalize = 0; a.thresh = thresh;

@@ -24,6 +24,9 @@
 #include "common.hpp"
 
 int g_mte_gn_prezeroed = 0;
+int g_mte_handoff_fences = 0;
+unsigned* g_mte_err_dev = nullptr;             // device address of the error word (mte_device_error_init)
+static volatile unsigned* g_mte_err_host = nullptr;
 
 namespace {
 
@@ -48,6 +51,10 @@ struct GnArgs {
     int cps_shift;                     // slab kernels: log2(chunks per pixel inside one group)
     int reverse;                       // stream kernels: walk the samples last-to-first (see gn_zigzag)
     int b0, nb, ppl;                   // cluster kernels: this launch covers samples [b0, b0 + nb), nb <= ppl = samples a full launch takes (8, 4, 2 or 1)
+    const double* stats_in;            // residual-tail kernel: the statistics of y1 (the inner GroupNorm's sums; `stats` receives those of the sum)
+    unsigned* err;                     // device error word (common.hpp) or null
+    int fences;                        // MTE_OPT_HANDOFF_FENCES
+    unsigned spin_max;                 // bound of the cluster kernels' arrival poll
 };
 
 // Pixel rows are processed in batches of GN_U: all 16-byte loads of a batch are issued before any of its stores, so a
@@ -104,6 +111,21 @@ template <bool HAS2> __device__ __forceinline__ void keep_packed(RawRow<HAS2>& r
     const int p_end = min(a.HW, p_begin + per_blk);                                \
     const int gs = a.C / GN_GROUPS;
 
+// The fp64 mean / rstd of the 16 groups of sample b are evaluated once per block and shared through LDS (per-thread
+// evaluation -- 8 fp64 divisions + square roots per thread -- used to dominate the short low-resolution launches).
+__device__ __forceinline__ void block_group_stats(const double* stats, const GnArgs& a, int b, int gs, float* s_mr) {
+    if (threadIdx.x < GN_GROUPS) {
+        const double* sp = stats + ((long)b * GN_GROUPS + threadIdx.x) * 2;
+        const double n = (double)a.HW * gs;
+        const double m = sp[0] / n;
+        double var = sp[1] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        s_mr[2 * threadIdx.x] = (float)m;
+        s_mr[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+}
+
 // Statistics pass.  Bit-reproducible by construction (GPUTEST_r02: the LDS / fp64 atomics this replaces made two forward passes
 // of the same frame differ by 1-2 % in inverse depth -- a one-ulp change of one statistic is amplified by ~60 bf16 layers):
 //   thread   : fp32 sums over its pixels of its 16-byte channel chunk (fixed order)
@@ -112,7 +134,12 @@ template <bool HAS2> __device__ __forceinline__ void keep_packed(RawRow<HAS2>& r
 //              performed at the memory side before the ticket is drawn) into this block's own slot
 //   sample   : the block that draws the last ticket of sample b adds the records in slot order -> stats[b][16][2]
 // Grid (blocks_per_sample <= MTE_GN_SLOTS(B), B), NT = 1024 threads so that <= 64 blocks per sample still fill the chip at B = 8.
-template <typename T, bool HAS2, int NT>
+//
+// TAIL = true (round 5): the residual block's tail (layers01.py:62-73).  y1 is the inner Conv2D's convolution output with statistics
+// `stats_in` and affine (gamma, beta); the kernel forms t = ELU(GN(y1)) + scale2 * y2 -- the sum the block normalises -- stores it (rounded to the
+// storage type) into z and takes the statistics of the STORED values: the inner layer's apply pass, the stand-alone statistics pass over two
+// tensors and the second tensor read of the outer apply / both backward passes are gone (see mte_gn_tail_fwd).
+template <typename T, bool HAS2, int NT, bool TAIL = false>
 __global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
     constexpr int P = Elem<T>::PER16;
     constexpr int NW = NT / 64;
@@ -134,6 +161,20 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
     for (int i = 0; i < P; ++i) { s[i] = 0.f; q[i] = 0.f; }
     float sc[P];
     if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    float ka[P], kb[P];
+    if constexpr (TAIL) {
+        static_assert(HAS2, "the tail adds a second tensor");
+        __shared__ float s_mr[GN_GROUPS * 2];
+        block_group_stats(a.stats_in, a, b, gs, s_mr);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int g = (ch0 + i) / gs;
+            const float mean = s_mr[2 * g], rstd = s_mr[2 * g + 1];
+            const float gm = a.gamma[ch0 + i];
+            ka[i] = rstd * gm;
+            kb[i] = a.beta[ch0 + i] - mean * rstd * gm;
+        }
+    }
     for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
         RawRow<HAS2> raw[GN_U];
 #pragma unroll
@@ -143,7 +184,16 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
         for (int u = 0; u < GN_U; ++u) {
             if (p + u * rstep >= p_end) break;
             float v[P];
-            finish_v<T, HAS2>(raw[u], sc, v);
+            if constexpr (TAIL) {
+                float w[P];
+                unpack16<T>(raw[u].c1, v);
+                unpack16<T>(raw[u].c2, w);
+#pragma unroll
+                for (int i = 0; i < P; ++i) v[i] = elu1(fmaf(v[i], ka[i], kb[i])) + w[i] * sc[i];
+                const u32x4_t pk = pack16<T>(v);
+                *(u32x4_t*)((T*)a.z + ((long)b * a.HW + p + u * rstep) * a.ldz + ch0) = pk;
+                unpack16<T>(pk, v);                        // the statistics of what every later pass reads back
+            } else finish_v<T, HAS2>(raw[u], sc, v);
 #pragma unroll
             for (int i = 0; i < P; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
         }
@@ -183,8 +233,17 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        // (TAIL writes its output through this XCD's L2: a release there would also write those lines back, per workgroup -- the records are
+        //  returning exchanges, at the memory side already, so the tail keeps the relaxed ticket whatever the option says)
+        if (a.fences && !TAIL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         const unsigned old = __hip_atomic_fetch_add(mte_gn_tickets(a.stats, a.B) + 2 * b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = old == gridDim.x - 1;
+        if (s_last) {
+            // the last arriver puts the ticket back: a statistics buffer can be used again without being cleared (MTE_OPT_GN_PREZEROED is
+            // then an optimisation of the FIRST use, not a precondition of every use)
+            __hip_atomic_store(mte_gn_tickets(a.stats, a.B) + 2 * b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.fences) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
     }
     __syncthreads();
     if (!s_last) return;
@@ -207,26 +266,11 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
     }
 }
 
-// The fp64 mean / rstd of the 16 groups of sample b are evaluated once per block and shared through LDS (per-thread
-// evaluation -- 8 fp64 divisions + square roots per thread -- used to dominate the short low-resolution launches).
-__device__ __forceinline__ void block_group_stats(const GnArgs& a, int b, int gs, float* s_mr) {
-    if (threadIdx.x < GN_GROUPS) {
-        const double* sp = a.stats + ((long)b * GN_GROUPS + threadIdx.x) * 2;
-        const double n = (double)a.HW * gs;
-        const double m = sp[0] / n;
-        double var = sp[1] / n - m * m;
-        if (var < 0.0) var = 0.0;
-        s_mr[2 * threadIdx.x] = (float)m;
-        s_mr[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
-    }
-    __syncthreads();
-}
-
 template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void gn_elu_fwd_kernel(GnArgs a) {
     GN_THREAD_MAP();
     __shared__ float s_mr[GN_GROUPS * 2];
-    block_group_stats(a, b, gs, s_mr);
+    block_group_stats(a.stats, a, b, gs, s_mr);
     float ka[P], kb[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -263,7 +307,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
     extern __shared__ float s_red[];                      // [C][2]
     __shared__ float s_mr[GN_GROUPS * 2];
     for (int i = threadIdx.x; i < a.C * 2; i += 256) s_red[i] = 0.f;
-    block_group_stats(a, b, gs, s_mr);
+    block_group_stats(a.stats, a, b, gs, s_mr);
     float ka[P], kb[P], xa[P], xb[P], r1[P], r2[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -306,15 +350,18 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
 
 // pass 2: dv = rstd * (dyhat*gamma - (S1 + xhat*S2)/n) = dyhat*ka - (c0 + v*c1),
 //         S1 = sum_{c in g} gamma_c r1, S2 = sum gamma_c r2, c1 = rstd^2 S2/n, c0 = rstd S1/n - mean c1
-template <typename T, bool HAS2, bool HASDB>
+// M2: 0 = one input; 1 = v = y1 + scale2 * y2 (HAS2: the second tensor is read); 2 (round 5) = one input, but the gradient leaves twice:
+//     d1 = dv and d2 = scale2[b,c] * dv (and dbias = column sums of d2) -- the residual tail after mte_gn_tail_fwd, whose input is the stored sum.
+template <typename T, int M2, bool HASDB>
 __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
+    constexpr bool HAS2 = M2 == 1, SCL = M2 != 0;
     GN_THREAD_MAP();
     extern __shared__ float s_db[];                       // [C] when HASDB
     __shared__ float s_mr[GN_GROUPS * 2], s_S[GN_GROUPS * 2];
     if constexpr (HASDB)
         for (int i = threadIdx.x; i < a.C; i += 256) s_db[i] = 0.f;
     if (threadIdx.x < GN_GROUPS * 2) s_S[threadIdx.x] = 0.f;
-    block_group_stats(a, b, gs, s_mr);
+    block_group_stats(a.stats, a, b, gs, s_mr);
     // S1_g = sum_{c in g} gamma_c r1_c, S2_g likewise: one pass of the block over the C channels of this sample
     for (int c = threadIdx.x; c < a.C; c += 256) {
         const float gc = a.gamma[c];
@@ -344,7 +391,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
         c0[i] = rstd * (s_S[2 * g] * inv_n) - mean * c1[i];
         if constexpr (HASDB) db[i] = 0.f;
     }
-    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    if constexpr (SCL) load_scale2<T>(a, b, ch0, sc);
     for (int p = p_begin + prow; p < p_end; p += rstep * GN_U) {
         RawRow<HAS2> raw[GN_U];
         u32x4_t gr[GN_U];
@@ -369,7 +416,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
                 if constexpr (HASDB) db[i] += v[i];
             }
             *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
-            if constexpr (HAS2) {
+            if constexpr (SCL) {
                 if (a.d2) {
 #pragma unroll
                     for (int i = 0; i < P; ++i) v[i] *= sc[i];
@@ -382,7 +429,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
         // with a second input the bias gradient asked for is that of the SECOND input's producer (the 1x1 shortcut conv of a residual
         // block): sum of d2 = scale2[b][c] * d1 over the pixels -- the factor is constant per (sample, channel), so it multiplies the sum
 #pragma unroll
-        for (int i = 0; i < P; ++i) atomicAdd(&s_db[ch0 + i], HAS2 ? db[i] * sc[i] : db[i]);
+        for (int i = 0; i < P; ++i) atomicAdd(&s_db[ch0 + i], SCL ? db[i] * sc[i] : db[i]);
         __syncthreads();
         for (int i = threadIdx.x; i < a.C; i += 256) atomicAdd(&a.dbias[i], s_db[i]);
     }
@@ -506,8 +553,9 @@ __device__ __forceinline__ void block_channel_sums(float* x, int cps, int lane, 
     __syncthreads();
 }
 
-template <typename T, bool HAS2, bool HASDB, int NCH, int NT>
+template <typename T, int M2, bool HASDB, int NCH, int NT>
 __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
+    constexpr bool HAS2 = M2 == 1, SCL = M2 != 0;
     GN_SLAB_MAP();
     __shared__ float s_part[(NT / 64) * 32];               // per-wave channel partials (a group has <= 32 channels)
     __shared__ float s_r1[32], s_r2[32], s_db[32], s_S[2];
@@ -537,7 +585,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
         const float gm = a.gamma[ch0 + k];
         ka[k] = rstd * gm; kb[k] = a.beta[ch0 + k] - mean * rstd * gm;
     }
-    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    if constexpr (SCL) load_scale2<T>(a, b, ch0, sc);
     float r1[P], r2[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) { r1[k] = 0.f; r2[k] = 0.f; }
@@ -589,7 +637,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
                 if constexpr (HASDB) db[k] += v[k];
             }
             *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
-            if constexpr (HAS2) {
+            if constexpr (SCL) {
                 if (a.d2) {
 #pragma unroll
                     for (int k = 0; k < P; ++k) v[k] *= sc[k];
@@ -600,7 +648,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
     }
     if constexpr (HASDB) {
         block_channel_sums<NT, P>(db, cps, lane, wave, s_part, s_db, gs);
-        if (t < gs) atomicAdd(&a.dbias[g * gs + t], s_db[t]);
+        // (with a scale the bias gradient asked for is that of the scaled copy d2: the factor is constant per (sample, channel))
+        if (t < gs) atomicAdd(&a.dbias[g * gs + t], SCL && a.scale2 ? s_db[t] * a.scale2[(long)b * a.C + g * gs + t] : s_db[t]);
     }
 }
 
@@ -639,11 +688,33 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(GnArgs a) {
     double* xch = mte_gn_partials(a.stats, a.B) + ((long)b * MTE_GN_SLOTS(a.B) * 32) + (long)g * (MTE_GN_SLOTS(a.B) * 2);
 
 constexpr unsigned GN_SPIN_MAX = 1u << 24;
+unsigned g_gn_spin_max = GN_SPIN_MAX;              // development knob (mte_debug_set(25, 1000 + n) -> n polls): tests force the give-up path with it
 
-// thread 0: all CL workgroups of the cluster have published (bounded: a hand-off that cannot complete leaves wrong numbers, not a hung GPU)
-__device__ __forceinline__ void cluster_wait(unsigned* ticket, unsigned want) {
+// thread 0: all CL workgroups of the cluster have published.  Bounded: a hand-off that cannot complete (a member of the cluster not resident --
+// the launch geometry keeps them resident, but nothing in HIP promises it) gives up instead of hanging the GPU; the caller then REPORTS it
+// through the device error word and the host fails the step (round 4 went on with whatever records there were: wrong statistics, no error).
+__device__ __forceinline__ bool cluster_wait(unsigned* ticket, unsigned want, unsigned spin_max) {
     unsigned spins = 0;
-    while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < GN_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (++spins >= spin_max) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+}
+// thread 0: this workgroup's record, two values.  RETURNING exchanges: a value comes back only after the store has been performed at the memory
+// side (edge_loss.hip saw a ticket overtake plain and no-return forms once per few thousand workgroups), then the wait, then -- by the caller --
+// the ticket.  Readers use agent-scope atomic loads (never a CU's L1).
+template <typename V> __device__ __forceinline__ void cluster_publish(V* rec, V v0, V v1) {
+    if constexpr (sizeof(V) == 8) {
+        const unsigned long long r0 = atomicExch((unsigned long long*)rec, (unsigned long long)__double_as_longlong((double)v0));
+        const unsigned long long r1 = atomicExch((unsigned long long*)rec + 1, (unsigned long long)__double_as_longlong((double)v1));
+        asm volatile("" ::"v"(r0), "v"(r1));
+    } else {
+        const unsigned r0 = atomicExch((unsigned*)rec, __float_as_uint((float)v0));
+        const unsigned r1 = atomicExch((unsigned*)rec + 1, __float_as_uint((float)v1));
+        asm volatile("" ::"v"(r0), "v"(r1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // thread 0, after its workgroup has read the records: the last reader of the cluster zeroes both counters (the buffer can be used again)
 __device__ __forceinline__ void cluster_done(unsigned* ticket, unsigned* done, unsigned cl) {
@@ -693,11 +764,9 @@ __global__ __launch_bounds__(256, 4) void gn_fwd_cluster_kernel(GnArgs a) {
     const double Qw = block_sum<NT>(q, s_w, lane, wave);
     unsigned* ticket = (unsigned*)xch; unsigned* done = (unsigned*)(xch + 1);
     if (t == 0) {
-        __hip_atomic_store(xch + 2 + 2 * w, Sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(xch + 3 + 2 * w, Qw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cluster_publish(xch + 2 + 2 * w, Sw, Qw);
         __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_wait(ticket, CL);
+        if (!cluster_wait(ticket, CL, a.spin_max)) mte_report_device_error(a.err, MTE_DEVERR_GN_CLUSTER_FWD);
         // sum v^2 over the slab from the per-workgroup (S_w, Q_w = sum (v - m_w)^2 about m_w = (float)(S_w / n_w)):
         // sum_w v^2 = Q_w + 2 m_w S_w - n_w m_w^2 for ANY m_w, exactly -- one pass over the records, in slot order
         double S = 0.0, SQ = 0.0;
@@ -742,8 +811,9 @@ __global__ __launch_bounds__(256, 4) void gn_fwd_cluster_kernel(GnArgs a) {
     }
 }
 
-template <typename T, bool HAS2, bool HASDB, int NCH, int CL>
+template <typename T, int M2, bool HASDB, int NCH, int CL>
 __global__ __launch_bounds__(256, 4) void gn_bwd_cluster_kernel(GnArgs a) {
+    constexpr bool HAS2 = M2 == 1, SCL = M2 != 0;
     GN_CLUSTER_MAP();
     __shared__ float s_part[(NT / 64) * 32];
     __shared__ float s_r1[32], s_r2[32], s_db[32], s_S[2];
@@ -773,7 +843,7 @@ __global__ __launch_bounds__(256, 4) void gn_bwd_cluster_kernel(GnArgs a) {
         const float gm = a.gamma[ch0 + k];
         ka[k] = rstd * gm; kb[k] = a.beta[ch0 + k] - mean * rstd * gm;
     }
-    if constexpr (HAS2) load_scale2<T>(a, b, ch0, sc);
+    if constexpr (SCL) load_scale2<T>(a, b, ch0, sc);
     float r1[P], r2[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) { r1[k] = 0.f; r2[k] = 0.f; }
@@ -805,11 +875,9 @@ __global__ __launch_bounds__(256, 4) void gn_bwd_cluster_kernel(GnArgs a) {
             atomicAdd(&a.dbeta[g * gs + t], s_r1[t]);
         }
         if (t == 0) {
-            __hip_atomic_store(rec + 2 * w, S1w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(rec + 2 * w + 1, S2w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cluster_publish(rec + 2 * w, S1w, S2w);
             __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cluster_wait(ticket, CL);
+            if (!cluster_wait(ticket, CL, a.spin_max)) mte_report_device_error(a.err, MTE_DEVERR_GN_CLUSTER_BWD);
             float S1 = 0.f, S2 = 0.f;
 #pragma unroll
             for (int k = 0; k < CL; ++k) {
@@ -844,7 +912,7 @@ __global__ __launch_bounds__(256, 4) void gn_bwd_cluster_kernel(GnArgs a) {
                 if constexpr (HASDB) db[k] += v[k];
             }
             *(u32x4_t*)((T*)a.d1 + pix * a.ldd1 + ch0) = pack16<T>(v);
-            if constexpr (HAS2) {
+            if constexpr (SCL) {
                 if (a.d2) {
 #pragma unroll
                     for (int k = 0; k < P; ++k) v[k] *= sc[k];
@@ -855,7 +923,7 @@ __global__ __launch_bounds__(256, 4) void gn_bwd_cluster_kernel(GnArgs a) {
     }
     if constexpr (HASDB) {
         block_channel_sums<NT, P>(db, cps, lane, wave, s_part, s_db, gs);
-        if (t < gs) atomicAdd(&a.dbias[g * gs + t], s_db[t]);
+        if (t < gs) atomicAdd(&a.dbias[g * gs + t], SCL && a.scale2 ? s_db[t] * a.scale2[(long)b * a.C + g * gs + t] : s_db[t]);
     }
 }
 
@@ -912,7 +980,7 @@ template <typename T, bool HAS2> bool launch_fwd_slab(const GnArgs& a, long n, h
 #undef GN_FWD_SLAB
     return false;
 }
-template <typename T, bool HAS2, bool HASDB> bool launch_bwd_slab(const GnArgs& a, long n, hipStream_t st) {
+template <typename T, int HAS2, bool HASDB> bool launch_bwd_slab(const GnArgs& a, long n, hipStream_t st) {
     const dim3 grid(slab_grid(a.B));
 #define GN_BWD_SLAB(NCH, NT)                                                                                   \
     if (n <= (long)NT * NCH) { hipLaunchKernelGGL((gn_bwd_slab_kernel<T, HAS2, HASDB, NCH, NT>), grid, dim3(NT), 0, st, a); return true; }
@@ -922,6 +990,7 @@ template <typename T, bool HAS2, bool HASDB> bool launch_bwd_slab(const GnArgs& 
 }
 
 int g_gn_cluster = 1;                               // development knob (mte_debug_set(25, v)): 0 = no cluster kernels
+void gn_common(GnArgs& a) { a.err = g_mte_err_dev; a.fences = g_mte_handoff_fences; a.spin_max = g_gn_spin_max; }
 
 // cluster geometry for a slab of n chunks that is too large for the slab kernels: CL workgroups of 256 threads, NCH chunks per thread.
 // regs = 16-byte registers a thread holds per chunk (forward: 1 + second input; backward: 2 + second input).  0 = not a cluster shape.
@@ -969,10 +1038,10 @@ template <typename T, bool HAS2> bool launch_fwd_cluster(const GnArgs& a, int cl
     if (cl == 2) return launch_fwd_cluster_cl<T, HAS2, 2>(a, nch, per_launch, st);
     return false;
 }
-template <typename T, bool HAS2, bool HASDB, int CL> bool launch_bwd_cluster_cl(GnArgs a, int nch, int per_launch, hipStream_t st) {
+template <typename T, int HAS2, bool HASDB, int CL> bool launch_bwd_cluster_cl(GnArgs a, int nch, int per_launch, hipStream_t st) {
     const dim3 grid((unsigned)(per_launch * GN_GROUPS * CL));
     a.ppl = per_launch;
-#define GN_BWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 ? 3 : 2) <= 12) { \
+#define GN_BWD_CL(NCH) if (nch == NCH) { if constexpr (NCH * (HAS2 == 1 ? 3 : 2) <= 12) { \
         for (a.b0 = 0; a.b0 < a.B; a.b0 += per_launch) { a.nb = a.B - a.b0 < per_launch ? a.B - a.b0 : per_launch;          \
             hipLaunchKernelGGL((gn_bwd_cluster_kernel<T, HAS2, HASDB, NCH, CL>), grid, dim3(256), 0, st, a); }               \
         return true; } }
@@ -980,7 +1049,7 @@ template <typename T, bool HAS2, bool HASDB, int CL> bool launch_bwd_cluster_cl(
 #undef GN_BWD_CL
     return false;
 }
-template <typename T, bool HAS2, bool HASDB> bool launch_bwd_cluster(const GnArgs& a, int cl, int nch, int per_launch, hipStream_t st) {
+template <typename T, int HAS2, bool HASDB> bool launch_bwd_cluster(const GnArgs& a, int cl, int nch, int per_launch, hipStream_t st) {
     if (cl == 16) return launch_bwd_cluster_cl<T, HAS2, HASDB, 16>(a, nch, per_launch, st);
     if (cl == 8) return launch_bwd_cluster_cl<T, HAS2, HASDB, 8>(a, nch, per_launch, st);
     if (cl == 4) return launch_bwd_cluster_cl<T, HAS2, HASDB, 4>(a, nch, per_launch, st);
@@ -1005,9 +1074,9 @@ template <typename T> int run_stats(GnArgs& a, hipStream_t stream) {
     return mte_check_launch();
 }
 
-template <typename T> int run_fwd(GnArgs& a, hipStream_t stream) {
+template <typename T> int run_fwd(GnArgs& a, hipStream_t stream, int reverse = 0) {
     a.blocks_per_sample = gn_blocks(a.B, a.HW, 256 / (a.C / Elem<T>::PER16), true);
-    a.reverse = 0;                                         // ... and the statistics pass ended on sample 0
+    a.reverse = reverse;                                   // ... and the statistics pass ended on sample 0
     dim3 grid(a.blocks_per_sample, a.B);
     if (a.y2) hipLaunchKernelGGL((gn_elu_fwd_kernel<T, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gn_elu_fwd_kernel<T, false>), grid, dim3(256), 0, stream, a);
@@ -1017,18 +1086,22 @@ template <typename T> int run_fwd(GnArgs& a, hipStream_t stream) {
 template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
     int sh = 0;
     const long n = slab_chunks(a.HW, a.C, dtype, &sh);
-    if (n > 0 && n <= GN_SLAB_MAX && !(a.y2 && a.dbias)) {
+    // second-output mode (see gn_elu_bwd_apply_kernel): 1 = second input tensor, 2 = one input whose gradient also leaves scaled (d2 = scale2 * d1)
+    const int m2 = a.y2 ? 1 : (a.scale2 && a.d2 ? 2 : 0);
+    if (m2 != 1) a.y2 = nullptr;
+    if (m2 == 0) { a.scale2 = nullptr; a.d2 = nullptr; }
+    if (n > 0 && n <= GN_SLAB_MAX && m2 != 2) {
         a.cps_shift = sh;
         // the slab kernels ADD this sample's part of dgamma / dbeta (the stream kernels overwrite them): clear them first (prezeroed callers did)
         if (!g_mte_gn_prezeroed && (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess ||
                                     mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess)) return MTE_ERR_LAUNCH;
         bool done;
-        if (a.y2) done = launch_bwd_slab<T, true, false>(a, n, stream);
-        else if (a.dbias) done = launch_bwd_slab<T, false, true>(a, n, stream);
-        else done = launch_bwd_slab<T, false, false>(a, n, stream);
+        if (a.y2) done = a.dbias ? launch_bwd_slab<T, 1, true>(a, n, stream) : launch_bwd_slab<T, 1, false>(a, n, stream);
+        else if (a.dbias) done = launch_bwd_slab<T, 0, true>(a, n, stream);
+        else done = launch_bwd_slab<T, 0, false>(a, n, stream);
         if (done) return mte_check_launch();
     }
-    if (n > GN_SLAB_MAX && !(a.y2 && a.dbias)) {
+    if (n > GN_SLAB_MAX) {                                  // (round 5: also the tail with a bias gradient -- the kernels scale the column sums now)
         int nch = 0, pl = 0;
         const int cl = cluster_plan(a.B, a.HW, a.C, n, sh, a.y2 ? 3 : 2, &nch, &pl);
         if (cl) {
@@ -1036,9 +1109,10 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
             if (!g_mte_gn_prezeroed && (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess ||
                                         mte_memset_async(a.dbeta, 0, sizeof(float) * a.C, stream) != hipSuccess)) return MTE_ERR_LAUNCH;
             bool done;
-            if (a.y2) done = launch_bwd_cluster<T, true, false>(a, cl, nch, pl, stream);
-            else if (a.dbias) done = launch_bwd_cluster<T, false, true>(a, cl, nch, pl, stream);
-            else done = launch_bwd_cluster<T, false, false>(a, cl, nch, pl, stream);
+            if (a.y2) done = a.dbias ? launch_bwd_cluster<T, 1, true>(a, cl, nch, pl, stream) : launch_bwd_cluster<T, 1, false>(a, cl, nch, pl, stream);
+            else if (m2 == 2) done = a.dbias ? launch_bwd_cluster<T, 2, true>(a, cl, nch, pl, stream) : launch_bwd_cluster<T, 2, false>(a, cl, nch, pl, stream);
+            else if (a.dbias) done = launch_bwd_cluster<T, 0, true>(a, cl, nch, pl, stream);
+            else done = launch_bwd_cluster<T, 0, false>(a, cl, nch, pl, stream);
             if (done) return mte_check_launch();
         }
     }
@@ -1047,15 +1121,35 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
     const size_t lds = sizeof(float) * a.C * 2;
     GnArgs a2 = a;
     a2.reverse = g_gn_zigzag;                              // the apply pass starts where the reduce pass ended
+    const size_t ldb = a.dbias ? sizeof(float) * a.C : 0;
     if (a.y2) {
         hipLaunchKernelGGL((gn_elu_bwd_reduce_kernel<T, true>), grid, dim3(256), lds, stream, a);
-        if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, true, true>), grid, dim3(256), sizeof(float) * a.C, stream, a2);
-        else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, true, false>), grid, dim3(256), 0, stream, a2);
+        if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 1, true>), grid, dim3(256), ldb, stream, a2);
+        else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 1, false>), grid, dim3(256), 0, stream, a2);
     } else {
         hipLaunchKernelGGL((gn_elu_bwd_reduce_kernel<T, false>), grid, dim3(256), lds, stream, a);
-        if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, false, true>), grid, dim3(256), sizeof(float) * a.C, stream, a2);
-        else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, false, false>), grid, dim3(256), 0, stream, a2);
+        if (m2 == 2) {
+            if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 2, true>), grid, dim3(256), ldb, stream, a2);
+            else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 2, false>), grid, dim3(256), 0, stream, a2);
+        } else if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 0, true>), grid, dim3(256), ldb, stream, a2);
+        else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 0, false>), grid, dim3(256), 0, stream, a2);
     }
+    return mte_check_launch();
+}
+
+// the residual tail's first kernel (gn_stats_kernel<.., TAIL>): the geometry of the statistics pass
+template <typename T> int run_tail(GnArgs& a, hipStream_t stream) {
+    constexpr int NT = 1024;
+    const int rstep = NT / (a.C / Elem<T>::PER16);
+    long want = ((long)g_gn_target * 256 / NT + a.B - 1) / a.B;
+    const int min_rows = g_gn_min_rows < 16 ? g_gn_min_rows : 16;
+    const long maxb = ((long)a.HW + (long)min_rows * rstep - 1) / ((long)min_rows * rstep);
+    if (want > maxb) want = maxb;
+    if (want > MTE_GN_SLOTS(a.B)) want = MTE_GN_SLOTS(a.B);
+    a.blocks_per_sample = (int)(want < 1 ? 1 : want);
+    a.reverse = 0;                                         // the inner layer's statistics pass ended on sample 0
+    dim3 grid(a.blocks_per_sample, a.B);
+    hipLaunchKernelGGL((gn_stats_kernel<T, true, NT, true>), grid, dim3(NT), 0, stream, a);
     return mte_check_launch();
 }
 
@@ -1065,7 +1159,7 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
 extern "C" int mtei_set_gn(int which, int value) {
     if (which == 2) { g_gn_slab = value; return MTE_OK; }
     if (which == 3) { g_gn_zigzag = value; return MTE_OK; }
-    if (which == 4) { g_gn_cluster = value; return MTE_OK; }
+    if (which == 4) { if (value >= 1000) g_gn_spin_max = (unsigned)(value - 1000); else g_gn_cluster = value; return MTE_OK; }
     if (value < 1) return MTE_ERR_ARG;
     if (which == 0) g_gn_min_rows = value; else g_gn_target = value;
     return MTE_OK;
@@ -1104,6 +1198,7 @@ int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float
     if (!y1 || !stats || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     if (!g_mte_gn_prezeroed && mte_memset_async(mte_gn_tickets(stats, B), 0, sizeof(double) * ((B + 15) & ~15), stream) != hipSuccess) return MTE_ERR_LAUNCH;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
+    gn_common(a);
     return dtype == MTE_DT_BF16 ? run_stats<bf16_t>(a, stream) : run_stats<float>(a, stream);
 }
 
@@ -1117,6 +1212,7 @@ int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const flo
     if (!y1 || !stats || !gamma || !beta || !z || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats;
     a.gamma = gamma; a.beta = beta; a.z = z; a.ldz = ldz; a.B = B; a.HW = HW; a.C = C; a.eps = eps;
+    gn_common(a);
     if (!stats_ready) {
         if (!mte_gn_fwd_is_single_pass_b(B, HW, C, y2 != nullptr, dtype)) return MTE_ERR_ARG;
         int sh = 0;
@@ -1156,13 +1252,59 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
     GnArgs a{}; a.dbias = dbias; a.dgamma = dgamma; a.dbeta = dbeta; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
     a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;
     a.B = B; a.HW = HW; a.C = C; a.eps = eps;
+    gn_common(a);
     return dtype == MTE_DT_BF16 ? run_bwd<bf16_t>(a, dtype, stream) : run_bwd<float>(a, dtype, stream);
+}
+
+// The residual block's tail, ELU(GN_t(ELU(GN_1(y1)) + scale2 * y2)) (ResidualConv.forward, layers01.py:62-73: y1 = conv2's convolution output,
+// GN_1 / ELU = the rest of that Conv2D, y2 = the 1x1 shortcut, scale2 = Dropout2d's per-(sample, channel) factor or null), in TWO launches:
+//   1. t = ELU(GN_1(y1)) + scale2 * y2, stored in the activation type, and the statistics of the stored t  (stats1: the sums of y1 from mte_gn_stats)
+//   2. z = ELU(GN_t(t))
+// against four before (inner apply, statistics over two tensors, outer apply over two tensors; + the inner statistics either way): 6 tensor passes
+// instead of 8, and the backward pass of the outer norm reads ONE saved tensor (t) -- mte_gn_elu_bwd with y2 = null, scale2 and d2 given.
+// stats_t: a statistics buffer (mte_gn_stats_elems(B) doubles, tickets zero at entry); bit-reproducible like mte_gn_stats.
+int mte_gn_tail_fwd(const void* y1, long ld1, const double* stats1, const float* gamma1, const float* beta1,
+                    const void* y2, long ld2, const float* scale2, void* t, long ldt, double* stats_t,
+                    const float* gamma_t, const float* beta_t, void* z, long ldz,
+                    int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!y1 || !stats1 || !gamma1 || !beta1 || !y2 || !t || !stats_t || !gamma_t || !beta_t || !z || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
+    if (!g_mte_gn_prezeroed && mte_memset_async(mte_gn_tickets(stats_t, B), 0, sizeof(double) * ((B + 15) & ~15), stream) != hipSuccess) return MTE_ERR_LAUNCH;
+    GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats_in = stats1; a.stats = stats_t;
+    a.gamma = gamma1; a.beta = beta1; a.z = t; a.ldz = ldt; a.B = B; a.HW = HW; a.C = C; a.eps = eps;
+    gn_common(a);
+    int rc = dtype == MTE_DT_BF16 ? run_tail<bf16_t>(a, stream) : run_tail<float>(a, stream);
+    if (rc != MTE_OK) return rc;
+    GnArgs f{}; f.y1 = t; f.ld1 = ldt; f.stats = stats_t; f.gamma = gamma_t; f.beta = beta_t; f.z = z; f.ldz = ldz; f.B = B; f.HW = HW; f.C = C; f.eps = eps;
+    gn_common(f);
+    rc = dtype == MTE_DT_BF16 ? run_fwd<bf16_t>(f, stream, g_gn_zigzag) : run_fwd<float>(f, stream, g_gn_zigzag);   // (the tail kernel ended on the last sample)
+    return rc;
 }
 
 int mte_set_option(int option, int value) {
     if (option == 0) { g_mte_gn_prezeroed = value ? 1 : 0; return MTE_OK; }      // MTE_OPT_GN_PREZEROED
     if (option == 1) { g_mte_loss_prezeroed = value ? 1 : 0; return MTE_OK; }    // MTE_OPT_LOSS_PREZEROED
+    if (option == 2) { g_mte_handoff_fences = value ? 1 : 0; return MTE_OK; }    // MTE_OPT_HANDOFF_FENCES
     return MTE_ERR_ARG;
+}
+
+// Device error word (common.hpp).  init: one 32-bit word of pinned, host-coherent memory (call once, outside any stream capture; a second call
+// is a no-op).  poll: -> the flags reported since the last poll (0 = none) and clears them; does not synchronise -- a kernel still running may
+// report later, so a step's error can surface at the NEXT poll.  Without init the kernels' bounded waits still give up, silently.
+int mte_device_error_init(void) {
+    if (g_mte_err_host) return MTE_OK;
+    unsigned* h = nullptr; unsigned* d = nullptr;
+    if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped) != hipSuccess || !h) { (void)hipGetLastError(); return MTE_ERR_LAUNCH; }
+    *h = 0u;
+    if (hipHostGetDevicePointer((void**)&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(h); return MTE_ERR_LAUNCH; }
+    g_mte_err_host = h; g_mte_err_dev = d;
+    return MTE_OK;
+}
+int mte_device_error_poll(void) {
+    if (!g_mte_err_host) return 0;
+    const unsigned v = *g_mte_err_host;
+    if (v) *g_mte_err_host = 0u;
+    return (int)v;
 }
 
 }  // extern "C"

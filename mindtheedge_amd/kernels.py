@@ -261,7 +261,10 @@ class _ZeroArena:
         if not self.enabled:             # from now on the library trusts GroupNorm accumulation buffers to arrive zeroed
             lib.set_option(0, 1)
             lib.set_option(1, 1)         # ... and the loss workspaces (also carved from here)
+            if os.environ.get("MTE_HANDOFF_FENCES"):
+                lib.set_option(2, 1 if os.environ["MTE_HANDOFF_FENCES"] == "1" else 0)
             self.enabled = True
+            _device_errors_init()
         n = 1
         for d in shape:
             n *= d
@@ -299,6 +302,27 @@ class _ZeroArena:
 
 
 _arena = _ZeroArena()
+_DEVERR_NAMES = {1: "GroupNorm cluster kernel (forward): a workgroup of a cluster never arrived",
+                 2: "GroupNorm cluster kernel (backward): a workgroup of a cluster never arrived"}
+
+
+def _device_errors_init():
+    """allocate the device error word of the library build in use (include/mte_kernels.h: mte_device_error_init; a no-op from the second call on) --
+    never inside a stream capture.  -> True when the word exists"""
+    if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        lib.mte_device_error_init()
+        return True
+    return False
+
+
+def check_device_errors():
+    """Raise if a kernel of this process reported through the device error word since the last call (a bounded inter-workgroup wait that gave up:
+    its results are wrong by construction).  Costs one read of host memory, no synchronisation: the trainer and the optimizer call it once per
+    step, so an error surfaces at the end of the step that caused it or of the next one."""
+    code = int(lib.mte_device_error_poll()) if _device_errors_init() else 0
+    if code:
+        what = "; ".join(v for k, v in _DEVERR_NAMES.items() if code & k) or "code %d" % code
+        raise MteError("device error word set (0x%x): %s -- the results of that step are invalid" % (code, what))
 
 
 def begin_graph_capture():
@@ -547,7 +571,10 @@ _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0
         "fuse_inv_term": os.environ.get("MTE_FUSE_INV", "1") == "1",
         # residual blocks: the 1x1 shortcut's data gradient rides the 3x3 conv1's data-gradient launch as extra K-steps (mte_conv2d_patch_fwd_plus1x1) where
         # that launch runs on the LDS-patch kernel -- no stand-alone 1x1 launch, no accumulating pass over dx.  MTE_FOLD_SHORTCUT=0: two launches
-        "fold_shortcut_dgrad": os.environ.get("MTE_FOLD_SHORTCUT", "1") == "1"}
+        "fold_shortcut_dgrad": os.environ.get("MTE_FOLD_SHORTCUT", "1") == "1",
+        # residual blocks: conv2's GroupNorm + ELU applied inside the kernel that forms x_out + Dropout2d(shortcut) and takes the sum's statistics
+        # (ConvResidualTailFn / mte_gn_tail_fwd).  MTE_FUSE_TAIL=0: the round-4 form (ConvGnEluFn + ResidualTailFn over two tensors)
+        "fuse_residual_tail": os.environ.get("MTE_FUSE_TAIL", "1") == "1"}
 
 
 def use_pack_folding(flag):
@@ -1095,6 +1122,79 @@ class ResidualTailFn(torch.autograd.Function):
             return da, ds, None, _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), _grad_ret(ctx.bias_s, dbs, sbs)
         da, ds, dgamma, dbeta = _gn_backward(dz, a, s, ctx.scale, stats, gamma, beta, GN_EPS, True, dgamma=gg, dbeta=gb)
         return da, ds, None, _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None
+
+
+def residual_tail_fused_ok(B, C, H, W, dtype):
+    """the two-launch residual tail (ConvResidualTailFn) is the better form: everywhere except where the tail over two tensors is a single-pass cluster
+    kernel already (512 channels at 24x80 with B = 8: one read of each input, one write)"""
+    if not _cfg["fuse_residual_tail"]:
+        return False
+    return lib.mte_gn_fwd_is_single_pass_b(B, H * W, C, 1, DT_BF16 if dtype == torch.bfloat16 else DT_F32) != 1
+
+
+class ConvResidualTailFn(torch.autograd.Function):
+    """ELU(GN_t(ELU(GN_2(conv2(x1) + b2)) + scale[b,c] * s)) -- conv2 of a ResidualConv TOGETHER with the block's tail (reference layers01.py:59-73:
+    `x_out = self.conv2(x_out)`, `self.activ(self.normalize(x_out + shortcut))`; s = the 1x1 shortcut, scale = Dropout2d's factor or None).
+    Round 5: conv2's own GroupNorm + ELU is applied on the fly by the kernel that forms the sum t = x_out + scale * s, which also takes t's statistics
+    (mte_gn_tail_fwd): x_out is never written, the stand-alone statistics pass over (x_out, s) is gone, and both backward passes of the outer norm read t
+    instead of (x_out, s).  Saved for backward: conv2's convolution output c2 and t (before: c2, x_out and s)."""
+
+    @staticmethod
+    def forward(ctx, x1, w2, b2, gamma2, beta2, pack2, s, scale, gamma_t, beta_t, bias_s):
+        ctx.fork_slot = getattr(x1, "_mte_fork_slot", None)
+        wf, _ = pack2.get(w2, x1.dtype, bool(ctx.needs_input_grad[0]))
+        cout, cin, kh, kw = w2.shape
+        c2 = conv_forward(x1, wf, b2, cout, kh, kw, pack=pack2, w=w2)
+        B, C, H, W = c2.shape
+        if tuple(s.shape) != (B, C, H, W) or s.dtype != c2.dtype:
+            raise MteError("residual tail: shortcut %s / %s against %s / %s" % (tuple(s.shape), s.dtype, (B, C, H, W), c2.dtype))
+        st = _stream()
+        p1, l1 = _pl(c2)
+        p2, l2 = _pl(s)
+        stats2 = gn_stats_buffer(B, c2.device)
+        lib.mte_gn_stats(p1, l1, 0, 0, 0, stats2.data_ptr(), B, H * W, C, _dt(c2), st)
+        stats_t = gn_stats_buffer(B, c2.device)
+        t = new_act(B, C, H, W, c2.dtype, c2.device)
+        z = new_act(B, C, H, W, c2.dtype, c2.device)
+        pt, lt = _pl(t)
+        pz, lz = _pl(z)
+        lib.mte_gn_tail_fwd(p1, l1, stats2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), p2, l2, _ptr(scale), pt, lt, stats_t.data_ptr(),
+                            gamma_t.data_ptr(), beta_t.data_ptr(), pz, lz, B, H * W, C, GN_EPS, _dt(c2), st)
+        ctx.save_for_backward(x1, w2, c2, stats2, gamma2, beta2, t, stats_t, gamma_t, beta_t)
+        ctx.scale = scale
+        ctx.bias_s = bias_s
+        ctx.bias2 = b2
+        ctx.pack = pack2
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x1, w2, c2, stats2, gamma2, beta2, t, stats_t, gamma_t, beta_t = ctx.saved_tensors
+        scale, bias_s, b2 = ctx.scale, ctx.bias_s, ctx.bias2
+        # ---- outer norm: dt (= the gradient of conv2's Conv2D output) and ds = scale * dt (the shortcut's output gradient; its bias gradient = column sums)
+        ggt, sgt = _grad_dst(gamma_t, zero=True)
+        gbt, sbt = _grad_dst(beta_t, zero=True)
+        want_bs = bias_s is not None and ctx.needs_input_grad[10]
+        gbs, sbs = _grad_dst(bias_s, zero=True) if want_bs else (None, False)
+        if scale is None:          # no Dropout2d: ds IS dt
+            out = _gn_backward(dz, t, None, None, stats_t, gamma_t, beta_t, GN_EPS, False, want_dbias=want_bs, dgamma=ggt, dbeta=gbt, dbias=gbs)
+            dt = ds = out[0]
+        else:
+            out = _gn_backward(dz, t, None, scale, stats_t, gamma_t, beta_t, GN_EPS, True, want_dbias=want_bs, dgamma=ggt, dbeta=gbt, dbias=gbs)
+            dt, ds = out[0], out[1]
+        dgamma_t, dbeta_t = out[2], out[3]
+        dbs = out[4] if want_bs else None
+        # ---- conv2's own norm, then its convolution
+        gg2, sg2 = _grad_dst(gamma2, zero=True)
+        gb2, sb2 = _grad_dst(beta2, zero=True)
+        gbias2, sbias2 = _grad_dst(b2, zero=True)
+        gw2, sw2 = _grad_dst(w2)
+        dc2, _, dgamma2, dbeta2, db2 = _gn_backward(dt, c2, None, None, stats2, gamma2, beta2, GN_EPS, False, want_dbias=True,
+                                                    dgamma=gg2, dbeta=gb2, dbias=gbias2)
+        dx1, dw2, _ = conv_backward(x1, dc2, w2, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw2, fork_slot=ctx.fork_slot, sunk=sw2)
+        return (dx1, _grad_ret(w2, dw2, sw2), _grad_ret(b2, db2, sbias2), _grad_ret(gamma2, dgamma2, sg2), _grad_ret(beta2, dbeta2, sb2), None,
+                ds if ctx.needs_input_grad[6] else None, None, _grad_ret(gamma_t, dgamma_t, sgt), _grad_ret(beta_t, dbeta_t, sbt),
+                _grad_ret(bias_s, dbs, sbs) if want_bs else None)
 
 
 class Pack3dFn(torch.autograd.Function):

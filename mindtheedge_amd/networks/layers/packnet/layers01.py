@@ -109,10 +109,17 @@ class ResidualConv(nn.Module):
         sc = self._shortcut_params()
         x = _enter(x, sc.in_channels)
         xa, xb = K.fork(x)
-        y = self.conv2(self.conv1(xa))
+        y1 = self.conv1(xa)
         s = K.ConvFn.apply(xb, sc.weight, sc.bias, sc.pack, False)          # (its bias gradient comes out of the tail's backward pass)
         if channel_scale is None and self.dropout and self.training:
             channel_scale = K.dropout2d_scale(x.shape[0], sc.out_channels, self.dropout, x.device)
+        B, _, H, W = x.shape
+        if K.residual_tail_fused_ok(B, sc.out_channels, H, W, y1.dtype):
+            # conv2 (a Conv2D) and the block's tail as one op: conv2's norm + ELU happen inside the kernel that forms the sum (kernels.ConvResidualTailFn)
+            cb, gn = self.conv2.conv_base, self.conv2.normalize
+            return K.ConvResidualTailFn.apply(y1, cb.weight, cb.bias, gn.weight, gn.bias, cb.pack, s, channel_scale,
+                                              self.normalize.weight, self.normalize.bias, sc.bias)
+        y = self.conv2(y1)
         return K.ResidualTailFn.apply(y, s, channel_scale, self.normalize.weight, self.normalize.bias, sc.bias)
 
 

@@ -233,6 +233,8 @@ class FusedAdam(torch.optim.Optimizer):
                              betas=g['betas'], eps=g['eps'], gscale=gscale)
         if self.flatp.grad.is_cuda:
             K.prefetch_weight_packs()                       # next step's kernel-ready weight packs, off the critical path
+            if not torch.cuda.is_current_stream_capturing():
+                K.check_device_errors()                     # a bounded inter-workgroup wait gave up somewhere: fail the step (one host-memory read)
 
     def advance(self):
         """Host side of one step: count it and hand the kernel its learning rate and bias corrections (same double-precision

@@ -140,3 +140,129 @@ def test_cluster_route_is_taken_and_is_bit_reproducible():
             torch.cuda.synchronize()
         assert float((zs.float() - outs[0][0].float()).abs().max()) <= 2.0 ** -6 * float(zs.float().abs().max())
         assert float((ds.float() - outs[0][2].float()).abs().max()) <= 2.0 ** -6 * float(ds.float().abs().max())
+
+
+# ---- round 5: the residual block's tail in two launches (mte_gn_tail_fwd) and its backward (mte_gn_elu_bwd with a scaled second output)
+def _tail_reference(y1, s, scale, g1, b1, gt, bt, dz):
+    y1, s = y1.double().requires_grad_(True), s.double().requires_grad_(True)
+    ps = [p.double().requires_grad_(True) for p in (g1, b1, gt, bt)]
+    a = F.elu(F.group_norm(y1, 16, ps[0], ps[1], eps=1e-5))
+    t = a + (s * scale.double()[:, :, None, None] if scale is not None else s)
+    z = F.elu(F.group_norm(t, 16, ps[2], ps[3], eps=1e-5))
+    z.backward(dz.double())
+    return {"t": t.detach(), "z": z.detach(), "dy1": y1.grad, "ds": s.grad, "dg1": ps[0].grad, "db1": ps[1].grad, "dgt": ps[2].grad, "dbt": ps[3].grad,
+            "dbias_s": s.grad.sum(dim=(0, 2, 3)), "dbias1": y1.grad.sum(dim=(0, 2, 3))}
+
+
+def _tail_run(K, y1, s, scale, g1, b1, gt, bt, dz):
+    B, C, H, W = y1.shape
+    dt_ = K._dt(y1)
+    st = K._stream()
+    stats1 = K.gn_stats_buffer(B, y1.device)
+    K.lib.mte_gn_stats(K._pl(y1)[0], K._pl(y1)[1], 0, 0, 0, stats1.data_ptr(), B, H * W, C, dt_, st)
+    stats_t = K.gn_stats_buffer(B, y1.device)
+    t, z = K.new_act(B, C, H, W, y1.dtype), K.new_act(B, C, H, W, y1.dtype)
+    K.lib.mte_gn_tail_fwd(K._pl(y1)[0], K._pl(y1)[1], stats1.data_ptr(), g1.data_ptr(), b1.data_ptr(), K._pl(s)[0], K._pl(s)[1], K._ptr(scale),
+                          K._pl(t)[0], K._pl(t)[1], stats_t.data_ptr(), gt.data_ptr(), bt.data_ptr(), K._pl(z)[0], K._pl(z)[1], B, H * W, C, 1e-5, dt_, st)
+    if scale is None:
+        o = K._gn_backward(dz, t, None, None, stats_t, gt, bt, 1e-5, False, want_dbias=True)
+        dt, ds = o[0], o[0]
+    else:
+        o = K._gn_backward(dz, t, None, scale, stats_t, gt, bt, 1e-5, True, want_dbias=True)
+        dt, ds = o[0], o[1]
+    i = K._gn_backward(dt, y1, None, None, stats1, g1, b1, 1e-5, False, want_dbias=True)
+    torch.cuda.synchronize()
+    return {"t": t, "z": z, "dy1": i[0], "ds": ds, "dg1": i[2], "db1": i[3], "dgt": o[2], "dbt": o[3], "dbias_s": o[4], "dbias1": i[4],
+            "stats_t": stats_t[:B * 32].clone()}
+
+
+TAIL_SHAPES = [(2, 64, 32, 64), (1, 128, 16, 24), (3, 256, 23, 79), (2, 128, 96, 320), (8, 256, 48, 160), (8, 512, 24, 80), (2, 32, 64, 64)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dropout", [True, False])
+@pytest.mark.parametrize("shape", TAIL_SHAPES)
+def test_residual_tail_in_two_launches(shape, dropout, dtype):
+    """t = ELU(GN(y1)) + scale * s and z = ELU(GN_t(t)) with every gradient, against the double-precision statement of layers01.py:62-73; twice, bit for bit."""
+    from mindtheedge_amd import kernels as K
+    B, C, H, W = shape
+    K.set_compute_dtype(dtype)
+    try:
+        tdt = K.compute_dtype()
+        g = torch.Generator().manual_seed(B * 77 + C + W)
+        rnd = lambda *sh: torch.randn(*sh, generator=g)
+        y1 = (rnd(B, C, H, W) * 1.5 + 0.3).to(tdt).float()
+        s = rnd(B, C, H, W).to(tdt).float()
+        scale = ((torch.rand(B, C, generator=g) >= 0.5).float() * 2.0) if dropout else None
+        g1, b1, gt, bt = 1.0 + 0.25 * rnd(C), 0.1 * rnd(C), 1.0 + 0.25 * rnd(C), 0.1 * rnd(C)
+        dz = rnd(B, C, H, W).to(tdt).float()
+        want = _tail_reference(y1, s, scale, g1, b1, gt, bt, dz)
+        dev = torch.device("cuda")
+        args = (K.as_act(y1.to(dev), tdt), K.as_act(s.to(dev), tdt), None if scale is None else scale.to(dev), g1.to(dev), b1.to(dev), gt.to(dev), bt.to(dev),
+                K.as_act(dz.to(dev), tdt))
+        got = _tail_run(K, *args)
+        again = _tail_run(K, *args)
+        for k in ("t", "z", "stats_t"):                            # the forward has no floating-point atomics
+            assert torch.equal(got[k], again[k]), k
+        tol = 2e-5 if dtype == "fp32" else 1.2e-2
+        gtol = 1e-4 if dtype == "fp32" else 2e-2
+        for k, w in want.items():
+            e = _err(got[k].float().cpu(), w)
+            # bf16: z and the gradients are functions of the ROUNDED t (2^-9 of its size), one more rounding than the single norm of the test above
+            assert e <= (tol if k in ("t", "z", "dy1", "ds") else gtol) * (1.0 if dtype == "fp32" else 1.5), (k, e, shape, dropout, dtype)
+    finally:
+        K.set_compute_dtype("bf16")
+
+
+def test_residual_tail_matches_the_four_launch_form_in_bf16():
+    """the same block through the round-4 kernels (inner norm stored, then the tail over two tensors): agreement to bf16 storage rounding"""
+    from mindtheedge_amd import kernels as K
+    K.set_compute_dtype("bf16")
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(31)
+    for B, C, H, W in ((8, 64, 96, 160), (8, 256, 48, 160)):
+        y1 = K.as_act((torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to(dev), torch.bfloat16)
+        s = K.as_act(torch.randn(B, C, H, W, generator=g).to(dev), torch.bfloat16)
+        scale = ((torch.rand(B, C, generator=g) >= 0.5).float() * 2.0).to(dev)
+        g1, b1, gt, bt = [(v + 0.2 * torch.randn(C, generator=g)).to(dev) for v in (1.0, 0.0, 1.0, 0.0)]
+        dz = K.as_act(torch.randn(B, C, H, W, generator=g).to(dev), torch.bfloat16)
+        new = _tail_run(K, y1, s, scale, g1, b1, gt, bt, dz)
+        a, st1 = K._gn_forward(y1, None, None, g1, b1, 1e-5)
+        z, stt = K._gn_forward(a, s, scale, gt, bt, 1e-5)
+        o = K._gn_backward(dz, a, s, scale, stt, gt, bt, 1e-5, True, want_dbias=True)
+        i = K._gn_backward(o[0], y1, None, None, st1, g1, b1, 1e-5, False, want_dbias=True)
+        torch.cuda.synchronize()
+        old = {"z": z, "dy1": i[0], "ds": o[1], "dg1": i[2], "db1": i[3], "dgt": o[2], "dbt": o[3], "dbias_s": o[4], "dbias1": i[4]}
+        for k, w in old.items():
+            e = _err(new[k].float().cpu(), w.float().cpu())
+            assert e <= 2.5e-2, (k, e, (B, C, H, W))
+
+
+def test_a_cluster_wait_that_gives_up_is_reported_not_silent():
+    """advisor (round 4): a GroupNorm cluster kernel whose arrival poll ran out used to go on with whatever records there were.  Development knob
+    25 = 1000 + n bounds the poll to n tries: with 0 the first workgroups of every cluster give up, the kernel must set the device error word and
+    kernels.check_device_errors() -- which FusedAdam.step() calls once per step -- must raise."""
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd._lib import dev_library, MteError
+    K.set_compute_dtype("bf16")
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 8, 512, 24, 80
+    y = K.as_act(torch.randn(B, C, H, W, generator=g).to(dev), torch.bfloat16)
+    gm, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    with dev_library() as lib:
+        K.check_device_errors()                                   # (allocates this build's error word; nothing pending)
+        assert lib.mte_gn_fwd_is_single_pass_b(B, H * W, C, 0, 0) == 1
+        lib.mte_debug_set(25, 1000)
+        try:
+            K._gn_forward(y, None, None, gm, bt, 1e-5)
+            torch.cuda.synchronize()
+            with pytest.raises(MteError, match="device error word"):
+                K.check_device_errors()
+            K.check_device_errors()                               # cleared by the poll
+        finally:
+            lib.mte_debug_set(25, 1000 + (1 << 24))
+        z, _ = K._gn_forward(y, None, None, gm, bt, 1e-5)          # and the normal bound works as before
+        torch.cuda.synchronize()
+        K.check_device_errors()
+        assert bool(torch.isfinite(z.float()).all())
