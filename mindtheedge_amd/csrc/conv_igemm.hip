@@ -23,6 +23,10 @@
 #include "common.hpp"
 #include "conv_args.hpp"
 
+// conv_wgrad9.hip: the nine-tap 3x3 weight gradient (bf16).  MTE_ERR_UNSUPPORTED when the shape is outside what the kernel covers.
+__attribute__((visibility("hidden"))) int wgrad9_launch(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int parts_cap, int* parts_out,
+                                                        int B, int H, int W, int Cin_p, int N, hipStream_t st);
+
 // In-loop s_memtime sums of the DMA main loop (diagnostic build only: -DMTE_STAMPS, tools/igemm_stamps.py).  Round-3 reading, cycles per K-step
 // and wave: 256 x 128 tile (512 -> 512 @24x80) stage wait 57 | barrier 314 | DMA issue 267 | fragment reads + MFMA issue 468 | total 1192
 // (MFMA pipe busy 512); 256 x 256 tile (256 -> 256 @48x160) 68 | 861 | 207 | 484 | 1707 (pipe busy 1024).  Issuing the DMA behind the MFMAs
@@ -1587,7 +1591,9 @@ extern "C" int mtei_set_pack3d_lds(int value);
 extern "C" int mtei_set_gn(int which, int value);
 extern "C" int mtei_set_patch_tall(int v);
 extern "C" int mtei_set_head_mfma(int v);
+extern int g_wgrad9;
 int mte_debug_set(int key, int value) {
+    if (key == 26) { g_wgrad9 = value; return MTE_OK; }
     if (key == 30) return mtei_set_head_mfma(value);
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
     if (key == 1) return mtei_set_pack3d_lds(value);
@@ -1652,6 +1658,11 @@ int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* d
     if (!x || !dy || !dw_stage) return MTE_ERR_ARG;
     if (Cin_p % 8 != 0 || N % 8 != 0) return MTE_ERR_ARG;
     WgradArgs a{x, ldx, dy, ldy, dw_stage, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, 0, 0, 0};
+    if (dtype == MTE_DT_BF16 && KH == 3 && KW == 3 && stage_parts >= 1 && parts_out) {
+        // round 5: the 3x3 layers with >= 64 / 128 channels take all nine taps from one staged patch (conv_wgrad9.hip)
+        const int rc = wgrad9_launch(x, ldx, dy, ldy, dw_stage, stage_parts, parts_out, B, H, W, Cin_p, N, stream);
+        if (rc != MTE_ERR_UNSUPPORTED) return rc;
+    }
     if (dtype == MTE_DT_BF16) return dispatch_wgrad<bf16_t>(a, stream, stage_parts, parts_out);
     if (dtype == MTE_DT_F32) return dispatch_wgrad<float>(a, stream, stage_parts, parts_out);
     return MTE_ERR_UNSUPPORTED;

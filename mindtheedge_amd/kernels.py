@@ -785,7 +785,7 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     # generic kernel: <= 32 pixel splits -- except where a slab is small (1x1 shortcuts: 64 KB .. 1 MB): one output tile means the pixel splits
     # ARE the launch's workgroups, and 32 of them streamed the two 63 MB operands of a full-resolution shortcut at 1.4 TB/s (round 4)
     # (0.091 -> 0.035 ms for 128 -> 128 at 96x320, 0.051 -> 0.026 ms for 256 -> 256 at 48x160 with up to 256 splits; the two-level part sum takes > 32 parts)
-    wide = 256 if per <= (1 << 18) else 32
+    wide = 256 if per <= (1 << 18) else (64 if per <= (1 << 19) else 32)      # (64: the nine-tap kernel's 128 -> 256 layer, 4 tiles x 64 pixel splits)
     cap = max(1, min(512, (192 << 20) // (4 * per))) if patch and _cfg["patch_wgrad_slabs"] else max(1, min(wide, (96 << 20) // (4 * per)))
     stem = _stem_ok(W, Cp, cout, kh, kw, x.dtype)
     if stem:

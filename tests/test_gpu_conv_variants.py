@@ -299,3 +299,56 @@ def test_eight_phase_igemm_equals_the_128x128_tile_bit_for_bit(devlib, shape, pe
         K._splitk_workspace = saved
         devlib.mte_debug_set(23, 19); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
         K.use_patch_kernels(True)
+
+
+# ---- round 5: the nine-tap 3x3 weight gradient (csrc/conv_wgrad9.hip) behind mte_conv2d_wgrad
+WGRAD9_SHAPES = [  # cin, cout, B, H, W, input as a channel slice of a wider buffer?
+    (128, 128, 2, 16, 64, False),      # one tile, 1 x 32 K-steps
+    (256, 256, 2, 12, 32, False),      # 2 x 4 tiles, one K-step per image row: every patch column block touches both borders
+    (128, 256, 2, 8, 80, False),       # 80-pixel rows: 2 x 16 K-steps (the 24x80 layers' form)
+    (512, 512, 1, 8, 48, False),       # 2 x 16 K-steps, 4 x 8 tiles, few K-steps per split
+    (192, 128, 1, 6, 160, True),       # three input tiles out of a 256-channel buffer (a decoder concat slice)
+    (64, 384, 3, 10, 32, False),       # three output tiles, three images
+    (256, 128, 1, 5, 64, True),        # odd height
+    (64, 128, 8, 24, 80, False),       # many pixel splits (one tile: splits = the CU count, capped by the stage)
+]
+
+
+@pytest.mark.parametrize("shape", WGRAD9_SHAPES)
+def test_nine_tap_wgrad_matches_the_per_tap_kernel_and_fp64(shape, devlib):
+    """mte_conv2d_wgrad's nine-tap kernel against the generic per-tap kernel (development knob 26 = 0) on identical bf16 operands -- fp32
+    accumulation, only the order of the pixel sum differs -- against an fp64 convolution gradient of the same rounded operands, and twice
+    bit for bit (plain stores into per-split slabs, fixed-order sums)."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, B, H, W, sliced = shape
+    K.set_compute_dtype("bf16")
+    K.use_patch_kernels(False)
+    try:
+        g = torch.Generator().manual_seed(cin + 3 * cout + W)
+        xf = (torch.rand(B, cin, H, W, generator=g) * 2 - 1).bfloat16().float()
+        gf = (torch.rand(B, cout, H, W, generator=g) * 2 - 1).bfloat16().float()
+        w = torch.zeros(cout, cin, 3, 3, device="cuda")
+        if sliced:
+            buf = K.new_act(B, cin + 64, H, W, torch.bfloat16)
+            buf.zero_()
+            x = K.channel_slice(buf, 32, 32 + cin)
+            x.copy_(xf.cuda())
+        else:
+            x = K.as_act(xf.cuda(), torch.bfloat16)
+        dy = K.as_act(gf.cuda(), torch.bfloat16)
+        assert devlib.mte_debug_set(26, 1) is None
+        a, _ = K._conv_wgrad(x, dy, w, False, None, None)
+        a2, _ = K._conv_wgrad(x, dy, w, False, None, None)
+        devlib.mte_debug_set(26, 0)
+        r, _ = K._conv_wgrad(x, dy, w, False, None, None)
+        torch.cuda.synchronize()
+        assert torch.equal(a, a2)
+        assert rel_err(a.cpu(), r.cpu()) < 2e-4
+        xd = xf.double().requires_grad_(False)
+        wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = torch.nn.functional.conv2d(xd, wd, None, padding=1)
+        (y * gf.double()).sum().backward()
+        assert rel_err(a.cpu(), wd.grad) < 2e-5, rel_err(a.cpu(), wd.grad)
+    finally:
+        devlib.mte_debug_set(26, 1)
+        K.use_patch_kernels(True)
