@@ -19,7 +19,8 @@
 //     of LDS reads per CU -- the 8-phase forward kernel's ratio.
 //   * operands transposed on the way out of LDS (ds_read_b64_tr_b16: the reduction runs over PIXELS, memory is pixel-major): inline asm with
 //     hand-counted lgkmcnt, as in conv_wgrad_dma_kernel (the compiler would fence the intrinsic against the in-flight DMA).
-//   * 3-slot ring, one s_barrier per K-step, counted vmcnt (the next K-step's three pieces per wave stay in flight across the barrier).
+//   * 4-slot ring, one s_barrier per K-step, counted vmcnt (three pieces per wave stay in flight across the barrier); the fragment reads run two
+//     taps ahead of their MFMAs and cross the K-step boundary (the next K-step's slot is complete one barrier early).
 //   * LDS swizzles (on the DMA source chunk, the same XOR on the read): dy rows of 256 B: chunk ^= 2 * ((k & 3) | ((k >> 3) & 1) << 2);
 //     x pixels of 128 B: chunk ^= (((px >> 1) & 1) << 1) | (((px >> 3) & 1) << 2) -- the eight 32-byte blocks a 32-lane half of a transposing
 //     read touches (pixels s..s+3 and s+8..s+11, any shift s) fall on 64 distinct banks.
@@ -27,6 +28,13 @@
 //     [N][9][Cin_p] staging slab of its pixel split (plain stores; mte_unpack_conv_wgrad adds the slabs in order: no atomics, bit-reproducible).
 #include "common.hpp"
 #include <type_traits>
+
+// Private diagnostic builds (tools/w9_ablate.py; the shipped library defines none of this): leave out pieces of the main loop to see what a K-step
+// costs.  bit 0: no LDS-DMA in the loop, 1: no MFMAs, 2: no fragment reads, 3: no barrier, 4: no epilogue stores, 5: no vmcnt wait in the loop,
+// 6: only the dy piece of every K-step, 7: every DMA out of range (issued, nothing fetched).  Results are wrong by design.
+#ifndef MTE_W9_ABL
+#define MTE_W9_ABL 0
+#endif
 
 struct Wgrad9Args {
     const bf16_t* x; long ldx;
@@ -61,15 +69,23 @@ __device__ __forceinline__ bf16x8_t frag(unsigned long long lo, unsigned long lo
 __device__ __forceinline__ int swz_y(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }          // 16-byte chunk XOR of dy row k (0..31)
 __device__ __forceinline__ int swz_x(int px) { return (((px >> 1) & 1) << 1) | (((px >> 3) & 1) << 2); } // ... of patch pixel px
 
-// RK = 1: a K-step is 32 consecutive pixels of one image row; RK = 2: 16 columns of two consecutive rows (k < 16: the upper row)
+// RK = 1: a K-step is 32 consecutive pixels of one image row; RK = 2: 16 columns of two consecutive rows (k < 16: the upper row).
+// K-steps are numbered DOWN the image first: u = (image * CB + column block) * RB + row block -- along a column walk only the first and the last
+// K-step touch the zero padding, so the loader's per-lane offsets (valid / out of range) change a few times per column, not every K-step.
+//
+// What bounds the loop (profiles/r05_wgrad9_steps.txt: ablation of the first two versions): a SIMD issues ~one instruction per 4 cycles for BOTH of
+// its waves together -- MFMA time, fragment reads, DMA bookkeeping and waits ADDED UP (2,200 cycles per K-step against 1,152 of MFMA pipe time).
+// So this version spends instructions only where it must: 36 MFMAs + 26 reads + 3 DMA per wave and K-step, LDS addresses as immediates (the loop
+// is unrolled over the four ring slots; two base registers per lane offset), six counted waits, and a loader that adds two scalar strides.
 template <int RK>
 __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     constexpr int CK = 32 / RK;                       // columns of a K-step
     constexpr int PW = CK + 8, PR = RK + 2;           // patch: PR rows x PW pixels (columns x0 - 4 .. x0 + CK + 3: whole 8-pixel pieces)
     constexpr int PB = PW / 8, NX = PR * PB;          // 1-KiB pieces per patch row, per patch
-    constexpr int SLOT = 24 * 1024;                   // 8 dy pieces + NX x pieces + (16 - NX) pieces of padding: 3 pieces per wave and K-step
-    constexpr int XOFF = 8 * 1024;
-    constexpr int RING = 3;
+    constexpr int RING = 4;
+    constexpr int YSLOT = 8 * 1024, XSLOT = 16 * 1024; // per ring slot: 8 dy pieces; NX x pieces (+ 16 - NX pieces of padding): 3 pieces per wave and K-step
+    constexpr int XBASE = RING * YSLOT;               // LDS: [RING][dy 8 KiB] then [RING][x 16 KiB] -- every slot, tap row and second read is a 16-bit
+                                                      // immediate off ONE base register per lane offset (x: 3 * 16 KiB + 2 * PW * 128 < 64 KiB)
     static_assert(NX <= 16 && NX >= 8, "three pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -84,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     const int u0 = split * a.units_per_split;
     const int u1 = min(a.units, u0 + a.units_per_split);
     const int nst = u1 - u0;
-    const int CB = a.W / CK, RB = a.H / RK;           // K-steps per image row (pair), row (pairs) per image
+    const int CB = a.W / CK, RB = a.H / RK;           // column blocks per image row, row blocks per image
 
     // ---- DMA lane constants.  piece 0: dy pixels 4 wv .. 4 wv + 3 (16 chunks each); pieces 1, 2: patch pieces wv and wv + 8 (8 pixels x 8 chunks)
     unsigned voffY;
@@ -93,15 +109,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
         const int dr = RK == 1 ? 0 : (k >> 4), dc = RK == 1 ? k : (k & 15);
         voffY = (unsigned)((((long)dr * a.W + dc) * a.ldy + n0 + c * 8) * 2);
     }
-    unsigned voffX[2]; int colX[2], rowX[2]; bool realX[2];
+    unsigned voffX[2];
+    bool realX[2], rowTop[2], rowBot[2], colL[2], colR[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pc = wv + 8 * j;                    // patch piece
         realX[j] = pc < NX;
         const int pr = pc / PB, pb = pc - pr * PB;
         const int px = pb * 8 + (lane >> 3), c = (lane & 7) ^ swz_x(px);
-        rowX[j] = pr - 1;                             // image row relative to the K-step's first row
-        colX[j] = px - 4;                             // image column relative to x0
+        rowTop[j] = pr == 0; rowBot[j] = pr == PR - 1;                 // the patch rows above / below the K-step's own rows (wave-uniform)
+        colL[j] = pb == 0; colR[j] = pb == PB - 1;                     // the pieces that hold the patch's alignment columns (wave-uniform): their lanes
+                                                                        // (lane >> 3) < 4 resp. >= 4 lie left / right of the K-step's own columns + 1
         // (the descriptor's base sits (W + 4) pixels in front of the tensor: every lane offset is non-negative)
         voffX[j] = (unsigned)((((long)pr * a.W + px) * a.ldx + c0 + c * 8) * 2);
     }
@@ -111,39 +129,67 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - (long)(a.W + 4) * a.ldx), 0,
                                                        (int)((((long)a.B * a.H * a.W + 2 * a.W + 16) * a.ldx) * 2), 0x00020000);
 #endif
-    // the loader's position: K-step f_u = (image f_b, row block f_yb, column block f_xb)
-    int f_u = u0, f_b, f_yb, f_xb;
-    { const int per_img = RB * CB; f_b = u0 / per_img; const int r = u0 - f_b * per_img; f_yb = r / CB; f_xb = r - f_yb * CB; }
-    auto stage = [&](int slot) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        char* sb = smem + slot * SLOT;
+    // ---- the loader's position: K-step f_u = (image f_b, column block f_xb, row block f_yb); byte offsets of its first pixel; the lane offsets in use
+    int f_u = u0, f_b, f_xb, f_yb;
+    { const int per_img = RB * CB; f_b = u0 / per_img; const int r = u0 - f_b * per_img; f_xb = r / RB; f_yb = r - f_xb * RB; }
+    int soffY, soffX;
+    unsigned voY, voX[2];
+    const int stepY = (int)((long)RK * a.W * a.ldy * 2), stepX = (int)((long)RK * a.W * a.ldx * 2);
+    const unsigned inner = RB > 3 ? (unsigned)(RB - 3) : 0u;          // row blocks 2 .. RB - 2 need no look at the lane offsets (none when RB < 4)
+    auto locate = [&]() {                             // offsets of the column's first K-step
+        const long pix = ((long)f_b * a.H + (long)f_yb * RK) * a.W + f_xb * CK;
+        soffY = (int)(pix * a.ldy * 2); soffX = (int)(pix * a.ldx * 2);
+    };
+    auto classify = [&]() {                           // which lanes of this K-step's pieces lie outside the image (or past the split's end)
         const bool live = f_u < u1;
-        const int y = f_yb * RK, x0 = f_xb * CK;
-        const long pix = ((long)f_b * a.H + y) * a.W + x0;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lptr_t)(sb + wv * 1024), 16, live ? voffY : OOB9, (int)(pix * a.ldy * 2), 0, 0);
+        const bool top = f_yb == 0, bot = f_yb == RB - 1, left = f_xb == 0, right = f_xb == CB - 1;
+        voY = live ? voffY : OOB9;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int iy = y + rowX[j];
-            const bool ok = live && realX[j] && (unsigned)iy < (unsigned)a.H && (unsigned)(x0 + colX[j]) < (unsigned)a.W;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(sb + XOFF + (wv + 8 * j) * 1024), 16, ok ? voffX[j] : OOB9, (int)(pix * a.ldx * 2), 0, 0);
+            // (bitwise on purpose: `||` over lane-varying operands becomes divergent control flow)
+            const bool bad = (!live) | (!realX[j]) | (top & rowTop[j]) | (bot & rowBot[j]) | (left & colL[j] & (lane < 32)) | (right & colR[j] & (lane >= 32));
+            voX[j] = bad ? OOB9 : voffX[j];
         }
-        ++f_u;
-        if (++f_xb == CB) { f_xb = 0; if (++f_yb == RB) { f_yb = 0; ++f_b; } }
+    };
+    locate(); classify();
+    auto stage = [&](auto S) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        constexpr int slot = decltype(S)::value;
+        if (MTE_W9_ABL & 128) { voY = OOB9; voX[0] = OOB9; voX[1] = OOB9; }
+        if (!(MTE_W9_ABL & 1)) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lptr_t)(smem + slot * YSLOT + wv * 1024), 16, voY, soffY, 0, 0);
+            if (!(MTE_W9_ABL & 64)) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(smem + XBASE + slot * XSLOT + wv * 1024), 16, voX[0], soffX, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(smem + XBASE + slot * XSLOT + 8192 + wv * 1024), 16, voX[1], soffX, 0, 0);
+            }
+        }
+        // on to the next K-step: one row block down; the lane offsets change only at the ends of a column
+        ++f_u; ++f_yb;
+        soffY += stepY; soffX += stepX;
+        if ((unsigned)(f_yb - 2) >= inner || f_u >= u1) {                       // f_yb in {1, RB - 1, RB (wraps below)} or the end of the split: rare
+            if (f_yb >= RB) {
+                f_yb = 0;
+                if (++f_xb == CB) { f_xb = 0; ++f_b; }
+                locate();
+            }
+            classify();
+        }
 #else
-        (void)slot;
+        (void)S;
 #endif
     };
 
-    // ---- fragment read constants.  16-lane group g holds k = 8 g .. 8 g + 7 (two transposing reads of 4 pixel rows), lane li = 4 q + pp of
-    // the group supplies row q, 8-byte quarter pp of the 32-byte channel block
+    // ---- fragment read addresses.  16-lane group g holds k = 8 g .. 8 g + 7 (two transposing reads of 4 pixel rows), lane li = 4 q + pp of the
+    // group supplies row q, 8-byte quarter pp of the 32-byte channel block.  One register per lane offset; ring slot, tap row and second read are immediates.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-    unsigned offY[4];                                 // + 1024: the second read (k + 4: same swizzle)
+    unsigned adY[4];                                  // [block]; + slot * YSLOT, + 1024: the second read (k + 4: same swizzle)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = 8 * g + q, cb = wm * 4 + i;
-        offY[i] = (unsigned)(k * 256 + (((2 * cb + (pp >> 1)) ^ swz_y(k)) * 16) + (pp & 1) * 8);
+        adY[i] = lds0 + (unsigned)(k * 256 + (((2 * cb + (pp >> 1)) ^ swz_y(k)) * 16) + (pp & 1) * 8);
     }
-    unsigned offX[3][2];                              // [kx][read]; + ky * PW * 128
+    unsigned adX[3][2];                               // [kx][read]; + slot * XSLOT + ky * PW * 128
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -151,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
             const int k = 8 * g + q + 4 * rd;
             const int r = RK == 1 ? 0 : (k >> 4);
             const int px = (RK == 1 ? k : (k & 15)) + kx + 3;
-            offX[kx][rd] = (unsigned)(XOFF + (r * PW + px) * 128 + (((2 * wn + (pp >> 1)) ^ swz_x(px)) * 16) + (pp & 1) * 8);
+            adX[kx][rd] = lds0 + XBASE + (unsigned)((r * PW + px) * 128 + (((2 * wn + (pp >> 1)) ^ swz_x(px)) * 16) + (pp & 1) * 8);
         }
 
     f32x4_t acc[4][9];
@@ -160,49 +206,66 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 #define W9_WAIT_LGKM(N) { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
-    // taps of one kernel row: x fragments two reads ahead of their MFMAs
-    auto tap_row = [&](unsigned sb, const bf16x8_t (&fy)[4], auto KY) {
-        constexpr int ky = decltype(KY)::value;
-        unsigned long long xa[3][2];
+#define W9_C(N) std::integral_constant<int, N>{}
+    // ---- main loop: two PHASES per K-step, the two wave groups (waves w and w + 4 share a SIMD) one barrier apart -- the scheme of the 8-phase
+    // forward kernel (conv_igemm8.hip).  Measured on the first versions of this kernel (profiles/r05_wgrad9_steps.txt): with both waves of a SIMD
+    // running the same instruction mix, MFMA time, fragment reads and LDS-DMA issue ADD UP (a DMA instruction holds its wave ~100 cycles); apart by a
+    // barrier, one wave's load phase sits under the other's MFMAs.
+    //   L(i): DMA of K-step i + 3 (3 pieces) | all 26 fragment reads of K-step i into registers | vmcnt: own pieces of K-step i + 1 landed | lgkmcnt(0) | barrier
+    //   M(i): 36 MFMAs from registers | barrier
+    // Hazards by barrier count (group 0: L(i) between barriers 2i and 2i + 1, M(i) up to 2i + 2; group 1 one later):
+    //   RAW  a wave reads slot i + 1 in L(i + 1); every wave waited for its pieces of K-step i + 1 before the barrier that ends its L(i), which is not
+    //        later than barrier 2i + 2, where the earlier group's L(i + 1) begins.
+    //   WAR  stage i + 3 goes over slot i - 1 (RING = 4); its last reads are retired (lgkmcnt(0)) before the barrier that ends group 1's L(i - 1) =
+    //        barrier 2i, where group 0's L(i) begins.
+    unsigned long long ya[4][2], xt[9][2];
+    auto rd_y = [&](auto S) {
+        constexpr int s = decltype(S)::value, o = s * YSLOT;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            xa[kx][0] = tr16o<ky * PW * 128>(sb + offX[kx][0]);
-            xa[kx][1] = tr16o<ky * PW * 128>(sb + offX[kx][1]);
-        }
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            if (kx == 0) W9_WAIT_LGKM(4) else if (kx == 1) W9_WAIT_LGKM(2) else W9_WAIT_LGKM(0)
-            const bf16x8_t fx = frag(xa[kx][0], xa[kx][1]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fy[i], acc[i][ky * 3 + kx], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 4; ++i) {
+            if (MTE_W9_ABL & 4) { asm volatile("" : "+v"(ya[i][0]), "+v"(ya[i][1])); continue; }
+            ya[i][0] = tr16o<o>(adY[i]); ya[i][1] = tr16o<o + 1024>(adY[i]);
         }
     };
-
-    stage(0); stage(1);
-    for (int it = 0; it < nst; ++it) {
-        // this wave's three pieces of K-step `it` have landed (the three of K-step it + 1 may still be in flight); after the barrier everybody's have
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int slot = it % RING;
-        stage((it + 2) % RING);                       // over the slot K-step it - 1 was read from: every wave finished those reads before this barrier
-        const unsigned sb = lds0 + slot * SLOT;
-        unsigned long long ya[4][2];
+    auto rd_x = [&](auto S, auto T) {
+        constexpr int s = decltype(S)::value, t = decltype(T)::value, ky = t / 3, kx = t % 3, o = s * XSLOT + ky * PW * 128;
+        if (MTE_W9_ABL & 4) { asm volatile("" : "+v"(xt[t][0]), "+v"(xt[t][1])); return; }
+        xt[t][0] = tr16o<o>(adX[kx][0]); xt[t][1] = tr16o<o>(adX[kx][1]);
+    };
+    auto mma = [&](auto T) {
+        constexpr int t = decltype(T)::value;
+        if (MTE_W9_ABL & 2) { asm volatile("" ::"v"(xt[t][0]), "v"(xt[t][1]), "v"(ya[0][0]), "v"(ya[1][1]), "v"(ya[2][0]), "v"(ya[3][1])); return; }
+        const bf16x8_t fx = frag(xt[t][0], xt[t][1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ya[i][0] = tr16(sb + offY[i]); ya[i][1] = tr16o<1024>(sb + offY[i]); }
+        for (int i = 0; i < 4; ++i)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, frag(ya[i][0], ya[i][1]), acc[i][t], 0, 0, 0);
+    };
+#define W9_BARRIER() { __builtin_amdgcn_sched_barrier(0); if (!(MTE_W9_ABL & 8)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    auto kstep = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        stage(W9_C((s + 3) & 3));
+        rd_y(S);
+        rd_x(S, W9_C(0)); rd_x(S, W9_C(1)); rd_x(S, W9_C(2)); rd_x(S, W9_C(3)); rd_x(S, W9_C(4));
+        rd_x(S, W9_C(5)); rd_x(S, W9_C(6)); rd_x(S, W9_C(7)); rd_x(S, W9_C(8));
+        if (!(MTE_W9_ABL & 32)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         W9_WAIT_LGKM(0)
-        bf16x8_t fy[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fy[i] = frag(ya[i][0], ya[i][1]);
-        tap_row(sb, fy, std::integral_constant<int, 0>{});
-        tap_row(sb, fy, std::integral_constant<int, 1>{});
-        tap_row(sb, fy, std::integral_constant<int, 2>{});
-    }
+        W9_BARRIER()
+        __builtin_amdgcn_s_setprio(1);
+        mma(W9_C(0)); mma(W9_C(1)); mma(W9_C(2)); mma(W9_C(3)); mma(W9_C(4)); mma(W9_C(5)); mma(W9_C(6)); mma(W9_C(7)); mma(W9_C(8));
+        __builtin_amdgcn_s_setprio(0);
+        W9_BARRIER()
+    };
+
+    stage(W9_C(0)); stage(W9_C(1)); stage(W9_C(2));
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K-step 0 has landed
+    W9_BARRIER()
+    if (wm == 1) W9_BARRIER()                          // group 1 runs one barrier behind from here on
+    // (no early exit from the unrolled body: with exits between the four K-steps the compiler no longer keeps the 144 accumulator registers in place
+    //  -- 441 spilled registers; a split whose K-step count is not a multiple of four runs up to three K-steps on zero-filled slots instead, and the
+    //  launcher deals multiples of four)
+    for (int it = 0; it < nst; it += 4) { kstep(W9_C(0)); kstep(W9_C(1)); kstep(W9_C(2)); kstep(W9_C(3)); }
+    if (wm == 0) W9_BARRIER()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero-filling pieces past the end)
 
     // ---- epilogue: acc[i][t][e] = dW[n0 + wm * 64 + i * 16 + (lane & 15)][t][c0 + wn * 16 + 4 * (lane >> 4) + e]
@@ -211,7 +274,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) *(f32x4_t*)(dst0 + (long)i * 16 * Kp + (long)t * a.Cin_p) = acc[i][t];
+        for (int t = 0; t < 9; ++t) {
+            if ((MTE_W9_ABL & 16) && acc[i][t][0] != 12345.f) continue;
+            *(f32x4_t*)(dst0 + (long)i * 16 * Kp + (long)t * a.Cin_p) = acc[i][t];
+        }
 }
 
 int g_cus9 = 0;
@@ -224,7 +290,10 @@ int g_wgrad9 = 1;                                    // development knob (mte_de
 __attribute__((visibility("hidden"))) int wgrad9_launch(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int parts_cap, int* parts_out,
                                                         int B, int H, int W, int Cin_p, int N, hipStream_t st) {
     if (!g_wgrad9 || N % 128 != 0 || Cin_p % 64 != 0 || parts_cap < 1) return MTE_ERR_UNSUPPORTED;
-    const int rk = W % 32 == 0 ? 1 : ((W % 16 == 0 && H % 2 == 0) ? 2 : 0);
+    // 1 x 32 K-steps where the rows allow it: measured 2-4 % faster on the 48x160 layers than 2 x 16 ones although they stage 15 patch pieces against 12
+    // (development knob 26 = 2: 2 x 16 first)
+    const bool ok2 = W % 16 == 0 && H % 2 == 0, ok1 = W % 32 == 0;
+    const int rk = g_wgrad9 == 2 ? (ok2 ? 2 : (ok1 ? 1 : 0)) : (ok1 ? 1 : (ok2 ? 2 : 0));
     if (!rk) return MTE_ERR_UNSUPPORTED;
     const long M = (long)B * H * W;
     if (((M + 2 * W + 16) * ldx) * 2 >= 0x7ff00000L || ((M - 1) * ldy + N) * 2 >= 0x7ff00000L) return MTE_ERR_UNSUPPORTED;
@@ -245,10 +314,11 @@ __attribute__((visibility("hidden"))) int wgrad9_launch(const void* x, long ldx,
     if (splits > parts_cap) splits = parts_cap;
     if (splits > a.units / 12) splits = a.units / 12 > 0 ? a.units / 12 : 1;
     a.units_per_split = (int)((a.units + splits - 1) / splits);
+    a.units_per_split = (a.units_per_split + 3) & ~3;  // the main loop is unrolled over its four ring slots
     splits = (a.units + a.units_per_split - 1) / a.units_per_split;
     a.part_stride = (long)N * 9 * Cin_p;
     if (parts_out) *parts_out = (int)splits;
-    constexpr int LDS = 3 * 24 * 1024;
+    constexpr int LDS = 4 * (8 + 16) * 1024;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)conv_wgrad9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||

@@ -65,3 +65,30 @@ def test_shipped_patch_kernel_passes_the_audit(tmp_path):
     checked, findings = _auditor().audit(out.read_text())
     assert checked >= 72, "the 3x3 kernels alone hold 4 x 18 asm loads: the auditor no longer finds them (%d)" % checked
     assert not findings, "\n".join(findings[:10])
+
+
+def test_nine_tap_wgrad_kernel_keeps_its_hand_waited_lds_reads_in_order(tmp_path):
+    """round 5: conv_wgrad9.hip reads its MFMA operands with inline-asm ds_read_b64_tr_b16 (26 per K-step, issued in the load phase and retired
+    by a hand-placed lgkmcnt wait in front of the barrier that opens the MFMA phase).  tools/w9_audit.py walks the compiler's .s along the main loop's control flow: no instruction may touch a
+    destination while its read is outstanding, and the loop must hold the 26 reads / 36 MFMAs per K-step the source is written for."""
+    sys.path.insert(0, ROOT)
+    from mindtheedge_amd import _build
+    spec = importlib.util.spec_from_file_location("w9_audit", os.path.join(ROOT, "tools", "w9_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "conv_wgrad9.s"
+    cmd = [_build._hipcc()] + _build.FLAGS + ["-S", "--cuda-device-only", os.path.join(_build.CSRC, "conv_wgrad9.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    assert mod.audit(str(out)) == 0
+    text = out.read_text()
+    # two instantiations, main loop unrolled over the four ring slots: 4 x (26 reads, 36 MFMAs)
+    assert text.count("ds_read_b64_tr_b16") == 2 * 4 * 26 and text.count("v_mfma_f32_16x16x32_bf16") == 2 * 4 * 36
+    # (a handful of loop-invariant values -- epilogue pointers, the loader's lane offsets, used in its rare end-of-column block -- may live in scratch;
+    #  nothing of the K-step path does: the loop body proper holds no scratch access)
+    import re
+    assert all(int(m) <= 16 for m in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text))
+    # a stream the auditor must reject: an MFMA that reads a fragment in front of its wait
+    bad = tmp_path / "bad.s"
+    bad.write_text("_ZN1x18conv_wgrad9_kernelILi1EEEv: ; x\n\tds_read_b64_tr_b16 v[10:11], v2\n\tds_read_b64_tr_b16 v[12:13], v2 offset:1024\n"
+                   "\ts_waitcnt lgkmcnt(1)\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[10:13], v[20:23], v[0:3]\n\ts_endpgm\n")
+    assert mod.audit(str(bad)) == 1
