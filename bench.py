@@ -56,12 +56,19 @@ class ConvTimer:
         self.K, self.records, self.enabled = K, [], False
         lib = K.lib
         self._orig = {}
+        # (round 5: + the two LDS-patch forward entry points of round 4's late steps -- iconv1 / iconv2 with the rank-1 term inside, the 3x3 data
+        #  gradient that carries the 1x1 shortcut's -- which the round-4 line left out of the family: ~0.5 ms of conv kernels per step)
         for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad",
-                     "mte_conv2d_stem_fwd", "mte_conv2d_stem_wgrad"):
+                     "mte_conv2d_stem_fwd", "mte_conv2d_stem_wgrad", "mte_conv2d_patch_fwd_rank1", "mte_conv2d_patch_fwd_plus1x1"):
             self._orig[name] = getattr(lib, name)
+        self._optional = ("mte_gn_tail_fwd",)   # (entry points an older build of the library lacks: same-box A/B of two trees with ONE bench.py)
         self.hbm_records = []           # (name, e0, e1, algorithmic bytes) of the GroupNorm+ELU passes (HBM-bound family)
-        for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd"):
-            self._orig[name] = getattr(lib, name)
+        for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd", "mte_gn_tail_fwd"):
+            try:
+                self._orig[name] = getattr(lib, name)
+            except AttributeError:
+                if name not in self._optional:
+                    raise
         self.loss_records = []          # the fused depth-edge loss stencils ("reported as HBM GB/s vs 8.0 TB/s")
         for name in ("mte_edge_loss_fwd", "mte_edge_loss_bwd", "mte_edge_loss_multi_fwd", "mte_edge_loss_multi_bwd"):
             self._orig[name] = getattr(lib, name)
@@ -104,7 +111,10 @@ class ConvTimer:
                         return
                     if name.startswith("mte_gn_"):
                         # algorithmic bytes: every tensor the pass must touch once (2 B/element in bf16)
-                        if name == "mte_gn_stats":          # (y1, ld1, y2, ld2, scale2, stats, B, HW, C, dtype, stream)
+                        if name == "mte_gn_tail_fwd":       # (y1, ld1, stats1, gamma1, beta1, y2, ld2, scale2, t, ldt, stats_t, gamma_t, beta_t, z, ldz, B, HW, C, eps, dtype, stream)
+                            (B_, HW_, C_), dt_ = args[15:18], args[19]
+                            tensors = 5                                         # read y1, y2, write t; read t, write z
+                        elif name == "mte_gn_stats":        # (y1, ld1, y2, ld2, scale2, stats, B, HW, C, dtype, stream)
                             has2, (B_, HW_, C_, dt_) = bool(args[2]), args[6:10]
                             tensors = 1 + has2                                  # read y1 (+ y2)
                         elif name == "mte_gn_elu_fwd":      # (y1, ld1, y2, ld2, scale2, stats, stats_ready, gamma, beta, z, ldz, B, HW, C, eps, dtype, stream)
@@ -115,7 +125,13 @@ class ConvTimer:
                             tensors = 2 * (2 + has2) + 1 + hasd2                # reduce + apply each read dz, y1 (+ y2); write d1 (+ d2)
                         outer.hbm_records.append((name, e0, e1, float(tensors) * B_ * HW_ * C_ * (2 if dt_ == 0 else 4)))
                         return
-                    if name == "mte_conv2d_igemm":
+                    if name == "mte_conv2d_patch_fwd_rank1":     # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, inv, w1, stride, stream): 3x3 (+ the map's 16-slot MFMA step)
+                        shp = tuple(args[6:11]) + (3, 3)
+                    elif name == "mte_conv2d_patch_fwd_plus1x1":  # (dy, lddy, w, bias, dx, lddx, B, H, W, Cin_p, N, dy3, lddy3, w3, C3, stream): 3x3 over Cin_p + 1x1 over C3 channels
+                        B_, H_, W_, Ci_, N_ = args[6:11]
+                        outer.records.append((name, e0, e1, 2.0 * B_ * H_ * W_ * N_ * (9 * Ci_ + args[14]), (B_, H_, W_, Ci_, N_, 3, 3)))
+                        return
+                    elif name == "mte_conv2d_igemm":
                         shp = args[7:14]           # (x, ldx, w, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, ...)
                     elif name == "mte_conv2d_patch_fwd":
                         shp = args[6:13]           # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, KH, KW, stream)
@@ -163,7 +179,12 @@ def pmc_traffic_per_launch(args, B, H, W, launches_per_step, key="conv_family_MB
     if (d.get("mode"), d.get("batch"), d.get("height"), d.get("width"), d.get("dtype")) != (args.mode, B, H, W, args.dtype):
         return None
     mb = d.get(key)
-    return None if mb is None else mb * 1e6 / launches_per_step
+    # the figure is quoted only while THIS run counts the launches per step the PMC passes were taken with (round-4 advisor: a stale numerator
+    # over a live denominator); older files without the count are not used
+    rec = d.get(key.replace("_MB_per_step", "_api_launches_per_step"))
+    if mb is None or rec is None or abs(rec - launches_per_step) > 0.51:
+        return None
+    return mb * 1e6 / launches_per_step
 
 
 def conv_flops_per_image(H, W):
@@ -476,7 +497,7 @@ def main():
                 alg = conv2d_flops_per_image(H, W) * B * passes * ksteps          # algorithmic conv2d FLOPs of the timed launches
                 ach = alg / tot_t / 1e12
                 res["roofline"] = {"bound": "mfma", "kernel": "conv2d MFMA family (mte_conv2d_igemm fwd+dgrad, mte_conv2d_wgrad, "
-                                                              "mte_conv2d_patch_fwd, mte_conv2d_patch_wgrad, mte_conv2d_stem_fwd, mte_conv2d_stem_wgrad)",
+                                                              "mte_conv2d_patch_fwd (+ _rank1, _plus1x1), mte_conv2d_patch_wgrad, mte_conv2d_stem_fwd, mte_conv2d_stem_wgrad)",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": pmc_traffic_per_launch(args, B, H, W, n / ksteps),
                                    "launches_per_step": n / ksteps, "avg_launch_ms": tot_t / n * 1e3,
@@ -492,7 +513,7 @@ def main():
             if ht > 0:
                 # second roofline object: the HBM-bound GroupNorm+ELU family (26 of the 84 GB a step moves), same method --
                 # algorithmic bytes of the timed launches / HIP-event time, against the 8 TB/s HBM3E peak
-                res["roofline_hbm"] = {"bound": "hbm", "kernel": "GroupNorm(16)+ELU family (mte_gn_stats, mte_gn_elu_fwd, mte_gn_elu_bwd)",
+                res["roofline_hbm"] = {"bound": "hbm", "kernel": "GroupNorm(16)+ELU family (mte_gn_stats, mte_gn_elu_fwd, mte_gn_elu_bwd, mte_gn_tail_fwd)",
                                        "achieved": hb / ht / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / ht / 1e9 / HBM_PEAK_GBS,
                                        "traffic": pmc_traffic_per_launch(args, B, H, W, hn / ksteps, "gn_family_MB_per_step"),
                                        "launches_per_step": hn / ksteps, "ms_per_step": ht / ksteps * 1e3,

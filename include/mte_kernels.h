@@ -38,7 +38,8 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
  * reduction (pack4/pack5.conv at low resolution) are split along K over up to min(8, workspace_elems / (B*H*W*N)) workgroups
  * per tile.  Every split STORES its partial tile into its own [M][N] slab and a finish kernel adds the slabs in split order:
  * no floating-point atomics, the result is bit-reproducible and the workspace needs no clearing.
- * accumulate = 1: y += conv(x) (sum formed in fp32, rounded once): the second data gradient of an activation with two consumers
+ * accumulate = 1: y += conv(x) (conv + bias rounded to the activation type, added to the old value in fp32, rounded again -- every tile form
+ * alike): the second data gradient of an activation with two consumers
  * lands in the first one's buffer instead of going through a separate add.  `accumulate` is a bit set: MTE_CONV_ACCUMULATE (1) and
  * MTE_CONV_SOLO (2) = no kernel of another stream is expected to run beside this launch (forward pass, inference), so the 256 x 128
  * tile may use its 3-slot-ring variant that puts two workgroups on a CU and claims 148 of the 160 KB of LDS: measured 15-20 % faster

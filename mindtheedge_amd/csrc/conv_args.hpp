@@ -11,7 +11,9 @@ struct ConvArgs {
     long M;
     int splits; float* ws;          // split-K: split s STORES its partial sums into its own slab ws[s][M][N] (fp32); splitk_finish_kernel adds
                                     // the slabs in order -- no floating-point atomics, the result does not depend on the arrival order
-    int accum;                      // 1: y += conv (sum formed in fp32, rounded once) -- second gradient of a two-consumer activation
+    int accum;                      // 1: y += conv -- second gradient of a two-consumer activation.  Every tile form stages conv + bias in the OUTPUT type
+                                    // (its LDS image / packed registers), then adds the old value in fp32 and rounds again: two roundings, the same in
+                                    // all forms (they stay bit-identical with each other); only fp32 output (out_f32) rounds nothing
     int solo;                       // host-side hint (MTE_CONV_SOLO): nothing runs beside this launch on another stream
     // Sparse form (SAN branch, round 3): GEMM row m is pixel rows[m] of the dense NHWC maps, for m < *nrows (device-side count).  The
     // input map is zero-filled off the active set, so gathering a row's taps from it IS the sparse convolution's sum over active

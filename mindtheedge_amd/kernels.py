@@ -427,6 +427,8 @@ class WeightPack:
         self._last = (weakref.ref(w), dtype)
         self._order = next(WeightPack._seq)
         if key != self.key:
+            if self._event is not None:                      # a prefetch launch may still be writing these buffers on the side stream (advisor, round 4)
+                torch.cuda.current_stream().wait_event(self._event)
             self._event = None
             self._pack(w, dtype, need_bwd)
             self.key = key
@@ -507,6 +509,7 @@ def prefetch_weight_packs():
         side = torch.cuda.current_stream()
     with torch.cuda.stream(side):
         _refold_all()                                        # folded pack weights first: their packs are rebuilt below
+        _refresh_main_weights(packs)                         # ... and the main-channel copies of the rank-1 iconv layers
         for pk in packs:
             pk._want_pf = pk.pf_ok and pk.pkey == pk.key and pk.pf is not None
             pk._want_pb = pk.pb_ok and pk.pkey == pk.key and pk.pb is not None and pk.has_bwd
@@ -574,7 +577,9 @@ _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0
         "fold_shortcut_dgrad": os.environ.get("MTE_FOLD_SHORTCUT", "1") == "1",
         # residual blocks: conv2's GroupNorm + ELU applied inside the kernel that forms x_out + Dropout2d(shortcut) and takes the sum's statistics
         # (ConvResidualTailFn / mte_gn_tail_fwd).  MTE_FUSE_TAIL=0: the round-4 form (ConvGnEluFn + ResidualTailFn over two tensors)
-        "fuse_residual_tail": os.environ.get("MTE_FUSE_TAIL", "1") == "1"}
+        "fuse_residual_tail": os.environ.get("MTE_FUSE_TAIL", "1") == "1",
+        # residual blocks: the 1x1 shortcut's FORWARD launch on the (idle) weight-gradient side stream, beside conv1 / conv2.  MTE_OVERLAP_SHORTCUT=0: in line
+        "overlap_shortcut_fwd": os.environ.get("MTE_OVERLAP_SHORTCUT", "1") == "1"}
 
 
 def use_pack_folding(flag):
@@ -981,10 +986,29 @@ def _main_weight(pack, w, cm):
     if wm is None or tuple(wm.shape) != (w.shape[0], cm, w.shape[2], w.shape[3]) or wm.device != w.device:
         wm = pack._main_w = torch.empty((w.shape[0], cm, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device)
         pack._main_key = None
+    pack._main_src = (weakref.ref(w), cm)                # prefetch_weight_packs refreshes wm from the parameter before it re-packs (side stream)
     if pack._main_key != key:
         wm.copy_(w.detach()[:, :cm])
         pack._main_key = key
     return wm
+
+
+def _refresh_main_weights(packs):
+    """called by prefetch_weight_packs on the stream that re-packs, after the optimizer changed the parameters: the contiguous w[:, :C-1] copies of the
+    rank-1 iconv layers (ConvGnEluInvFn keys its packs on the COPY) are brought up to date first -- round 4 re-packed them from the stale copy and the
+    next forward pass then refreshed copy and packs on the main stream without waiting for that launch (advisor: a cross-stream write-after-read)."""
+    for pk in packs:
+        src = getattr(pk, "_main_src", None)
+        wm = getattr(pk, "_main_w", None)
+        if src is None or wm is None:
+            continue
+        w = src[0]()
+        if w is None or tuple(wm.shape) != (w.shape[0], src[1], w.shape[2], w.shape[3]):
+            continue
+        key = (w.data_ptr(), w._version, weights_epoch())
+        if pk._main_key != key:
+            wm.copy_(w.detach()[:, :src[1]])
+            pk._main_key = key
 
 
 class ConvGnEluInvFn(torch.autograd.Function):
@@ -1068,13 +1092,34 @@ class ConvFn(torch.autograd.Function):
     """Plain conv + bias (the 1x1 shortcut of ResidualConv, layers01.py:61)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, pack, bias_grad=True):
+    def forward(ctx, x, w, b, pack, bias_grad=True, overlap=False):
         """bias_grad=False: the consumer produces the bias gradient (ResidualTailFn: the column sums of this conv's output gradient fall
-        out of the GroupNorm backward pass that computes it -- no stand-alone column-sum launch)"""
+        out of the GroupNorm backward pass that computes it -- no stand-alone column-sum launch).
+        overlap=True (round 5): the launch goes to the weight-gradient side stream, which is idle during the forward pass -- a residual block's 1x1
+        shortcut depends only on the block's input and is not needed before the block's tail, so its HBM-bound launch (54-150 TFLOP/s) runs beside
+        conv1 / conv2 instead of between them.  The result carries the event its consumer must wait for (`wait_ready`); the backward pass is unchanged
+        (autograd sees one op on the main stream)."""
         ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
-        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
+        if overlap and _side["enabled"] and _cfg["overlap_shortcut_fwd"] and not torch.cuda.is_current_stream_capturing():
+            B, _, H, W = x.shape
+            y = new_act(B, cout, H, W, x.dtype, x.device)            # (allocated on the main stream: its memory is recycled in main-stream order)
+            if pack is not None and _patch_ok(W, x.shape[1], cout, kh, kw, x.dtype):
+                pack.get_patch(w, 'f')                               # (its re-pack, if due, stays on the main stream)
+            if not _side["streams"]:
+                _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
+            side = _side["streams"][0]
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                conv_forward(x, wf, b, cout, kh, kw, out=y, pack=pack, w=w)
+                done = torch.cuda.Event()
+                done.record(side)
+            y._mte_ready = done
+        else:
+            y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
         ctx.save_for_backward(x, w)
         ctx.pack = pack
         ctx.bias = b
@@ -1089,11 +1134,19 @@ class ConvFn(torch.autograd.Function):
         gw, sw = _grad_dst(w)
         if not ctx.bias_grad:
             dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw)
-            return dx, _grad_ret(w, dw, sw), None, None, None
+            return dx, _grad_ret(w, dw, sw), None, None, None, None
         gbias, sbias = _grad_dst(b)
         dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias, fork_slot=ctx.fork_slot,
                                    sunk=sw and sbias)
-        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None, None
+        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None, None, None
+
+
+def wait_ready(t):
+    """make the current stream wait for a result that was produced on the side stream (ConvFn overlap=True); a no-op otherwise"""
+    ev = getattr(t, "_mte_ready", None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        t._mte_ready = None
 
 
 class ResidualTailFn(torch.autograd.Function):
@@ -1104,6 +1157,7 @@ class ResidualTailFn(torch.autograd.Function):
         """bias_s: the bias parameter of the conv that produced `s` (the block's 1x1 shortcut).  Its value is already inside `s`; it is an
         input here only so that its GRADIENT -- sum of ds over batch and pixels -- can come out of this op's backward pass, where ds is
         formed anyway (the shortcut conv is then built with bias_grad=False)."""
+        wait_ready(s)
         z, stats = _gn_forward(a, s, scale, gamma, beta, GN_EPS)
         ctx.save_for_backward(a, s, stats, gamma, beta)
         ctx.scale = scale
@@ -1153,6 +1207,7 @@ class ConvResidualTailFn(torch.autograd.Function):
         p2, l2 = _pl(s)
         stats2 = gn_stats_buffer(B, c2.device)
         lib.mte_gn_stats(p1, l1, 0, 0, 0, stats2.data_ptr(), B, H * W, C, _dt(c2), st)
+        wait_ready(s)
         stats_t = gn_stats_buffer(B, c2.device)
         t = new_act(B, C, H, W, c2.dtype, c2.device)
         z = new_act(B, C, H, W, c2.dtype, c2.device)

@@ -80,20 +80,25 @@ class Decoder(nn.Module):
             cu = unp.conv.conv_base.out_channels                       # unpack output channels (out * r^2 / d == out)
             with_inv = lvl < 3
             cs = ico.conv_base.in_channels - cu - (1 if with_inv else 0)
-            buf = K.new_concat_buffer(B, [cu, cs], with_inv and not self._split_inv(cu + cs), H >> lvl, W >> lvl, device=device)
+            buf = K.new_concat_buffer(B, [cu, cs], with_inv and not self._split_inv(cu + cs, ico.conv_base.out_channels, H >> lvl, W >> lvl),
+                                      H >> lvl, W >> lvl, device=device)
             bufs.append(buf)
             skip_dst.append(K.channel_slice(buf, cu, cu + cs))
         return bufs, skip_dst
 
     @staticmethod
-    def _split_inv(c_main):
+    def _split_inv(c_main, c_out, h, w):
         """the up-sampled inverse-depth input of iconv3 / iconv2 / iconv1 as a rank-1 term beside the GEMM (kernels.ConvGnEluInvFn) instead of a
-        65th / 97th / 193rd channel of the concat buffer: when enabled and the other channels are a multiple of 32"""
-        return K._cfg["split_inv_channel"] and c_main % 32 == 0 and K.compute_dtype() in (torch.bfloat16, torch.float32)
+        65th / 97th / 193rd channel of the concat buffer: when enabled, the other channels are a multiple of 32, and ALL THREE rank-1 kernels take the
+        layer -- mte_rank1_conv_bwd_data / _bwd_weight cover 32, 64 or 128 output channels and even image sizes (round-4 advisor: the forward alone
+        accepts up to 256, so a wider decoder would have failed in its backward pass instead of taking the concat form)"""
+        return (K._cfg["split_inv_channel"] and c_main % 32 == 0 and c_out in (32, 64, 128) and h % 2 == 0 and w % 2 == 0
+                and K.compute_dtype() in (torch.bfloat16, torch.float32))
 
     def _iconv(self, layer, inv, buf, up, skip):
         """iconv(cat(unpack output, skip[, nearest_up2(inv)]))"""
-        if inv is not None and self._split_inv(up.shape[1] + skip.shape[1]) and (buf is None or buf.shape[1] == up.shape[1] + skip.shape[1]):
+        if (inv is not None and self._split_inv(up.shape[1] + skip.shape[1], layer.conv_base.out_channels, up.shape[2], up.shape[3])
+                and (buf is None or buf.shape[1] == up.shape[1] + skip.shape[1])):
             return layer(K.ConcatFn.apply(None, buf, up, skip), inv=inv)
         return layer(K.ConcatFn.apply(inv, buf, up, skip))
 

@@ -1,5 +1,8 @@
 """Summarise rocprofv3 FETCH_SIZE / WRITE_SIZE counter_collection.csv files per kernel family.
-usage: pmc_traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <steps in each run>"""
+usage: pmc_traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <steps in each run> [json-out [source tag]]
+With json-out: also writes the per-family figures bench.py quotes as `roofline.traffic` (profiles/pmc_traffic.json), stamped with the source tag and
+the launch counts of the passes -- bench.py reports the figure only while its own run counts the same launches per step (round-4 advisor: a stale
+numerator over a live denominator).  The conv family = igemm + patch + stem + generic / nine-tap weight gradients, as bench.py's timed set."""
 import csv
 import glob
 import sys
@@ -51,3 +54,17 @@ for k in sorted(set(Fk) | set(Wk), key=lambda k: -(2 * Fk[k][1] + Wk[k][1]))[:40
     r = 2.0 * Fk[k][1] * 1024 / steps / 1e6
     w = Wk[k][1] * 1024 / steps / 1e6
     print("%-62s %8.1f %10.1f %10.1f" % (k, max(Fk[k][0], Wk[k][0]) / steps, r, w))
+
+if len(sys.argv) > 4:
+    import json
+    conv = ("conv igemm (fwd+dgrad)", "conv wgrad generic", "conv patch fwd+dgrad", "conv patch wgrad", "conv stem fwd+wgrad")
+    mb = lambda fams: sum((2.0 * F[f][1] + W[f][1]) * 1024 / steps / 1e6 for f in fams)
+    out = {"mode": "train", "batch": 8, "height": 384, "width": 1280, "dtype": "bf16",
+           "source": sys.argv[5] if len(sys.argv) > 5 else "",
+           "conv_family_MB_per_step": round(mb(conv), 1),
+           "conv_family_kernel_launches_per_step": sum(max(F[f][0], W[f][0]) for f in conv) / steps,
+           "gn_family_MB_per_step": round(mb(("GroupNorm+ELU",)), 1),
+           "gn_family_kernel_launches_per_step": max(F["GroupNorm+ELU"][0], W["GroupNorm+ELU"][0]) / steps,
+           "all_kernels_MB_per_step": round(tot_r + tot_w, 1)}
+    with open(sys.argv[4], "w") as f:
+        json.dump(out, f, indent=1)
