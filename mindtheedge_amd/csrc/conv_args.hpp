@@ -20,8 +20,13 @@ struct ConvArgs {
     // neighbours; outputs are scattered to the same sites, nothing is written elsewhere.  Work scales with the active count: tiles past
     // *nrows return at once (the grid is sized for the dense capacity M, the count never visits the host).
     const int* rows; const int* nrows;
+    // K order of the 8-phase kernels (conv_igemm8.hip; every other tile form runs tap-major): 0 = filter tap outer, input channels inner (the order
+    // of the weight pack); 1 (round 5, Cin_p % 64 == 0) = 64-CHANNEL SLICE outer, taps inner -- the nine taps of a slice re-touch the lines the first
+    // tap brought into the XCD's L2 (a slice of the resident tiles' inputs fits it; a whole tap sweep over all channels does not: 9 x the input was
+    // fetched from the Infinity Cache).  A different summation order: results agree with the tap-major forms to fp32 rounding, not bit for bit.
+    int kslice;
 };
 
 // conv_igemm8.hip: the 8-phase 256-row tile kernels (bf16, buffer-descriptor LDS-DMA).  bn = 256 or 128 output columns per tile.
 // Returns MTE_ERR_UNSUPPORTED when the shape is outside what the kernel covers (the caller then takes the older tile forms).
-__attribute__((visibility("hidden"))) int igemm8_launch(ConvArgs a, int bn, int persistent, hipStream_t st);
+__attribute__((visibility("hidden"))) int igemm8_launch(ConvArgs a, int bn, hipStream_t st);

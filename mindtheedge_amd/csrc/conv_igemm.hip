@@ -669,7 +669,14 @@ launched:
 }
 
 int g_igemm_big_min_tiles = 224;
-int g_igemm8 = 19;                                   // development knob (mte_debug_set(23, v)): bit 0 = 8-phase 256 x 256 kernel, bit 1 = its 256 x 128 form, bit 2 every eligible launch, bit 3 force the tile-walking form, bit 4 never pick it by itself (round 4: on launches of more than one wave of tiles it measured 15-20 % SLOWER than one WG per tile -- profiles/r04_igemm8_ab_v1.txt)
+// Default 51 = 19 | 32: TAP-major.  The slice-major order of round 5 (ConvArgs.kslice) cuts the implicit GEMM's fetches beyond L2 (the nine tap sweeps
+// of a 64-channel slice re-use the lines of the first), but those fetches were Infinity-Cache hits, not HBM reads: same box, the training step takes
+// 24.80 ms with it and 24.77 ms without, and in isolation the kernels are 5 % SLOWER (a tap change, i.e. new lane offsets, every K-tile): 6.74 against
+// 6.43 ms over the step's launches (profiles/r05_igemm8_korder.txt).  It stays selectable: knob 23 without bit 5, or -DMTE_IGEMM8_DEFAULT=19.
+#ifndef MTE_IGEMM8_DEFAULT
+#define MTE_IGEMM8_DEFAULT 51
+#endif
+int g_igemm8 = MTE_IGEMM8_DEFAULT;                                   // development knob (mte_debug_set(23, v)): bit 0 = 8-phase 256 x 256 kernel, bit 1 = its 256 x 128 form, bit 2 every eligible launch, bit 5 (32) tap-major K order (the default; without it: slice-major where Cin_p % 64 == 0); bits 3 / 4 belonged to the tile-walking form, removed in round 5
 int g_igemm8_min_tiles = 200;                        // development knob (mte_debug_set(24, v))
 int g_igemm_pp = 1;                                  // development knob (mte_debug_set(21, v)): 0 = the 16-wave one-barrier loop on the 256 x 256 tile
 int g_igemm_big = 3;                                 // development knob (mte_debug_set(6, v)): 0 128x128 only, 1 + 256x128, 2 + 256x256, 3 + 192x96
@@ -719,10 +726,11 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
             if (bn) {
                 ConvArgs b = a;
                 b.splits = splits;
-                // several rounds of tiles: the tile-walking form keeps the stream of half-tiles running across tiles.  Off by default since round 4 (bit 4 of the knob):
-                // +1-2 % in the round-3 step A/B, but 15-20 % slower per launch in isolation on the 480- / 960-tile shapes; tests still force it (knob 15)
-                const int persistent = ((g_igemm8 >> 3) & 1) | (bn == 256 && splits == 1 && t256 > 256 && !(g_igemm8 & 16) ? 1 : 0);
-                const int rc = igemm8_launch(b, bn, persistent, st);
+                // round 5: 64-channel slices outer, taps inner where asked for and the channels allow it (ConvArgs.kslice; knob 23 bit 5 = tap-major, the order of
+                // every other tile form and the default -- see g_igemm8).  The tile-walking (persistent) form of round 4 is gone: it was 15-20 % slower per
+                // launch than one workgroup per tile and no launch used it.
+                b.kslice = (!(g_igemm8 & 32) && a.Cin_p % 64 == 0) ? 1 : 0;
+                const int rc = igemm8_launch(b, bn, st);
                 if (rc == MTE_OK) {
                     if (splits > 1) {
                         long g = (a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;

@@ -84,13 +84,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
     const int n0 = tile_n * BN;
 
     const int pad_h = a.KH >> 1, pad_w = a.KW >> 1;
+    const int taps = a.KH * a.KW;
     const int cpt = a.Cin_p >> 3;                                    // 16-byte chunks per tap (a multiple of 4)
-    const int ksteps_all = (a.KH * a.KW * cpt) >> 2;
-    const int per_split = (ksteps_all + a.splits - 1) / a.splits;
+    const int ksteps_all = (taps * cpt) >> 2;
+    const bool sm = a.kslice != 0;                                   // slice-major K order (ConvArgs.kslice; cpt % 8 == 0): K-tile T = (slice T / taps, tap T % taps)
+    // tap-major: the split's range in K-steps of 32 channels; slice-major: in K-tiles of 64 (the same variables, one unit up)
+    const int units_all = sm ? ksteps_all >> 1 : ksteps_all;
+    const int per_split = (units_all + a.splits - 1) / a.splits;
     const int s_begin = split * per_split;
-    const int s_end = min(ksteps_all, s_begin + per_split);
-    const int nkt = s_end > s_begin ? (s_end - s_begin + 1) >> 1 : 0;   // K-tiles of this split (the last may hold one K-step)
-    const long Kp = (long)a.KH * a.KW * a.Cin_p;
+    const int s_end = min(units_all, s_begin + per_split);
+    const int nkt = s_end > s_begin ? (sm ? s_end - s_begin : (s_end - s_begin + 1) >> 1) : 0;   // K-tiles of this split (tap-major: the last may hold one K-step)
+    const long Kp = (long)taps * a.Cin_p;
     const T* __restrict__ xp = (const T*)a.x;
     const T* __restrict__ wp = (const T*)a.w;
 
@@ -117,11 +121,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
         const int n = n0 + h * HN + brow;
         voffB[h] = n < a.N ? (unsigned)(((long)n * Kp + kc * 8) * 2) : OOB8;
     }
-    // tap state of the even / odd K-steps (K-half 0 / 1 of the K-tile the A stream is at); all scalars wave-uniform
+    // tap state of the even / odd K-steps (K-half 0 / 1 of the K-tile the A stream is at); all scalars wave-uniform.
+    //   tap-major  : the two K-halves are consecutive K-steps of the pack order and may sit in different taps (Cin_p % 64 == 32)
+    //   slice-major: both halves share the tap; the slice gives their chunk offsets; st_s[kh] = the half's K-step index IN THE PACK (weights), a_t the K-tile
     int st_s[2], st_ty[2], st_tx[2], st_cb[2];
+    bool st_live[2];
+    int a_t = s_begin, a_slice = 0;
     unsigned voffT[2][2];                                            // [K-half][pixel half]
     auto set_tap = [&](int kh) {
+#ifdef MTE_I8_TAP0      // private diagnostic build (tools/igemm8_locality.py): every tap reads the centre pixel -- what perfect L2 locality of the taps would be worth
+        const int dy = 0, dx = 0;
+#else
         const int dy = st_ty[kh] - pad_h, dx = st_tx[kh] - pad_w;
+#endif
         const int delta = (dy * a.W + dx) * (int)a.ldx * 2;         // byte shift of this tap (may be negative)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -130,22 +142,59 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
             voffT[kh][h] = ok ? voffA[h] + (unsigned)delta : OOB8;
         }
     };
+    auto sm_place = [&]() {                                          // slice-major: both halves from (a_slice, tap st_ty[0], st_tx[0])
+        const int tap = st_ty[0] * a.KW + st_tx[0];
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        st_s[kh] = s_begin + kh;
-        const int q0 = 4 * st_s[kh], tap0 = q0 / cpt;
-        st_cb[kh] = q0 - tap0 * cpt; st_ty[kh] = tap0 / a.KW; st_tx[kh] = tap0 - st_ty[kh] * a.KW;
-        set_tap(kh);
+        for (int kh = 0; kh < 2; ++kh) {
+            st_cb[kh] = a_slice * 8 + 4 * kh;
+            st_s[kh] = tap * (cpt >> 2) + a_slice * 2 + kh;
+            st_live[kh] = a_t < s_end;
+        }
+        st_ty[1] = st_ty[0]; st_tx[1] = st_tx[0];
+        set_tap(0);
+        voffT[1][0] = voffT[0][0]; voffT[1][1] = voffT[0][1];
+    };
+    if (sm) {
+        a_slice = s_begin / taps;
+        const int tap0 = s_begin - a_slice * taps;
+        st_ty[0] = tap0 / a.KW; st_tx[0] = tap0 - st_ty[0] * a.KW;
+        sm_place();
+    } else {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            st_s[kh] = s_begin + kh;
+            st_live[kh] = st_s[kh] < s_end;
+            const int q0 = 4 * st_s[kh], tap0 = q0 / cpt;
+            st_cb[kh] = q0 - tap0 * cpt; st_ty[kh] = tap0 / a.KW; st_tx[kh] = tap0 - st_ty[kh] * a.KW;
+            set_tap(kh);
+        }
     }
-    auto advance = [&]() {                                           // both K-halves to the next K-tile (8 chunks further)
+    auto advance = [&]() {                                           // the A stream to the next K-tile
+        if (sm) {                                                    // next tap of the slice; after the last one the next slice's first
+            ++a_t;
+            if (++st_tx[0] == a.KW) { st_tx[0] = 0; if (++st_ty[0] == a.KH) { st_ty[0] = 0; ++a_slice; } }
+            sm_place();
+            return;
+        }
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             st_s[kh] += 2; st_cb[kh] += 8;
+            st_live[kh] = st_s[kh] < s_end;
             if (st_cb[kh] >= cpt) {                                  // wave-uniform
                 do { st_cb[kh] -= cpt; if (++st_tx[kh] == a.KW) { st_tx[kh] = 0; ++st_ty[kh]; } } while (st_cb[kh] >= cpt);
                 set_tap(kh);
             }
         }
+    };
+    // the B (weight) stream: K-step index in the pack of K-half 0 of the K-tile it stands at (K-half 1 is the next one in both orders)
+    int b_t = s_begin, b_tap = 0, b_slice = 0, b_sp0 = s_begin;
+    if (sm) { b_slice = s_begin / taps; b_tap = s_begin - b_slice * taps; b_sp0 = b_tap * (cpt >> 2) + b_slice * 2; }
+    auto advanceB = [&]() {
+        if (sm) {
+            ++b_t;
+            if (++b_tap == taps) { b_tap = 0; ++b_slice; }
+            b_sp0 = b_tap * (cpt >> 2) + b_slice * 2;
+        } else { b_t += 2; b_sp0 += 2; }
     };
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -157,26 +206,26 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            const unsigned vo = st_s[kh] < s_end ? voffT[kh][h] : OOB8;
+            const unsigned vo = st_live[kh] ? voffT[kh][h] : OOB8;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + buf * BUF + (h * 2 + kh) * (HM * 64) + wv * 1024), 16, vo, st_cb[kh] * 16, 0, 0);
         }
 #endif
     };
-    // half-tile B_h of K-tile kt
-    auto stageB = [&](int h, int kt, int buf) {
+    // half-tile B_h of the K-tile the B stream stands at
+    auto stageB = [&](int h, int buf) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (BN == 256) {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
-                const int s = s_begin + 2 * kt + kh;
+                const bool live = sm ? b_t < s_end : b_t + kh < s_end;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + buf * BUF + A_BYTES + (h * 2 + kh) * (HN * 64) + wv * 1024), 16,
-                                                         s < s_end ? voffB[h] : OOB8, s * 64, 0, 0);
+                                                         live ? voffB[h] : OOB8, (b_sp0 + kh) * 64, 0, 0);
             }
         } else {
             const int kh = wv >> 2;
-            const int s = s_begin + 2 * kt + kh;
+            const bool live = sm ? b_t < s_end : b_t + kh < s_end;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + buf * BUF + A_BYTES + (h * 2 + kh) * (HN * 64) + (wv & 3) * 1024), 16,
-                                                     s < s_end ? voffB[h] : OOB8, s * 64, 0, 0);
+                                                     live ? voffB[h] : OOB8, (b_sp0 + kh) * 64, 0, 0);
         }
 #endif
     };
@@ -223,9 +272,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
 #define MTE8_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 
     // ---- prologue: stream elements 0..6 = B0 A0 B1 A1 of K-tile 0, B0 A0 B1 of K-tile 1
-    stageB(0, 0, 0); stageA(0, 0); stageB(1, 0, 0); stageA(1, 0);
-    advance();
-    stageB(0, 1, 1); stageA(0, 1); stageB(1, 1, 1);
+    stageB(0, 0); stageA(0, 0); stageB(1, 0); stageA(1, 0);
+    advance(); advanceB();
+    stageB(0, 1); stageA(0, 1); stageB(1, 1);
+    advanceB();
     MTE8_WAIT_VM(2 * IB + IA);                                       // K-tile 0 has landed
     MTE8_BARRIER();
     if (grp == 1) MTE8_BARRIER();                                    // group 1 runs one barrier behind from here on
@@ -259,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
         ST8(3)
         // ---- phase 2: quadrant (A0, B1); stage B0 of K-tile kt + 2, move the tap state there
         readB(1, fb1, pb);
-        stageB(0, kt + 2, buf);
+        stageB(0, buf);
         advance();
         ST8(4)
         MTE8_BARRIER();
@@ -283,7 +333,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
         MTE8_BARRIER();
         ST8(11)
         // ---- phase 4: quadrant (A1, B0); stage B1 of K-tile kt + 2; K-tile kt + 1 must have landed
-        stageB(1, kt + 2, buf);
+        stageB(1, buf);
+        advanceB();
         MTE8_WAIT_VM(2 * IB + IA);
         ST8(12)
         MTE8_BARRIER();
@@ -369,356 +420,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
 }
 
 
-// =====================================================================================================================================
-// PERSISTENT form: one workgroup per CU walks a list of work items (output tile x K split) and the half-tile stream simply runs on
-// across item boundaries -- the loader is 7 half-tiles ahead, so the first K-tiles of the next item are in flight (or landed) while the
-// last quadrants of the current one are computed: no ring fill per tile.  The epilogue leaves the ring alone: a lane holds 4 consecutive
-// channels of a pixel per block (swapped operands), v_permlane16_swap pairs the two column blocks of a quadrant so that every lane owns
-// 8 consecutive channels = one 16-byte store (64 contiguous bytes per pixel and instruction); the bias of the tile travels by LDS-DMA
-// into a 2 x BN-float corner of LDS at the item's first K-tile (older than the counted window of that K-tile's wait).
-// Items of a workgroup: ids are dealt to the 8 XCD labels (blockIdx & 7) in contiguous ranges (xcd_remap's ranges); the workgroups of a
-// label take that range's ids round-robin, so the tiles in flight on one XCD at a time are neighbours (shared A rows / weight panels).
-// =====================================================================================================================================
-template <int BN>
-__global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(ConvArgs a, int total_items) {
-    typedef bf16_t T;
-    constexpr int BM = 256, HM = 128, HN = BN / 2;
-    constexpr int WN = BN == 256 ? 4 : 2;
-    constexpr int QA = BN == 256 ? 4 : 2, QB = 2;
-    constexpr int IA = 2, IB = BN == 256 ? 2 : 1;
-    constexpr int A_BYTES = 4 * HM * 64, B_BYTES = 4 * HN * 64;
-    constexpr int BUF = A_BYTES + B_BYTES;
-    constexpr int BIAS_OFF = 2 * BUF;                                // [2][BN] floats behind the ring
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv / WN, wn = wv % WN;
-    const int grp = wv >> 2;
-    const int tiles_n = (a.N + BN - 1) / BN;
-    const int tiles_m = (int)((a.M + BM - 1) / BM);
-    const int ntiles = tiles_m * tiles_n;
-
-    // ---- this workgroup's items: ids first + j * stride, j < nitems
-    int first, stride, nitems;
-    {
-        const int xl = blockIdx.x & 7, li = blockIdx.x >> 3;
-        const int q = total_items >> 3, r = total_items & 7;
-        const int base = xl < r ? xl * (q + 1) : r * (q + 1) + (xl - r) * q;
-        const int cnt = q + (xl < r ? 1 : 0);
-        stride = ((int)gridDim.x - xl + 7) >> 3;
-        first = base + li;
-        nitems = li < cnt ? (cnt - li + stride - 1) / stride : 0;
-    }
-    if (nitems == 0) return;
-
-    const int pad_h = a.KH >> 1, pad_w = a.KW >> 1;
-    const int cpt = a.Cin_p >> 3;
-    const int ksteps_all = (a.KH * a.KW * cpt) >> 2;
-    const int per_split = (ksteps_all + a.splits - 1) / a.splits;
-    const long Kp = (long)a.KH * a.KW * a.Cin_p;
-    const T* __restrict__ xp = (const T*)a.x;
-    const T* __restrict__ wp = (const T*)a.w;
-    const bool has_bias = a.bias != nullptr && a.splits == 1;
-
-    // item j -> (split, first pixel, first column, K-step range)
-    auto decode = [&](int j, int& split, long& m0, int& n0, int& sb, int& se) {
-        const int id = first + j * stride;
-        split = id / ntiles;
-        const int t = id - split * ntiles;
-        const int tm = t / tiles_n;
-        n0 = (t - tm * tiles_n) * BN;
-        m0 = (long)tm * BM;
-        sb = split * per_split;
-        se = min(ksteps_all, sb + per_split);
-    };
-
-    const int lrow = wv * 16 + (lane >> 2);
-    const int kc = (lane & 3) ^ ((lane >> 3) & 3);
-    const int brow = BN == 256 ? lrow : (wv & 3) * 16 + (lane >> 2);
-
-    // ---- A stream: item, K-tile inside it, LDS buffer; per item the two pixel rows of this lane, per K-half the tap
-    int A_item = 0, A_kt = 0, A_nkt = 0, A_buf = 0, A_se = 0;
-    int a_oy[2], a_ox[2]; unsigned voffA[2]; bool a_ok[2];
-    int st_s[2], st_ty[2], st_tx[2], st_cb[2];
-    unsigned voffT[2][2];
-    auto set_tap = [&](int kh) {
-        const int dy = st_ty[kh] - pad_h, dx = st_tx[kh] - pad_w;
-        const int delta = (dy * a.W + dx) * (int)a.ldx * 2;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int iy = a_oy[h] + dy, ix = a_ox[h] + dx;
-            const bool ok = a_ok[h] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            voffT[kh][h] = ok ? voffA[h] + (unsigned)delta : OOB8;
-        }
-    };
-    auto loadA = [&](int j) {
-        if (j >= nitems) {                                           // past the last item: the stream goes on with zero fills
-            A_nkt = 0x40000000; A_se = 0;
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) { st_s[kh] = 0; st_cb[kh] = 0; voffT[kh][0] = voffT[kh][1] = OOB8; }
-            a_ok[0] = a_ok[1] = false;
-            return;
-        }
-        int split, n0, sb; long m0;
-        decode(j, split, m0, n0, sb, A_se);
-        A_nkt = (A_se - sb + 1) >> 1;
-        const unsigned hw = (unsigned)(a.H * a.W);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const long m = m0 + h * HM + lrow;
-            a_ok[h] = m < a.M;
-            const unsigned mm = a_ok[h] ? (unsigned)m : 0u;
-            const unsigned b = mm / hw, rem = mm - b * hw;
-            a_oy[h] = (int)(rem / (unsigned)a.W); a_ox[h] = (int)(rem - (unsigned)a_oy[h] * (unsigned)a.W);
-            voffA[h] = (unsigned)(((long)mm * a.ldx + kc * 8) * 2);
-        }
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            st_s[kh] = sb + kh;
-            const int q0 = 4 * st_s[kh], tap0 = q0 / cpt;
-            st_cb[kh] = q0 - tap0 * cpt; st_ty[kh] = tap0 / a.KW; st_tx[kh] = tap0 - st_ty[kh] * a.KW;
-            set_tap(kh);
-        }
-    };
-    auto advanceA = [&]() {
-        A_buf ^= 1;
-        if (++A_kt < A_nkt) {
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                st_s[kh] += 2; st_cb[kh] += 8;
-                if (st_cb[kh] >= cpt) {
-                    do { st_cb[kh] -= cpt; if (++st_tx[kh] == a.KW) { st_tx[kh] = 0; ++st_ty[kh]; } } while (st_cb[kh] >= cpt);
-                    set_tap(kh);
-                }
-            }
-        } else { A_kt = 0; loadA(++A_item); }
-    };
-    // ---- B stream
-    int B_item = 0, B_kt = 0, B_nkt = 0, B_buf = 0, B_s = 0, B_se = 0;
-    unsigned voffB[2];
-    auto loadB = [&](int j) {
-        if (j >= nitems) { B_nkt = 0x40000000; B_s = 0; B_se = 0; voffB[0] = voffB[1] = OOB8; return; }
-        int split, n0; long m0;
-        decode(j, split, m0, n0, B_s, B_se);
-        B_nkt = (B_se - B_s + 1) >> 1;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = n0 + h * HN + brow;
-            voffB[h] = n < a.N ? (unsigned)(((long)n * Kp + kc * 8) * 2) : OOB8;
-        }
-    };
-    auto advanceB = [&]() {
-        B_buf ^= 1; B_s += 2;
-        if (++B_kt == B_nkt) { B_kt = 0; loadB(++B_item); }
-    };
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, (int)(((a.M - 1) * a.ldx + a.Cin_p) * 2), 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, (int)((long)a.N * Kp * 2), 0x00020000);
-    const auto rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, has_bias ? a.N * 4 : 0, 0x00020000);
-#endif
-    auto stageA = [&](int h) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const unsigned vo = st_s[kh] < A_se ? voffT[kh][h] : OOB8;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + A_buf * BUF + (h * 2 + kh) * (HM * 64) + wv * 1024), 16, vo, st_cb[kh] * 16, 0, 0);
-        }
-#endif
-    };
-    auto stageB = [&](int h) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (BN == 256) {
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                const int s = B_s + kh;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + B_buf * BUF + A_BYTES + (h * 2 + kh) * (HN * 64) + wv * 1024), 16,
-                                                         s < B_se ? voffB[h] : OOB8, s * 64, 0, 0);
-            }
-        } else {
-            const int kh = wv >> 2;
-            const int s = B_s + kh;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + B_buf * BUF + A_BYTES + (h * 2 + kh) * (HN * 64) + (wv & 3) * 1024), 16,
-                                                     s < B_se ? voffB[h] : OOB8, s * 64, 0, 0);
-        }
-#endif
-    };
-    // bias of item j's column tile: BN floats = BN / 4 chunks, BN / 32 lanes of every wave bring one each
-    auto bias_dma = [&](int j, int n0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (has_bias && lane < BN / 32)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (lptr_t)(smem + BIAS_OFF + (j & 1) * (BN * 4) + wv * (BN / 2)), 16,
-                                                     (unsigned)((n0 + (wv * (BN / 32) + lane) * 4) * 4), 0, 0, 0);
-#endif
-    };
-
-    const int r16 = lane & 15, q16 = lane >> 4;
-    const int swz = (q16 ^ ((r16 >> 1) & 3)) << 4;
-    const int offA = (wm * QA * 16 + r16) * 64 + swz;
-    const int offB = A_BYTES + (wn * QB * 16 + r16) * 64 + swz;
-    u32x4_t fa[QA][2], fb0[QB][2], fb1[QB][2];
-    f32x4_t acc[2][QA][2][QB];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < QA; ++i)
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) acc[h][i][g][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
-    auto readA = [&](int h, const char* pb) {
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int i = 0; i < QA; ++i) fa[i][kh] = *(const u32x4_t*)(pb + offA + (h * 2 + kh) * (HM * 64) + i * 1024);
-    };
-    auto readB = [&](int g, u32x4_t (&fb)[QB][2], const char* pb) {
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int j = 0; j < QB; ++j) fb[j][kh] = *(const u32x4_t*)(pb + offB + (g * 2 + kh) * (HN * 64) + j * 1024);
-    };
-    auto quadrant = [&](int h, int g, const u32x4_t (&fb)[QB][2]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int i = 0; i < QA; ++i)
-#pragma unroll
-                for (int j = 0; j < QB; ++j) acc[h][i][g][j] = mma16(fb[j][kh], fa[i][kh], acc[h][i][g][j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // ---- the item being computed
-    int C_item = 0, C_kt = 0, C_nkt, C_buf = 0, C_split, C_n0; long C_m0;
-    {
-        int sb, se;
-        decode(0, C_split, C_m0, C_n0, sb, se);
-        C_nkt = (se - sb + 1) >> 1;
-    }
-    auto epilogue = [&]() {
-        if (a.splits > 1) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < QA; ++i) {
-                    const long m = C_m0 + h * HM + (wm * QA + i) * 16 + r16;
-#pragma unroll
-                    for (int g = 0; g < 2; ++g)
-#pragma unroll
-                        for (int j = 0; j < QB; ++j) {
-                            const int n = C_n0 + g * HN + (wn * QB + j) * 16 + 4 * q16;
-                            if (m < a.M && n < a.N) *(f32x4_t*)(a.ws + ((long)C_split * a.M + m) * a.N + n) = acc[h][i][g][j];
-                        }
-                }
-            return;
-        }
-        const char* pbias = smem + BIAS_OFF + (C_item & 1) * (BN * 4);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x4_t bv[QB];
-#pragma unroll
-            for (int j = 0; j < QB; ++j) {
-                bv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (has_bias) bv[j] = *(const f32x4_t*)(pbias + (g * HN + (wn * QB + j) * 16 + 4 * q16) * 4);
-            }
-            // after the swaps lane (r16, q16) owns channels 8 * (q16 >> 1) .. + 7 of column block (q16 & 1)
-            const int col = g * HN + (wn * QB + (q16 & 1)) * 16 + 8 * (q16 >> 1);
-            const bool col_ok = C_n0 + col < a.N;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < QA; ++i) {
-                    const f32x4_t v0 = acc[h][i][g][0] + bv[0], v1 = acc[h][i][g][1] + bv[1];
-                    const auto lo = __builtin_amdgcn_permlane16_swap(pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1]), false, false);
-                    const auto hi = __builtin_amdgcn_permlane16_swap(pack2bf(v0[2], v0[3]), pack2bf(v1[2], v1[3]), false, false);
-                    u32x4_t c = {lo[0], hi[0], lo[1], hi[1]};
-                    const long m = C_m0 + h * HM + (wm * QA + i) * 16 + r16;
-                    if (m < a.M && col_ok) {
-                        T* dst = (T*)a.y + m * a.ldy + C_n0 + col;
-                        if (a.accum) {
-                            float vn[8], vo[8];
-                            unpack16<T>(c, vn);
-                            unpack16<T>(*(const u32x4_t*)dst, vo);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) vn[k] += vo[k];
-                            c = pack16<T>(vn);
-                        }
-                        *(u32x4_t*)dst = c;
-                    }
-                }
-        }
-    };
-
-    // ---- prologue
-    loadA(0); loadB(0);
-    bias_dma(0, C_n0);
-    stageB(0); stageA(0); stageB(1); stageA(1);
-    advanceA(); advanceB();
-    stageB(0); stageA(0); stageB(1);
-    advanceB();
-    MTE8_WAIT_VM(2 * IB + IA);
-    MTE8_BARRIER();
-    if (grp == 1) MTE8_BARRIER();
-    while (true) {
-        const char* pb = smem + C_buf * BUF;
-        // ---- phase 1: quadrant (A0, B0); A1 of the next K-tile
-        readB(0, fb0, pb);
-        __builtin_amdgcn_sched_barrier(0);
-        readA(0, pb);
-        stageA(1);
-        MTE8_WAIT_LGKM(QA * 2);
-        MTE8_BARRIER();
-        MTE8_WAIT_LGKM(0);
-        __builtin_amdgcn_sched_barrier(0);
-        quadrant(0, 0, fb0);
-        MTE8_BARRIER();
-        // ---- phase 2: quadrant (A0, B1); B0 two K-tiles ahead; the A stream moves on
-        readB(1, fb1, pb);
-        stageB(0);
-        advanceA();
-        MTE8_BARRIER();
-        MTE8_WAIT_LGKM(0);
-        __builtin_amdgcn_sched_barrier(0);
-        quadrant(0, 1, fb1);
-        MTE8_BARRIER();
-        // ---- phase 3: quadrant (A1, B1); A0 two K-tiles ahead
-        readA(1, pb);
-        stageA(0);
-        MTE8_BARRIER();
-        MTE8_WAIT_LGKM(0);
-        __builtin_amdgcn_sched_barrier(0);
-        quadrant(1, 1, fb1);
-        MTE8_BARRIER();
-        // ---- phase 4: quadrant (A1, B0); B1 two K-tiles ahead; the next K-tile must have landed; the B stream moves on
-        stageB(1);
-        MTE8_WAIT_VM(2 * IB + IA);
-        advanceB();
-        MTE8_BARRIER();
-        quadrant(1, 0, fb0);
-        MTE8_BARRIER();
-        C_buf ^= 1;
-        if (++C_kt == C_nkt) {
-            __builtin_amdgcn_sched_barrier(0);
-            epilogue();
-            if (++C_item == nitems) break;
-            zero_acc();
-            int sb, se;
-            decode(C_item, C_split, C_m0, C_n0, sb, se);
-            C_nkt = (se - sb + 1) >> 1;
-            C_kt = 0;
-            bias_dma(C_item, C_n0);                                  // (before this K-tile's stages: older than the counted window)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (grp == 0) MTE8_BARRIER();
-    MTE8_WAIT_VM(0);
-}
-
 template <int BN> int launch8(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * (4 * 128 * 64 + 4 * (BN / 2) * 64);
     static bool attr = false;
@@ -731,37 +432,14 @@ template <int BN> int launch8(const ConvArgs& a, hipStream_t st) {
     return MTE_OK;
 }
 
-int g_cus = 0;
-template <int BN> int launch8p(const ConvArgs& a, hipStream_t st) {
-    constexpr int LDS = 2 * (4 * 128 * 64 + 4 * (BN / 2) * 64) + 2 * BN * 4;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_igemm8p_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return MTE_ERR_LAUNCH;
-        attr = true;
-    }
-    if (!g_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return MTE_ERR_LAUNCH;
-        g_cus = n;
-    }
-    const long total = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN) * a.splits;
-    if (total > 0x7fffffffL) return MTE_ERR_UNSUPPORTED;
-    // one workgroup per CU (128 KB of LDS); an equal number of items per workgroup where the count allows it
-    const long rounds = (total + g_cus - 1) / g_cus;
-    long grid = (total + rounds - 1) / rounds;
-    if (grid > g_cus) grid = g_cus;
-    hipLaunchKernelGGL(conv_igemm8p_kernel<BN>, dim3((unsigned)grid), dim3(512), LDS, st, a, (int)total);
-    return MTE_OK;
-}
-
 }  // namespace
 
-// a.splits is final (1, or the number of fp32 slabs the caller's finish kernel adds; no split may be empty); the caller checks the launch.
-// persistent: the tile-walking form (one workgroup per CU, direct-store epilogue).
-int igemm8_launch(ConvArgs a, int bn, int persistent, hipStream_t st) {
+// a.splits is final (1, or the number of fp32 slabs the caller's finish kernel adds); a.kslice selects the K order (ConvArgs); the caller checks the launch.
+int igemm8_launch(ConvArgs a, int bn, hipStream_t st) {
     if (a.out_f32 || a.rows || a.Cin_p % 32 != 0 || a.N % 8 != 0 || (a.splits > 1 && (!a.ws || a.N % 4 != 0))) return MTE_ERR_UNSUPPORTED;
+    if (a.kslice && a.Cin_p % 64 != 0) return MTE_ERR_ARG;
     if (((a.M - 1) * a.ldx + a.Cin_p) * 2 >= 0x7ff00000L || (long)a.N * a.KH * a.KW * a.Cin_p * 2 >= 0x7ff00000L || a.M >= 0x7fffff00L) return MTE_ERR_UNSUPPORTED;
-    if (bn == 256) return persistent ? launch8p<256>(a, st) : launch8<256>(a, st);
-    if (bn == 128) return persistent ? launch8p<128>(a, st) : launch8<128>(a, st);
+    if (bn == 256) return launch8<256>(a, st);
+    if (bn == 128) return launch8<128>(a, st);
     return MTE_ERR_UNSUPPORTED;
 }

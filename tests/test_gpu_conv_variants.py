@@ -129,7 +129,7 @@ def test_igemm_256x128_tiles_match_128x128_tiles(shape, devlib):
             return y.float().cpu(), None if dx is None else dx.float().cpu()
         finally:
             K._splitk_workspace = orig
-            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
+            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 51)
             K.lib.mte_debug_set(7, 224)
 
     K.use_patch_kernels(False)
@@ -176,7 +176,7 @@ def test_igemm_pingpong_loop_matches_one_barrier_loop(shape, devlib):
     finally:
         K._splitk_workspace = orig
         K.use_patch_kernels(True)
-        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
+        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 51)
         K.lib.mte_debug_set(7, 224)
         K.lib.mte_debug_set(21, 1)
 
@@ -203,7 +203,7 @@ def test_big_tile_split_k_matches_small_tiles(shape, devlib):
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
         assert float(outs[0].abs().mean()) > 0.1                 # (not trivially zero)
     finally:
-        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
+        K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 51)
         K.use_patch_kernels(True)
 
 
@@ -231,7 +231,7 @@ def test_igemm_192x96_tiles_match_128x128_tiles(shape, devlib):
             return y.float().cpu(), acc.float().cpu()
         finally:
             K._splitk_workspace = orig
-            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 19)
+            K.lib.mte_debug_set(6, 3); K.lib.mte_debug_set(23, 51)
             K.lib.mte_debug_set(7, 224)
 
     K.use_patch_kernels(False)
@@ -251,19 +251,22 @@ IGEMM8_SHAPES = [  # cin, cout, k, B, H, W, channels per input pixel (None = cin
 ]
 
 
-@pytest.mark.parametrize("persistent", [False, True])
+@pytest.mark.parametrize("order", ["tap-major", "slice-major"])
 @pytest.mark.parametrize("shape", IGEMM8_SHAPES)
-def test_eight_phase_igemm_equals_the_128x128_tile_bit_for_bit(devlib, shape, persistent):
-    """round 4 (csrc/conv_igemm8.hip): the 8-phase kernels -- 256 x 256 and 256 x 128 tiles, one tile per workgroup and the tile-walking
-    form -- accumulate the same K-steps in the same order as every other tile form, so forced onto small and awkward shapes (development
-    knob 23 = 7 / 15, 24 = 1) they must reproduce the 4-wave 128 x 128 kernel BIT FOR BIT, repeatedly (a stale LDS slot or a fragment read
-    that overtakes its DMA shows on some repetitions only), with and without accumulation into the output and through a channel-slice
-    output; the split-K form (different grouping of the fp32 sums) to one bf16 rounding."""
+def test_eight_phase_igemm_against_the_128x128_tile(devlib, shape, order):
+    """round 4 (csrc/conv_igemm8.hip): the 8-phase kernels -- 256 x 256 and 256 x 128 tiles -- forced onto small and awkward shapes (development knob
+    23 = 7, 24 = 1), repeatedly (a stale LDS slot or a fragment read that overtakes its DMA shows on some repetitions only), with and without
+    accumulation into the output and through a channel-slice output.
+      tap-major (knob bit 5: the K order of every other tile form): the same K-steps in the same order -> the 4-wave 128 x 128 kernel BIT FOR BIT;
+      slice-major (round 5, the product's order where Cin_p % 64 == 0: 64-channel slice outer, taps inner): bit-identical from run to run, and to the
+      128 x 128 kernel within one bf16 rounding of the output (another order of the same fp32 sum); shapes whose channels do not allow it run tap-major.
+    Split-K (another grouping of the fp32 sums): bitwise against itself, one bf16 rounding against the unsplit result."""
     from mindtheedge_amd import kernels as K
     cin, cout, k, B, H, W, ldx = shape
     K.set_compute_dtype("bf16")
     K.use_patch_kernels(False)
     saved = K._splitk_workspace
+    exact = order == "tap-major" or K.round8(cin) % 64 != 0
     try:
         g = torch.Generator().manual_seed(3 + cin + cout)
         w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
@@ -283,21 +286,31 @@ def test_eight_phase_igemm_equals_the_128x128_tile_bit_for_bit(devlib, shape, pe
             torch.cuda.synchronize()
             return out
 
-        v8 = 15 if persistent else 7
+        def one_rounding(a_, ref_, old=None):
+            # |d| <= one bf16 ulp of the result; with accumulation (old = the values added onto) the convolution is rounded BEFORE the sum, so an ulp
+            # of the convolution's own size (ref - old) can come on top -- far larger than the result's where the two nearly cancel
+            d = (a_.float() - ref_.float()).abs()
+            size = ref_.float().abs() if old is None else ref_.float().abs() + (ref_.float() - old.float()).abs()
+            return float((d - size * 2.0 ** -7).max()) <= 1e-3
+
+        v8 = 7 | (32 if order == "tap-major" else 0)                     # (23 = 0 below: the older tile forms; the test restores the product's 51)
         for accumulate in (False, True):
             ref = run(0, False, accumulate)
+            first = run(v8, False, accumulate)
             for rep in range(3):
-                assert torch.equal(run(v8, False, accumulate), ref), (shape, accumulate, rep)
-            assert torch.equal(ref[:, cout:], y0[:, cout:])                     # nothing written past the slice
-        # split-K: the new kernel against itself (bitwise) and against the unsplit result (one bf16 rounding)
+                assert torch.equal(run(v8, False, accumulate), first), (shape, accumulate, rep)
+            if exact:
+                assert torch.equal(first, ref), (shape, accumulate)
+            else:
+                # (accumulate: conv + bias is rounded to bf16, then the sum with the old value is -- two roundings that can each fall the other way)
+                assert one_rounding(first[:, :cout], ref[:, :cout], y0[:, :cout] if accumulate else None), (shape, accumulate)
+            assert torch.equal(first[:, cout:], y0[:, cout:])                   # nothing written past the slice
         first = run(v8, True, False)
         assert torch.equal(run(v8, True, False), first)
-        ref = run(0, False, False)
-        d = (first.float() - ref.float()).abs()
-        assert float((d - ref.float().abs() * 2.0 ** -7).max()) <= 1e-3
+        assert one_rounding(first, run(0, False, False))
     finally:
         K._splitk_workspace = saved
-        devlib.mte_debug_set(23, 19); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
+        devlib.mte_debug_set(23, 51); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
         K.use_patch_kernels(True)
 
 

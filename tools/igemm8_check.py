@@ -61,8 +61,15 @@ def check():
                 return out
 
             for split in (False, True):
-              for v8, name in ((7, "tile per workgroup"), (15, "persistent")):
+              for v8, name in ((39, "tap-major"), (7, "slice-major")):
                 ref = run(0, split)
+                if v8 == 7 and not split:                        # (round 5) another order of the fp32 sum: one bf16 rounding from the 128 x 128 tile, bitwise from run to run
+                    first = run(v8, False)
+                    d = (first.float() - ref.float()).abs()
+                    if int((d > ref.float().abs() * 2.0 ** -6 + 1e-3).sum()):
+                        print("   slice-major result off by more than one bf16 ulp, max |d| %.3e" % float(d.max()))
+                        bad += 1
+                    ref = first
                 if split:                                        # different split counts: equal up to the last bf16 rounding; the new kernel must repeat itself
                     first = run(v8, True)
                     d = (first.float() - ref.float()).abs()
@@ -82,7 +89,7 @@ def check():
                             print("   first mismatch rep %d: %d elements differ, max |d| %.3e (ref max %.3e)" % (r, int((d > 0).sum()), float(d.max()), float(ref.float().abs().max())))
                 bad += miss
                 print("%5d -> %-4d k%d B%d %3dx%-4d ldx %-4s acc %d split %d %-18s: %d / %d repetitions differ" % (cin, cout, k, B, H, W, ldx, accumulate, split, name, miss, reps))
-    S(23, 19); S(24, 200); S(6, 3)
+    S(23, 51); S(24, 200); S(6, 3)
     print("MISMATCHES:", bad)
     return bad
 
@@ -97,13 +104,13 @@ def bench():
               (128, 256, 3, 48, 160, 2), (256, 512, 3, 24, 80, 2), (512, 512, 3, 12, 40, 2), (128, 128, 1, 96, 320, 2), (256, 256, 1, 48, 160, 4),
               (512, 512, 1, 24, 80, 4),
               (192, 128, 3, 96, 320, 1), (128, 192, 3, 96, 320, 1)]       # iconv3 after the rank-1 split of its inverse-depth channel (forward, data gradient)
-    tot = {0: 0.0, 3: 0.0, 7: 0.0, 15: 0.0}
+    tot = {0: 0.0, 3: 0.0, 7: 0.0, 35: 0.0}
     for cin, cout, k, H, W, cnt in shapes:
         x, wf, b, _ = make(cin, cout, k, B, H, W)
         fl = 2.0 * B * H * W * cin * cout * k * k
-        t = {0: [], 3: [], 7: [], 15: []}
+        t = {0: [], 3: [], 7: [], 35: []}
         for rnd in range(5):
-            for v8 in (0, 3, 7, 15):
+            for v8 in (0, 3, 7, 35):
                 S(23, v8)
                 for _ in range(2):
                     K.conv_forward(x, wf, b, cout, k, k)
@@ -117,11 +124,11 @@ def bench():
         m = {v: sorted(t[v])[len(t[v]) // 2] for v in t}
         for v in m:
             tot[v] += m[v] * cnt
-        print("%5d -> %-4d k%d @%3dx%-4d x%-2d  old %7.1f us %6.0f TF   dispatch rule %7.1f us %6.0f TF %+5.1f %%   8-phase everywhere %7.1f us %6.0f TF %+5.1f %%   persistent %7.1f us %6.0f TF %+5.1f %%" % (
+        print("%5d -> %-4d k%d @%3dx%-4d x%-2d  old %7.1f us %6.0f TF   dispatch rule %7.1f us %6.0f TF %+5.1f %%   8-phase everywhere %7.1f us %6.0f TF %+5.1f %%   rule, tap-major %7.1f us %6.0f TF %+5.1f %%" % (
             cin, cout, k, H, W, cnt, m[0] * 1e3, fl / m[0] / 1e9, m[3] * 1e3, fl / m[3] / 1e9, (m[0] / m[3] - 1) * 100, m[7] * 1e3, fl / m[7] / 1e9, (m[0] / m[7] - 1) * 100,
-            m[15] * 1e3, fl / m[15] / 1e9, (m[0] / m[15] - 1) * 100))
-    print("weighted sum per step: old %.3f ms, dispatch rule %.3f ms, 8-phase everywhere %.3f ms, persistent everywhere %.3f ms" % (tot[0], tot[3], tot[7], tot[15]))
-    S(23, 19)
+            m[35] * 1e3, fl / m[35] / 1e9, (m[0] / m[35] - 1) * 100))
+    print("weighted sum per step: old %.3f ms, dispatch rule (slice-major) %.3f ms, 8-phase everywhere %.3f ms, dispatch rule tap-major %.3f ms" % (tot[0], tot[3], tot[7], tot[35]))
+    S(23, 51)
 
 
 rc = 0
