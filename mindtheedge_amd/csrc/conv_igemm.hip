@@ -1235,7 +1235,10 @@ __global__ __launch_bounds__(WNO * WC * 64) void conv_wgrad_dma_kernel(WgradArgs
 
 int g_wgrad_dma = 1;                                 // development knob (mte_debug_set(4, v))
 
-int g_wgrad_wgs = 512;                               // development knob (mte_debug_set(9, v)): workgroups aimed for (pixel splits)
+#ifndef MTE_WGRAD_WGS
+#define MTE_WGRAD_WGS 512
+#endif
+int g_wgrad_wgs = MTE_WGRAD_WGS;                     // development knob (mte_debug_set(9, v)): workgroups aimed for (pixel splits)
 int g_wgrad_big = 1;                                 // development knob (mte_debug_set(8, v)): 256 x 256 / 256 x 128 / 128 x 256 tiles
                                                      // (4x fewer re-reads of dy / x; pays once the pixel splits are few: g_wgrad_wgs)
 
@@ -1599,9 +1602,10 @@ extern "C" int mtei_set_pack3d_lds(int value);
 extern "C" int mtei_set_gn(int which, int value);
 extern "C" int mtei_set_patch_tall(int v);
 extern "C" int mtei_set_head_mfma(int v);
-extern int g_wgrad9;
+extern int g_wgrad9, g_wgrad9_wgs;
 int mte_debug_set(int key, int value) {
     if (key == 26) { g_wgrad9 = value; return MTE_OK; }
+    if (key == 27) { g_wgrad9_wgs = value; return MTE_OK; }
     if (key == 30) return mtei_set_head_mfma(value);
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }
     if (key == 1) return mtei_set_pack3d_lds(value);

@@ -790,7 +790,16 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
     }
 }
 
-int g_patch_wgrad_wgs = 512;                         // development knob (mte_debug_set(12, v))
+// Workgroup groups of the weight-gradient launches (round 5, same-box step times with the two-stream schedule, profiles/r05_side_queue_width.txt):
+// 512 -> 256 groups: 23.25 -> 23.16 ms per step (192: the same, 128: 23.60); the wide (65..128-output) variant 256 -> 128: a further -0.08 ms.  Fewer,
+// longer workgroups leave CUs to the data-gradient chain and halve the slabs the unpack pass adds up.
+#ifndef MTE_PATCH_WGRAD_WGS
+#define MTE_PATCH_WGRAD_WGS 256
+#endif
+#ifndef MTE_PATCH_WGRAD_WIDE_WGS
+#define MTE_PATCH_WGRAD_WIDE_WGS 128
+#endif
+int g_patch_wgrad_wgs = MTE_PATCH_WGRAD_WGS;         // development knob (mte_debug_set(12, v))
 int g_patch_tall = 1;                                // development knob (mte_debug_set(11, v))
 
 #ifdef MTE_PATCH_FWD1
@@ -845,7 +854,7 @@ template <int K, int NT, int SL, int NW = 4, int NH = 1, int THW = 8> int launch
     const int nslices = (a.Cin_p + 32 * SL - 1) / (32 * SL);
     const long ntiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
     // ~2 workgroups per CU in total; the 147 KB wide variant (NH = 2) holds one per CU: one round of workgroups, half the slabs to add up
-    long groups = ((NH == 2 ? 256 : g_patch_wgrad_wgs) + nslices - 1) / nslices;
+    long groups = ((NH == 2 ? MTE_PATCH_WGRAD_WIDE_WGS : g_patch_wgrad_wgs) + nslices - 1) / nslices;
     if (groups > ntiles) groups = ntiles;
     if (groups > parts_cap) groups = parts_cap < 1 ? 1 : parts_cap;   // one slab per workgroup group, always (round 4: no fp32-atomic combine on this launch path)
     a.groups = (int)groups;

@@ -13,6 +13,10 @@
 // weights + 4 biases are wave-uniform scalar loads.  These kernels move 2..10 bytes per 27 FMAs: they sit
 // between the HBM and the fp32-VALU roofs, not on MFMA (N = 4 features cannot fill a matrix tile).
 #include "common.hpp"
+#ifndef MTE_P3W_WGS
+#define MTE_P3W_WGS 768      // workgroups of the conv3d weight-gradient launches (side queue)
+#endif
+
 
 namespace {
 
@@ -1748,7 +1752,7 @@ int mte_pack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo, f
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
         P3LArgs l = p3l_args(B, H, W, C); l.x = (const bf16_t*)x; l.ldx = ldx; l.o = (const bf16_t*)dout; l.ldo = ldo; l.dwb = dwb;
         { const int dpairs = 4 * C / 16; l.dshift = (dpairs & (dpairs - 1)) == 0 ? __builtin_ctz(dpairs) : -1; l.tshift = __builtin_ctz(l.TW); }
-        if (g_p3_mfma) return launch_p3l(conv3d_bwd_weight_mfma_kernel<false>, l, l.ntiles < 768 ? l.ntiles : 768, stream, p3_lds_bytes(C) + 16, g_p3_mfma_threads);
+        if (g_p3_mfma) return launch_p3l(conv3d_bwd_weight_mfma_kernel<false>, l, l.ntiles < MTE_P3W_WGS ? l.ntiles : MTE_P3W_WGS, stream, p3_lds_bytes(C) + 16, g_p3_mfma_threads);
         return launch_p3l(pack3d_bwd_weight_lds_kernel, l, l.ntiles < 512 ? l.ntiles : 512, stream);
     }
     if (C <= 256) a.total *= 2;
@@ -1853,7 +1857,7 @@ int mte_unpack3d_bwd_weight(const void* x, long ldx, const void* dout, long ldo,
         const size_t lds = (size_t)(l.TH + 2) * (l.TW + 2) * LDP(C) * 2;
         const int cap = g_p3_small_tiles ? 1024 : 512;
         { const int dpairs = C / 16; l.dshift = (dpairs & (dpairs - 1)) == 0 ? __builtin_ctz(dpairs) : -1; l.tshift = __builtin_ctz(l.TW); }
-        if (g_p3_mfma) return launch_p3l(conv3d_bwd_weight_mfma_kernel<true>, l, l.ntiles < 768 ? l.ntiles : 768, stream, lds + 16, g_p3_mfma_threads);
+        if (g_p3_mfma) return launch_p3l(conv3d_bwd_weight_mfma_kernel<true>, l, l.ntiles < MTE_P3W_WGS ? l.ntiles : MTE_P3W_WGS, stream, lds + 16, g_p3_mfma_threads);
         return launch_p3l(unpack3d_bwd_weight_lds_kernel, l, l.ntiles < cap ? l.ntiles : cap, stream, lds);
     }
     a.total = (long)B * H * W * (C / 8);
