@@ -61,6 +61,10 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
  * the other workgroups' records.  Off, the protocol is the one MI355X_MICROARCH.md's visibility table lists as measured-valid: records by
  * returning atomic exchanges (performed at the memory side), a drained wait, a relaxed agent-scope ticket, agent-scope atomic loads. */
 #define MTE_OPT_HANDOFF_FENCES 2
+/* MTE_OPT_WGRAD_SHARES_CHIP (3), round 5: 1 = the caller queues the weight-gradient launches (mte_conv2d_wgrad, mte_conv2d_patch_wgrad) on a stream of their own
+ * beside the data-gradient chain; those kernels then aim for half a chip of workgroups, which is faster for the STEP (same box 23.59 -> 23.1 ms) although each launch
+ * is slower on its own.  0 (default): one workgroup (group) per CU, the right geometry when nothing runs beside them. */
+#define MTE_OPT_WGRAD_SHARES_CHIP 3
 int mte_set_option(int option, int value);
 /* Device error word, round 5.  Kernels whose workgroups wait for each other inside a launch (the GroupNorm cluster kernels) bound that wait;
  * a wait that gives up sets a flag in one word of pinned host memory instead of going on silently with incomplete statistics.

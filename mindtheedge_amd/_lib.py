@@ -86,9 +86,11 @@ class _Lib:
         self._dll, self._path, self._dev = None, path, bool(dev)
         self._protos = parse_header(dev=self._dev)
 
-    def set_option(self, option, value):
+    def set_option(self, option, value, lazy=False):
+        """lazy: only remember the option when the library is not in the process yet (applied by load())"""
         self._options[int(option)] = int(value)
-        self.mte_set_option(int(option), int(value))
+        if not lazy or self._dll is not None:
+            self.mte_set_option(int(option), int(value))
 
     def __getattr__(self, name):
         if name.startswith("mte_"):

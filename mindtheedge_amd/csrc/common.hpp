@@ -116,6 +116,10 @@ __device__ __forceinline__ void mte_report_device_error(unsigned* err, unsigned 
 // are returning atomic exchanges / agent-scope atomic loads (performed at the memory side, never served from a CU's L1), which is the form
 // MI355X_MICROARCH.md's visibility table lists as measured-valid; the fences make the protocol independent of that table.  Defined in norm_act.hip.
 extern int g_mte_handoff_fences;
+// mte_set_option(MTE_OPT_WGRAD_SHARES_CHIP, v): 1 = the caller queues the weight-gradient launches on a stream of their own beside the data-gradient chain (the
+// host side of this repository does): the MFMA weight-gradient kernels then aim for HALF a chip of workgroups (profiles/r05_side_queue_width.txt: same-box step
+// 23.59 -> 23.1 ms); 0 (default) = nothing runs beside them: one workgroup (group) per CU.  Defined in norm_act.hip.
+extern int g_mte_wgrad_shared;
 
 // GroupNorm statistics buffer of a batch of B samples, in doubles (mte_gn_stats_elems(B)):
 //   [0, 32 B)                       final (sum, sum of squares) per (sample, group): what every consumer reads

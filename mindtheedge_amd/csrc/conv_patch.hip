@@ -790,7 +790,8 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
     }
 }
 
-// Workgroup groups of the weight-gradient launches (round 5, same-box step times with the two-stream schedule, profiles/r05_side_queue_width.txt):
+// Workgroup groups of the weight-gradient launches WHEN THEY SHARE THE CHIP with the data-gradient chain (MTE_OPT_WGRAD_SHARES_CHIP; round 5, same-box
+// step times with the two-stream schedule, profiles/r05_side_queue_width.txt):
 // 512 -> 256 groups: 23.25 -> 23.16 ms per step (192: the same, 128: 23.60); the wide (65..128-output) variant 256 -> 128: a further -0.08 ms.  Fewer,
 // longer workgroups leave CUs to the data-gradient chain and halve the slabs the unpack pass adds up.
 #ifndef MTE_PATCH_WGRAD_WGS
@@ -854,7 +855,9 @@ template <int K, int NT, int SL, int NW = 4, int NH = 1, int THW = 8> int launch
     const int nslices = (a.Cin_p + 32 * SL - 1) / (32 * SL);
     const long ntiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
     // ~2 workgroups per CU in total; the 147 KB wide variant (NH = 2) holds one per CU: one round of workgroups, half the slabs to add up
-    long groups = ((NH == 2 ? MTE_PATCH_WGRAD_WIDE_WGS : g_patch_wgrad_wgs) + nslices - 1) / nslices;
+    // (alone on the chip -- MTE_OPT_WGRAD_SHARES_CHIP off -- twice the groups: the round-4 geometry)
+    const int want = (NH == 2 ? MTE_PATCH_WGRAD_WIDE_WGS : g_patch_wgrad_wgs) * (g_mte_wgrad_shared ? 1 : 2);
+    long groups = (want + nslices - 1) / nslices;
     if (groups > ntiles) groups = ntiles;
     if (groups > parts_cap) groups = parts_cap < 1 ? 1 : parts_cap;   // one slab per workgroup group, always (round 4: no fp32-atomic combine on this launch path)
     a.groups = (int)groups;

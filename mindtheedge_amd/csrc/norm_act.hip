@@ -25,6 +25,7 @@
 
 int g_mte_gn_prezeroed = 0;
 int g_mte_handoff_fences = 0;
+int g_mte_wgrad_shared = 0;
 unsigned* g_mte_err_dev = nullptr;             // device address of the error word (mte_device_error_init)
 static volatile unsigned* g_mte_err_host = nullptr;
 
@@ -1285,6 +1286,7 @@ int mte_set_option(int option, int value) {
     if (option == 0) { g_mte_gn_prezeroed = value ? 1 : 0; return MTE_OK; }      // MTE_OPT_GN_PREZEROED
     if (option == 1) { g_mte_loss_prezeroed = value ? 1 : 0; return MTE_OK; }    // MTE_OPT_LOSS_PREZEROED
     if (option == 2) { g_mte_handoff_fences = value ? 1 : 0; return MTE_OK; }    // MTE_OPT_HANDOFF_FENCES
+    if (option == 3) { g_mte_wgrad_shared = value ? 1 : 0; return MTE_OK; }      // MTE_OPT_WGRAD_SHARES_CHIP
     return MTE_ERR_ARG;
 }
 

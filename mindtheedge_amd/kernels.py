@@ -663,12 +663,14 @@ _CONV_SOLO = 2      # MTE_CONV_SOLO: the forward pass has no weight-gradient ker
 # stream re-joins at the end of the autograd pass (engine callback) and wherever gradients are consumed earlier
 # (bucketed all-reduce).
 _side = {"enabled": True, "streams": [], "next": 0, "keep": [], "keep_bytes": 0, "callback_queued": False, "dirty": False}
+lib.set_option(3, 1, lazy=True)
 _SIDE_STREAMS = int(os.environ.get("MTE_SIDE_STREAMS", "1"))
 _SIDE_KEEP_LIMIT = 24 << 30          # bytes of (x, dy) kept alive for the side stream before a forced join
 
 
 def use_wgrad_side_stream(flag):
     _side["enabled"] = bool(flag)
+    lib.set_option(3, 1 if flag else 0, lazy=True)           # MTE_OPT_WGRAD_SHARES_CHIP: the weight-gradient launch widths follow the schedule
 
 
 class _BandChain:
