@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmte_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm8.hip", "conv_wgrad9.hip", "conv_patch.hip", "conv_stem.hip", "norm_act.hip", "pack3d.hip", "pack_fold.hip", "heads_misc.hip", "edge_loss.hip", "eval_metrics.hip", "dee_post.hip", "chamfer.hip", "canny.hip", "san.hip", "data_prep.hip"]
+SOURCES = ["conv_igemm.hip", "conv_igemm8.hip", "conv_wgrad9.hip", "tap_wgrad.hip", "conv_patch.hip", "conv_stem.hip", "norm_act.hip", "pack3d.hip", "pack_fold.hip", "heads_misc.hip", "edge_loss.hip", "eval_metrics.hip", "dee_post.hip", "chamfer.hip", "canny.hip", "san.hip", "data_prep.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=off"]
 
 

@@ -9,6 +9,8 @@
 #include "common.hpp"
 #include <atomic>
 
+int tap_wgrad_mfma_launch(const bf16_t* x, long ldx, const float* m, float* rec, long rec_stride, int B, int H, int W, int C, int sgn, int up2, int has_db,
+                          int max_wgs, int* groups, hipStream_t st);                                // tap_wgrad.hip
 namespace {
 
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float* v);
@@ -852,6 +854,16 @@ int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float*
     const long npix = (long)B * H * W;
     HeadArgs a{}; a.x = x; a.ldx = ldx; a.dlogit = dlogit; a.dw = records; a.rec_stride = head_record_stride(C);
     a.B = B; a.H = H; a.W = W; a.C = C; a.npix = npix;
+    const int n = C * 9 + 1;
+    if (dtype == MTE_DT_BF16) {                                  // round 5: the sums as a GEMM over pixels on the matrix cores (tap_wgrad.hip)
+        int groups = 0;
+        const int rc = tap_wgrad_mfma_launch((const bf16_t*)x, ldx, dlogit, records, a.rec_stride, B, H, W, C, -1, 0, 1, HEAD_WGRAD_MAX_BLOCKS, &groups, stream);
+        if (rc == MTE_OK) {
+            hipLaunchKernelGGL(invdepth_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, stream, records, a.rec_stride, groups, n, dwb);
+            return mte_check_launch();
+        }
+        if (rc != MTE_ERR_UNSUPPORTED) return rc;
+    }
     const size_t lds = sizeof(float) * (C * 9 + 4);
     long g = head_strips(B, H, W, C);
     static std::atomic<int> res_b[64], res_f[64];               // by C / 8 (head_ok: C is a multiple of 8, at most 504)
@@ -861,7 +873,6 @@ int mte_invdepth_bwd_weight(const void* x, long ldx, const float* dlogit, float*
     if (g > HEAD_WGRAD_MAX_BLOCKS) g = HEAD_WGRAD_MAX_BLOCKS;
     if (dtype == MTE_DT_BF16) hipLaunchKernelGGL(invdepth_bwd_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(invdepth_bwd_weight_kernel<float>, dim3((unsigned)g), dim3(256), lds, stream, a);
-    const int n = C * 9 + 1;
     hipLaunchKernelGGL(invdepth_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, stream, records, a.rec_stride, (int)g, n, dwb);
     return mte_check_launch();
 }
@@ -923,6 +934,15 @@ int mte_rank1_conv_bwd_weight(const void* dy, long lddy, const float* inv, float
                               int B, int h, int wl, int N, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dy || !inv || !dw || !records || (N != 32 && N != 64 && N != 128) || B < 1 || h < 1 || wl < 1) return MTE_ERR_ARG;
+    if (dtype == MTE_DT_BF16) {                                  // round 5: tap_wgrad.hip (x = dy at full resolution, the map up-sampled on the way into LDS)
+        int groups = 0;
+        const int rc = tap_wgrad_mfma_launch((const bf16_t*)dy, lddy, inv, records, (long)N * 9, B, 2 * h, 2 * wl, N, +1, 1, 0, RANK1_BWD_WGS, &groups, stream);
+        if (rc == MTE_OK) {
+            hipLaunchKernelGGL(rank1_wgrad_reduce_kernel, dim3((N * 9 + 3) / 4), dim3(256), 0, stream, records, groups, N, dw, dw_stride);
+            return mte_check_launch();
+        }
+        if (rc != MTE_ERR_UNSUPPORTED) return rc;
+    }
     const int per16 = dtype == MTE_DT_BF16 ? 8 : 4;
     const long items = (long)B * h * ((wl + 15) / 16) * (N / per16);
     long g = (items + 255) / 256; if (g > RANK1_BWD_WGS) g = RANK1_BWD_WGS; if (g < 1) g = 1;

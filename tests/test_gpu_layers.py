@@ -449,3 +449,63 @@ def test_inv_depth_head_forward_on_mfma_matches_the_valu_kernel(C, B, H, W):
         with kernel_variant(30, knob, 1):
             v = run()
         assert torch.isfinite(v).all() and rel_err(v, ref) < 2e-5, knob
+
+
+@pytest.mark.parametrize("C,B,H,W,extra", [(32, 2, 6, 64, 0), (32, 1, 3, 32, 32), (64, 2, 5, 96, 0), (128, 1, 4, 64, 64), (256, 1, 3, 32, 0), (64, 1, 40, 160, 0),
+                                           (32, 3, 17, 128, 0), (256, 2, 7, 64, 0)])
+def test_one_channel_weight_gradients_on_mfma_match_the_valu_kernels_and_fp64(C, B, H, W, extra):
+    """tap_wgrad_mfma_kernel (tap_wgrad.hip, round 5): the InvDepth head's weight gradient (reference layers01.py:99-123, Conv2d(C, 1, 3): dw[c][tap] =
+    sum x[q][c] dlogit[q - (tap - 1)], db = sum dlogit) and the weight column of the decoder's inverse-depth input channel (PackNetSAN01.py:118-143, kept as
+    a rank-1 term: dw[n][tap] = sum dy[p][n] up2(inv)[p + tap - 1]) as GEMMs over pixels, against the fp32-VALU kernels they replace on the same inputs and
+    against float64; channel slices of a wider buffer (ldx > C), one- and many-unit waves, image borders in every unit, batches."""
+    from conftest import kernel_variant
+    from mindtheedge_amd import kernels as K
+    g = torch.Generator().manual_seed(C + H + W + extra)
+    st = torch.cuda.current_stream().cuda_stream
+    wide = K.image_to_act((torch.rand(B, C + extra, H, W, generator=g) * 2 - 1).cuda())
+    x = wide[:, extra // 2:extra // 2 + C] if extra else wide
+    xp, ldx = K._pl(x)
+    assert ldx == C + extra
+    dl = ((torch.rand(B, H, W, generator=g) * 2 - 1) * torch.rand(B, H, W, generator=g)).cuda()
+
+    def head():
+        dwb = torch.full((C * 9 + 1,), float("nan"), device="cuda")
+        rec = torch.empty((int(K.lib.mte_invdepth_bwd_weight_workspace_elems(C)),), dtype=torch.float32, device="cuda")
+        K.lib.mte_invdepth_bwd_weight(xp, ldx, dl.data_ptr(), dwb.data_ptr(), rec.data_ptr(), B, H, W, C, K.DT_BF16, st)
+        torch.cuda.synchronize()
+        return dwb.cpu()
+
+    got = head()
+    with kernel_variant(31, 0, 1):
+        old = head()
+    xd = x.float().double().contiguous()
+    ref = torch.nn.grad.conv2d_weight(xd, (1, C, 3, 3), dl.double()[:, None], padding=1).reshape(-1).cpu()
+    ref = torch.cat([ref, dl.double().sum().reshape(1).cpu()])
+    assert torch.isfinite(got).all()
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < 2e-5 * scale + 2 * float((old.double() - ref).abs().max())
+    assert float((got.double() - ref).abs().max()) < 1e-4 * scale            # fp32 sums of products exact to 2^-17
+    assert torch.equal(got, head())                                          # fixed summation order
+
+    if C <= 128:                                                             # rank-1 column: x = dy at full resolution, the map at half resolution
+        inv = (torch.rand(B, H, W, generator=g) * 2).cuda()
+        dy = K.image_to_act((torch.rand(B, C + extra, 2 * H, 2 * W, generator=g) * 2 - 1).cuda())
+        dys = dy[:, extra // 2:extra // 2 + C] if extra else dy
+        dp, ldd = K._pl(dys)
+
+        def column():
+            dw = torch.full((C, 5, 9), float("nan"), device="cuda")          # column 3 of a 5-input-channel OIHW weight
+            rec = torch.empty((int(K.lib.mte_rank1_conv_bwd_records_elems(C)),), dtype=torch.float32, device="cuda")
+            K.lib.mte_rank1_conv_bwd_weight(dp, ldd, inv.data_ptr(), dw.data_ptr() + 4 * 3 * 9, 5 * 9, rec.data_ptr(), B, H, W, C, K.DT_BF16, st)
+            torch.cuda.synchronize()
+            return dw[:, 3].cpu()
+
+        got = column()
+        with kernel_variant(31, 0, 1):
+            old = column()
+        up = torch.nn.functional.interpolate(inv.double()[:, None], scale_factor=2, mode="nearest")
+        ref = torch.nn.grad.conv2d_weight(up, (C, 1, 3, 3), dys.float().double().contiguous(), padding=1).reshape(C, 9).cpu()
+        scale = float(ref.abs().max())
+        assert torch.isfinite(got).all()
+        assert float((got.double() - ref).abs().max()) < 2e-5 * scale + 2 * float((old.double() - ref).abs().max())
+        assert float((got.double() - ref).abs().max()) < 1e-4 * scale
