@@ -82,6 +82,10 @@ int mte_device_error_poll(void);
  * up to 32 further slabs BEHIND the parts as scratch: a stage of more than 32 parts is allocated with parts + 32 slabs. */
 int mte_conv2d_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int stage_parts, int* parts_out,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, mte_stream_t stream);
+/* 1 when mte_conv2d_wgrad takes this 3x3 bf16 layer with its nine-tap kernel (conv_wgrad9.hip: N % 128 == 0, Cin_p % 64 == 0, W % 32 == 0 or W % 16 == 0
+ * and H even).  Round 5: measured faster than the LDS-patch weight gradient on every 128-output layer both take (128 -> 128 @96x320: 100.5 -> 84.9 us,
+ * 192 -> 128: 147 -> 115), so the host asks this first. */
+int mte_conv2d_wgrad_nine_tap(int H, int W, int Cin_p, int N, int KH, int KW, int dtype);
 /* OIHW fp32 master weights -> forward pack [Cout][taps][Cin_p] and (optional) dgrad pack [Cin_p][taps rot180][Cout_p] */
 int mte_pack_conv_weights(const float* w_oihw, void* wfwd, void* wbwd, int Cout, int Cin, int KH, int KW,
                           int Cin_p, int Cout_p, int dtype, mte_stream_t stream);

@@ -294,14 +294,22 @@ int g_wgrad9 = 1;                                    // development knob (mte_de
 #endif
 int g_wgrad9_wgs = MTE_W9_WGS;                       // development knob (mte_debug_set(27, v)): workgroups aimed for per shared-chip launch (0 = one per CU)
 
-// -> MTE_OK and *parts_out slabs written, or MTE_ERR_UNSUPPORTED (the caller takes the generic kernel)
-__attribute__((visibility("hidden"))) int wgrad9_launch(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int parts_cap, int* parts_out,
-                                                        int B, int H, int W, int Cin_p, int N, hipStream_t st) {
-    if (!g_wgrad9 || N % 128 != 0 || Cin_p % 64 != 0 || parts_cap < 1) return MTE_ERR_UNSUPPORTED;
+static int wgrad9_form(int H, int W, int Cin_p, int N) {     // 0: not this kernel's; 1: 1 x 32 K-steps; 2: 2 x 16
+    if (!g_wgrad9 || N % 128 != 0 || Cin_p % 64 != 0) return 0;
     // 1 x 32 K-steps where the rows allow it: measured 2-4 % faster on the 48x160 layers than 2 x 16 ones although they stage 15 patch pieces against 12
     // (development knob 26 = 2: 2 x 16 first)
     const bool ok2 = W % 16 == 0 && H % 2 == 0, ok1 = W % 32 == 0;
-    const int rk = g_wgrad9 == 2 ? (ok2 ? 2 : (ok1 ? 1 : 0)) : (ok1 ? 1 : (ok2 ? 2 : 0));
+    return g_wgrad9 == 2 ? (ok2 ? 2 : (ok1 ? 1 : 0)) : (ok1 ? 1 : (ok2 ? 2 : 0));
+}
+extern "C" int mte_conv2d_wgrad_nine_tap(int H, int W, int Cin_p, int N, int KH, int KW, int dtype) {
+    return dtype == MTE_DT_BF16 && KH == 3 && KW == 3 && H > 0 && W > 0 && wgrad9_form(H, W, Cin_p, N) ? 1 : 0;
+}
+
+// -> MTE_OK and *parts_out slabs written, or MTE_ERR_UNSUPPORTED (the caller takes the generic kernel)
+__attribute__((visibility("hidden"))) int wgrad9_launch(const void* x, long ldx, const void* dy, long ldy, float* dw_stage, int parts_cap, int* parts_out,
+                                                        int B, int H, int W, int Cin_p, int N, hipStream_t st) {
+    if (parts_cap < 1) return MTE_ERR_UNSUPPORTED;
+    const int rk = wgrad9_form(H, W, Cin_p, N);
     if (!rk) return MTE_ERR_UNSUPPORTED;
     const long M = (long)B * H * W;
     if (((M + 2 * W + 16) * ldx) * 2 >= 0x7ff00000L || ((M - 1) * ldy + N) * 2 >= 0x7ff00000L) return MTE_ERR_UNSUPPORTED;

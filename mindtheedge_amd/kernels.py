@@ -786,6 +786,8 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     # in the unpack pass measured 7 % slower)
     per = cout * kh * kw * Cp
     patch = _cfg["patch_kernels"] and x.dtype == torch.bfloat16 and lib.mte_conv2d_patch_wgrad_supported(W, Cp, cout, kh, kw, DT_BF16) == 1
+    if patch and lib.mte_conv2d_wgrad_nine_tap(H, W, Cp, cout, kh, kw, _dt(x)) == 1:
+        patch = False                    # 3x3 with 128 outputs: the nine-tap kernel (round 5: 128 -> 128 @96x320 100.5 -> 84.9 us, 192 -> 128 147 -> 115 incl. the unpack pass)
     if kh * kw == 1 and Cp >= 64:
         patch = False                    # 1x1 with >= 64 inputs: the generic kernel with many pixel splits streams both operands at 4.5 TB/s (the patch kernel deals TAPS to its waves: 91 -> 56 us)
     # the LDS-patch kernel runs 128..512 workgroups per layer: one slab each (plain stores), combined by a two-level reduction

@@ -324,6 +324,8 @@ WGRAD9_SHAPES = [  # cin, cout, B, H, W, input as a channel slice of a wider buf
     (64, 384, 3, 10, 32, False),       # three output tiles, three images
     (256, 128, 1, 5, 64, True),        # odd height
     (64, 128, 8, 24, 80, False),       # many pixel splits (one tile: splits = the CU count, capped by the stage)
+    (2048, 128, 16, 3, 160, False),    # the folded pack layers' form (round 5: taken over from the LDS-patch kernel): three rows, every K-step at a border
+    (128, 128, 1, 1, 32, False),       # one row: top and bottom border in the same K-step
 ]
 
 
