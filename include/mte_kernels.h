@@ -115,6 +115,15 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
                          int B, int H, int W, int Cin_p, int N, int KH, int KW, int accumulate, mte_stream_t stream);
 int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, mte_stream_t stream);
+/* round 5 -- mte_conv2d_patch_fwd that also leaves the GroupNorm(16) statistics of what it stores (reference layers01.py:35-38: Conv2d -> GroupNorm(16) -> ELU;
+ * the reference's GroupNorm is a cuDNN call that reads the conv output again): one record of 32 floats (sum, sum of squares per group, fp32 over the tile's
+ * pixels) per output tile, written in the store loop from the bf16 values being stored -- with `accumulate` from the sums.  rec: at least
+ * mte_conv2d_patch_fwd_gn_elems(B, H, W) floats; *tiles_per_sample_out records per sample were written (tile height depends on the kernel form).
+ * mte_gn_stats_from_records (below) adds them in tile order into the buffer mte_gn_stats would have filled: the stand-alone statistics pass over y
+ * (252 MB per full-resolution layer at B = 8) is not run.  N % 16 == 0, else MTE_ERR_UNSUPPORTED.  Bit-reproducible (no atomics). */
+long mte_conv2d_patch_fwd_gn_elems(int B, int H, int W);
+int mte_conv2d_patch_fwd_gn(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N, int KH, int KW,
+                            int accumulate, float* rec, long rec_elems, int* tiles_per_sample_out, mte_stream_t stream);
 
 /* ---- stem convolution: exactly 8 input channels (the zero-padded rgb image), C_out <= 32, k in {3,5,7}, W % 32 == 0, bf16
  * (encoder.pre_calc = Conv2D(3, 32, 5, 1): networks/depth/PackNetSAN01.py:27, layers01.py:29-31).  With 8 channels a pixel is one
@@ -139,6 +148,9 @@ int mte_conv2d_stem_wgrad(const void* x, long ldx, const void* dy, long lddy, fl
 long mte_gn_stats_elems(int B);
 int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float* scale2, double* stats,
                  int B, int HW, int C, int dtype, mte_stream_t stream);
+/* round 5: the same sums from the per-tile records a convolution left in its store loop (mte_conv2d_patch_fwd_gn): stats[b][group][2] = the
+ * tiles_per_sample records of sample b added in tile order (fp64).  Only the first 32 B doubles of `stats` are written. */
+int mte_gn_stats_from_records(const float* rec, int tiles_per_sample, double* stats, int B, mte_stream_t stream);
 /* mte_gn_elu_fwd: stats_ready = 1: `stats` holds the sums of mte_gn_stats.  stats_ready = 0 (allowed where
  * mte_gn_fwd_is_single_pass(HW, C, y2 != NULL, dtype) returns 1: a (sample, group) slab fits one workgroup's registers): the
  * kernel loads each slab ONCE, computes its statistics on chip, normalises and stores `stats` in the same format as an

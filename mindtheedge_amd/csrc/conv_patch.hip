@@ -54,7 +54,47 @@ struct PatchArgs {
     const float* r1_w; long r1_ws;                 // element (n, tap) at r1_w[n * r1_ws + tap]
     // second K source (first form, mte_conv2d_patch_fwd_plus1x1): y += conv_1x1(x2, wp2) -- more K-steps of the same tile at the centre tap only
     const bf16_t* x2; long ldx2; const bf16_t* wp2; int C2;
+    // round 5 (mte_conv2d_patch_fwd_gn): GroupNorm(16) statistics of the tile AS STORED, one record of 32 floats (sum, sum of squares per group) per tile at
+    // gn_rec + ((b * tiles_y + ty) * tiles_x + tx) * 32 -- the consumer's stand-alone statistics pass over y (252 MB at full resolution) is not needed
+    float* gn_rec;
 };
+
+// ---- GroupNorm statistics in the store loop (round 5) ----------------------------------------------------------------------------------------------------------
+// Both forward forms end with the tile staged in LDS as bf16 and every thread storing the 16-byte chunk column c = tid % (NT * 4) of 4 NT pixels: exactly the
+// thread -> (channel chunk, pixel rows) map of the statistics pass (norm_act.hip: gn_stats_kernel).  With a.gn_rec set the thread also adds the values it stores
+// (after the bf16 rounding, after the accumulation: what every later pass reads back) into 8 + 8 fp32 sums; the lanes of a wave that share c are added by
+// xor butterflies, the four waves and the channels of a group in a fixed order by 32 threads: bit-reproducible, no atomics.  mte_gn_stats_from_records adds
+// the tiles of a sample in tile order (fp64).  Cost: ~25 VALU per stored chunk + ~150 instructions per tile, against one pass over the tensor.
+__device__ __forceinline__ void patch_gn_add(const u32x4_t& v, bool ok, float* s, float* q) {
+    float f[8];
+    unpack16<bf16_t>(v, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float t = ok ? f[k] : 0.f; s[k] += t; q[k] = fmaf(t, t, q[k]); }
+}
+template <int NT>
+__device__ __forceinline__ void patch_gn_record(const PatchArgs& a, float* s, float* q, int tid, long tile, char* smem) {
+    constexpr int NC = NT * 4;                                     // chunk columns of the staged tile
+    const int lane = tid & 63, wave = tid >> 6, c = tid % NC;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int off = NC; off < 64; off <<= 1) { s[k] += __shfl_xor(s[k], off, 64); q[k] += __shfl_xor(q[k], off, 64); }
+    __syncthreads();                                               // every thread has read its chunks of the staged tile: the buffer is free
+    float* sred = (float*)smem;                                    // [4 waves][NC][16]
+    if (lane < NC) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sred[(wave * NC + c) * 16 + k] = s[k]; sred[(wave * NC + c) * 16 + 8 + k] = q[k]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int g = tid >> 1, which = tid & 1, gs = a.N >> 4;    // group, sum / sum of squares, channels per group (launcher: N % 16 == 0)
+        float t = 0.f;
+        for (int ch = g * gs; ch < (g + 1) * gs; ++ch)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += sred[(w * NC + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
+        a.gn_rec[tile * 32 + tid] = t;
+    }
+}
 
 
 // ---- second K source at the centre tap (EXTRA; mte_conv2d_patch_fwd_plus1x1) ---------------------------------------------------------------------------------
@@ -236,6 +276,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
     const int c = tid % (NT * 4);
+    const bool gnrec = a.gn_rec != nullptr;                        // (wave-uniform)
+    float gs_[8], gq_[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gs_[k] = 0.f; gq_[k] = 0.f; }
     if constexpr (ACC) {
         // accumulating: branch-free, every LDS and global read of the thread's pixels issued before the first use (see the second form's epilogue;
         // same-box A/B, 32 -> 64 at 384 x 1280: the guarded read -> wait -> add -> store loop cost 100 us over the plain store)
@@ -260,18 +304,22 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
             unpack16<bf16_t>(vold[i], vo);
 #pragma unroll
             for (int k = 0; k < 8; ++k) vn[k] += vo[k];
-            if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pack16<bf16_t>(vn);
+            const u32x4_t pk = pack16<bf16_t>(vn);
+            if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pk;
+            if (gnrec) patch_gn_add(pk, ok[i], gs_, gq_);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < OCH / 256; ++i) {
             const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
             const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
-            if (yy < a.H && c < cpp)
-                *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * NB + c * 16);
+            const u32x4_t pk = *(const u32x4_t*)(smem + pix * NB + c * 16);
+            if (yy < a.H && c < cpp) *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = pk;
+            if (gnrec) patch_gn_add(pk, yy < a.H && c < cpp, gs_, gq_);
             asm volatile("" ::: "memory");                         // one read -> store per iteration: with the reads hoisted the stores leave in one burst (2-4 % slower)
         }
     }
+    if (gnrec) patch_gn_record<NT>(a, gs_, gq_, tid, ((long)b * tiles_y + ty_) * tiles_x + tx_, smem);
     PATCH_STAMP();
 }
 
@@ -570,6 +618,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
     const int c = tid % (NT * 4);
+    const bool gnrec = a.gn_rec != nullptr;                        // (wave-uniform)
+    float gs_[8], gq_[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gs_[k] = 0.f; gq_[k] = 0.f; }
     if constexpr (ACC) {
         // accumulating (a consumer's gradient added onto another's, or onto a term written first; an instantiation of its own: as a run-time branch beside
         // the plain loop it cost the tall plain kernels 2 %): branch-free, with the LDS and global reads of all of the
@@ -597,18 +649,22 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
             unpack16<bf16_t>(vold[i], vo);
 #pragma unroll
             for (int k = 0; k < 8; ++k) vn[k] += vo[k];
-            if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pack16<bf16_t>(vn);
+            const u32x4_t pk = pack16<bf16_t>(vn);
+            if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pk;
+            if (gnrec) patch_gn_add(pk, ok[i], gs_, gq_);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < OCH / 256; ++i) {
             const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
             const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
-            if (yy < a.H && c < cpp)
-                *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
+            const u32x4_t pk = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
+            if (yy < a.H && c < cpp) *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = pk;
+            if (gnrec) patch_gn_add(pk, yy < a.H && c < cpp, gs_, gq_);
             asm volatile("" ::: "memory");                         // one read -> store per iteration (see the first form)
         }
     }
+    if (gnrec) patch_gn_record<NT>(a, gs_, gq_, tid, ((long)b * tiles_y + ty_) * tiles_x + tx_, smem);
     PATCH_STAMP();
 }
 
@@ -810,7 +866,7 @@ int g_patch_fwd2 = 1;
 #endif
 //                               // development knob (mte_debug_set(11, 400 + v)): 0 = the first form of the forward kernel
 
-template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
+template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int* tile_rows = nullptr) {
     // the second form addresses the input through a buffer descriptor (< 2 GiB)
     // Same-box A/B over the network's shapes (tools/conv_shape_bench.py): 7x7 -12..-15 %, 5x5 -8..-12 %, 3x3 with 32 outputs -4..-12 %, 3x3
     // with 64 outputs -8 % from three slices on; with one or two slices the first form wins by 8-15 % (167 VGPRs, three workgroups per CU,
@@ -819,6 +875,7 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
                     (((long)a.B * a.H * a.W - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((uintptr_t)a.bias & 15) == 0;   // (it reads the bias in 16-byte groups)
     if constexpr (NT == 1) {
         if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
+            if (tile_rows) *tile_rows = 16;
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
             if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
@@ -827,6 +884,7 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
             return mte_check_launch();
         }
     }
+    if (tile_rows) *tile_rows = TH;
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
     if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
@@ -834,12 +892,12 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     return mte_check_launch();
 }
-template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st) {
+template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st, int* tile_rows = nullptr) {
     switch (K) {
-        case 1: return launch_fwd<1, NT>(a, st);
-        case 3: return launch_fwd<3, NT>(a, st);
-        case 5: return launch_fwd<5, NT>(a, st);
-        case 7: return launch_fwd<7, NT>(a, st);
+        case 1: return launch_fwd<1, NT>(a, st, tile_rows);
+        case 3: return launch_fwd<3, NT>(a, st, tile_rows);
+        case 5: return launch_fwd<5, NT>(a, st, tile_rows);
+        case 7: return launch_fwd<7, NT>(a, st, tile_rows);
     }
     return MTE_ERR_UNSUPPORTED;
 }
@@ -960,6 +1018,23 @@ int mte_conv2d_patch_fwd(const void* x, long ldx, const void* wpatch, const floa
     if (!x || !wpatch || !y || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
     PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
     return N <= 32 ? dispatch_fwd<1>(a, KH, stream) : dispatch_fwd<2>(a, KH, stream);
+}
+
+// mte_conv2d_patch_fwd that also leaves the GroupNorm(16) statistics of y as per-tile records (round 5): rec needs mte_conv2d_patch_fwd_gn_elems(B, H, W) floats;
+// *tiles_per_sample_out = records written per sample (the tile height depends on the kernel form), to be handed to mte_gn_stats_from_records.
+// With accumulate the records describe the SUMS this launch stores.  N % 16 == 0 (whole groups).
+long mte_conv2d_patch_fwd_gn_elems(int B, int H, int W) { return (long)B * (W / TW) * ((H + TH - 1) / TH) * 32; }
+int mte_conv2d_patch_fwd_gn(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N, int KH, int KW,
+                            int accumulate, float* rec, long rec_elems, int* tiles_per_sample_out, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpatch || !y || !rec || !tiles_per_sample_out || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
+    if (N % 16 != 0) return MTE_ERR_UNSUPPORTED;
+    if (rec_elems < mte_conv2d_patch_fwd_gn_elems(B, H, W)) return MTE_ERR_ARG;
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, rec};
+    int rows = TH;
+    const int rc = N <= 32 ? dispatch_fwd<1>(a, KH, stream, &rows) : dispatch_fwd<2>(a, KH, stream, &rows);
+    *tiles_per_sample_out = (W / TW) * ((H + rows - 1) / rows);
+    return rc;
 }
 
 // The 3x3 forward with ONE MORE input channel given as a low-resolution map: y = conv_3(x, wpatch) + bias + conv_1(nearest_up2(inv), w1).  inv [B][H/2][W/2] fp32;

@@ -1058,6 +1058,30 @@ template <typename T, int HAS2, bool HASDB> bool launch_bwd_cluster(const GnArgs
     return false;
 }
 
+// statistics from per-tile records (round 5: the LDS-patch forward kernels leave one record of 32 floats per output tile, conv_patch.hip: patch_gn_record):
+// stats[b][group][2] (fp64) = the records of sample b added in tile order.  One workgroup per sample; 32 threads per value take tiles k, k + 32, ... in order,
+// then the 32 partial sums are added in order (the scheme of the statistics pass's last arriver).
+__global__ __launch_bounds__(1024) void gn_stats_from_records_kernel(const float* __restrict__ rec, int nrec, double* __restrict__ stats) {
+    __shared__ double s_fin[32 * 32];
+    const int b = blockIdx.x, v = threadIdx.x & 31, k = threadIdx.x >> 5;
+    const float* r = rec + (long)b * nrec * 32 + v;
+    double acc = 0.0;
+    int j = k;
+    for (; j + 3 * 32 < nrec; j += 4 * 32) {
+        const float t0 = r[(long)j * 32], t1 = r[(long)(j + 32) * 32], t2 = r[(long)(j + 64) * 32], t3 = r[(long)(j + 96) * 32];
+        acc += (double)t0; acc += (double)t1; acc += (double)t2; acc += (double)t3;
+    }
+    for (; j < nrec; j += 32) acc += (double)r[(long)j * 32];
+    s_fin[k * 32 + v] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += s_fin[i * 32 + threadIdx.x];
+        stats[(long)b * 32 + threadIdx.x] = t;
+    }
+}
+
 template <typename T> int run_stats(GnArgs& a, hipStream_t stream) {
     constexpr int NT = 1024;
     const int rstep = NT / (a.C / Elem<T>::PER16);
@@ -1201,6 +1225,13 @@ int mte_gn_stats(const void* y1, long ld1, const void* y2, long ld2, const float
     GnArgs a{}; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = stats; a.B = B; a.HW = HW; a.C = C;
     gn_common(a);
     return dtype == MTE_DT_BF16 ? run_stats<bf16_t>(a, stream) : run_stats<float>(a, stream);
+}
+
+int mte_gn_stats_from_records(const float* rec, int tiles_per_sample, double* stats, int B, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!rec || !stats || tiles_per_sample < 1 || B < 1) return MTE_ERR_ARG;
+    hipLaunchKernelGGL(gn_stats_from_records_kernel, dim3((unsigned)B), dim3(1024), 0, stream, rec, tiles_per_sample, stats);
+    return mte_check_launch();
 }
 
 // z = ELU(GN(y1 + scale2*y2)).  stats: the sums mte_gn_stats (or a conv epilogue) accumulated -- or, where

@@ -578,6 +578,8 @@ _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0
         # residual blocks: conv2's GroupNorm + ELU applied inside the kernel that forms x_out + Dropout2d(shortcut) and takes the sum's statistics
         # (ConvResidualTailFn / mte_gn_tail_fwd).  MTE_FUSE_TAIL=0: the round-4 form (ConvGnEluFn + ResidualTailFn over two tensors)
         "fuse_residual_tail": os.environ.get("MTE_FUSE_TAIL", "1") == "1",
+        # round 5: the LDS-patch forward kernels leave the GroupNorm statistics of their output as per-tile records (no statistics pass over y)
+        "gn_stats_in_conv": os.environ.get("MTE_GN_IN_CONV", "1") == "1",
         # residual blocks: the 1x1 shortcut's FORWARD launch on the (idle) weight-gradient side stream, beside conv1 / conv2.  MTE_OVERLAP_SHORTCUT=0: in line
         # (measured same-box, round 5: 23.75 ms per step with it against 23.72 without -- the forward pass has no idle CUs for it to fill; OFF by default)
         "overlap_shortcut_fwd": os.environ.get("MTE_OVERLAP_SHORTCUT", "0") == "1"}
@@ -623,9 +625,11 @@ class SiteList:
         self.shape = tuple(mask.shape)
 
 
-def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumulate=False, sites=None):
+def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumulate=False, sites=None, gn_records=None):
     """y = conv_k(zero_pad(x)) + bias -> NHWC activation (written into `out` when given).
-    sites (SiteList): the sparse form -- only the active sites are computed and written (mte_conv2d_igemm_sparse)."""
+    sites (SiteList): the sparse form -- only the active sites are computed and written (mte_conv2d_igemm_sparse).
+    gn_records (a list): the caller normalises y with GroupNorm(16) next -- where the launch can, it leaves the statistics of what it stores as per-tile
+    records and appends (records, tiles per sample) to the list (round 5: mte_conv2d_patch_fwd_gn); an empty list afterwards = run the statistics pass."""
     B, Cp, H, W = x.shape
     if out is None:
         out = new_act(B, cout, H, W, x.dtype, x.device)
@@ -643,6 +647,14 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumul
         lib.mte_conv2d_stem_fwd(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, B, H, W, cout, kh, kw, _stream())
         return out
     if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
+        if gn_records is not None and _cfg["gn_stats_in_conv"] and cout % 16 == 0:
+            n = int(lib.mte_conv2d_patch_fwd_gn_elems(B, H, W))
+            rec = torch.empty((n,), dtype=torch.float32, device=x.device)
+            tiles = ctypes.c_int(0)
+            lib.mte_conv2d_patch_fwd_gn(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw,
+                                        1 if accumulate else 0, rec.data_ptr(), n, ctypes.byref(tiles), _stream())
+            gn_records.append((rec, tiles.value))
+            return out
         lib.mte_conv2d_patch_fwd(xp, ldx, pack.get_patch(w, 'f').data_ptr(), _ptr(bias), yp, ldy, B, H, W, Cp, cout, kh, kw,
                                  1 if accumulate else 0, _stream())
         return out
@@ -890,7 +902,9 @@ def gn_stats_buffer(B, device):
     return _zeros((n,), torch.float64, device)
 
 
-def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
+def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, records=None):
+    """records: [(per-tile records, tiles per sample)] left by the convolution that produced y1 (conv_forward(gn_records=...)) -- the statistics pass
+    over y1 is replaced by the sum of the records"""
     B, C, H, W = y1.shape
     p1, l1 = _pl(y1)
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
@@ -899,6 +913,8 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None):
     stats = gn_stats_buffer(B, y1.device)
     if lib.mte_gn_fwd_is_single_pass_b(B, H * W, C, 1 if y2 is not None else 0, _dt(y1)) == 1:
         ready = 0                      # one kernel holds each (sample, group) slab on chip (one workgroup, or a cluster of them) -- statistics + apply
+    elif records and y2 is None:
+        lib.mte_gn_stats_from_records(records[0][0].data_ptr(), records[0][1], stats.data_ptr(), B, st)
     else:
         lib.mte_gn_stats(p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), B, H * W, C, _dt(y1), st)
     z = out if out is not None else new_act(B, C, H, W, y1.dtype, y1.device)
@@ -962,8 +978,9 @@ class ConvGnEluFn(torch.autograd.Function):
         ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
-        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
-        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out))
+        recs = []
+        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w, gn_records=recs)
+        z, stats = _gn_forward(y, None, None, gamma, beta, GN_EPS, out=None if out is None else alias_of(out), records=recs)
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
         ctx.bias = b
@@ -1203,7 +1220,8 @@ class ConvResidualTailFn(torch.autograd.Function):
         ctx.fork_slot = getattr(x1, "_mte_fork_slot", None)
         wf, _ = pack2.get(w2, x1.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w2.shape
-        c2 = conv_forward(x1, wf, b2, cout, kh, kw, pack=pack2, w=w2)
+        recs = []
+        c2 = conv_forward(x1, wf, b2, cout, kh, kw, pack=pack2, w=w2, gn_records=recs)
         B, C, H, W = c2.shape
         if tuple(s.shape) != (B, C, H, W) or s.dtype != c2.dtype:
             raise MteError("residual tail: shortcut %s / %s against %s / %s" % (tuple(s.shape), s.dtype, (B, C, H, W), c2.dtype))
@@ -1211,7 +1229,10 @@ class ConvResidualTailFn(torch.autograd.Function):
         p1, l1 = _pl(c2)
         p2, l2 = _pl(s)
         stats2 = gn_stats_buffer(B, c2.device)
-        lib.mte_gn_stats(p1, l1, 0, 0, 0, stats2.data_ptr(), B, H * W, C, _dt(c2), st)
+        if recs:                       # (round 5) conv2 left its statistics as per-tile records
+            lib.mte_gn_stats_from_records(recs[0][0].data_ptr(), recs[0][1], stats2.data_ptr(), B, st)
+        else:
+            lib.mte_gn_stats(p1, l1, 0, 0, 0, stats2.data_ptr(), B, H * W, C, _dt(c2), st)
         wait_ready(s)
         stats_t = gn_stats_buffer(B, c2.device)
         t = new_act(B, C, H, W, c2.dtype, c2.device)

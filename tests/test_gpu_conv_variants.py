@@ -367,3 +367,60 @@ def test_nine_tap_wgrad_matches_the_per_tap_kernel_and_fp64(shape, devlib):
     finally:
         devlib.mte_debug_set(26, 1)
         K.use_patch_kernels(True)
+
+
+GN_IN_CONV_SHAPES = [
+    # cin, cout, k, B, H, W, accumulate
+    (32, 32, 7, 2, 16, 64, False),     # tall second form (16-row tiles)
+    (32, 64, 3, 1, 24, 32, False),     # first form, two 32-channel output blocks
+    (96, 64, 3, 2, 12, 64, False),     # second form, two output blocks, ragged last tile row (12 = 8 + 4)
+    (64, 32, 3, 1, 40, 32, False),     # tall 3x3, 40 = 2 x 16 + 8 rows
+    (32, 32, 3, 1, 9, 32, False),      # H < 16: 8-row tiles, one row in the second tile
+    (128, 32, 7, 1, 16, 32, False),    # 7x7 with four input slices (8-row tiles)
+    (32, 64, 5, 2, 8, 96, False),
+    (32, 64, 3, 1, 24, 32, True),      # accumulating launches: the statistics of the SUMS that are stored
+    (96, 32, 3, 2, 20, 64, True),
+    (32, 16, 3, 1, 16, 32, False),     # 16 outputs: one channel per group
+]
+
+
+@pytest.mark.parametrize("shape", GN_IN_CONV_SHAPES)
+def test_patch_forward_leaves_the_groupnorm_statistics_of_what_it_stores(shape):
+    """mte_conv2d_patch_fwd_gn (round 5; reference layers01.py:35-38, Conv2d -> GroupNorm(16)): the per-tile records written in the store loop, added by
+    mte_gn_stats_from_records, against the stand-alone statistics pass (mte_gn_stats) over the same output -- every kernel form, ragged tile rows, accumulating
+    launches; the convolution output itself must not change by a bit, and two runs must agree bit for bit."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W, accumulate = shape
+    K.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(cin + cout + k + H)
+    x = K.image_to_act((torch.rand(B, cin, H, W, generator=g) * 2 - 1).cuda())
+    w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+    b = (torch.rand(cout, generator=g) - 0.5).cuda()
+    old = K.image_to_act((torch.rand(B, cout, H, W, generator=g) * 2 - 1).cuda()) if accumulate else None
+    pack = K.WeightPack()
+    wf, _ = pack.get(w, x.dtype, False)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(records):
+        out = old.clone() if accumulate else None
+        recs = [] if records else None
+        y = K.conv_forward(x, wf, b, cout, k, k, out=out, pack=pack, w=w, accumulate=accumulate, gn_records=recs)
+        stats = K.gn_stats_buffer(B, x.device)
+        if records:
+            assert len(recs) == 1
+            K.lib.mte_gn_stats_from_records(recs[0][0].data_ptr(), recs[0][1], stats.data_ptr(), B, st)
+        else:
+            p, l = K._pl(y)
+            K.lib.mte_gn_stats(p, l, 0, 0, 0, stats.data_ptr(), B, H * W, cout, K.DT_BF16, st)
+        torch.cuda.synchronize()
+        return y, stats[:32 * B].clone().cpu()
+
+    y0, ref = run(False)
+    y1, got = run(True)
+    assert torch.equal(y0, y1)                                                 # the store loop stores what it stored before
+    v = y1.float().double()
+    exact = torch.stack([v.reshape(B, 16, -1).sum(2), (v * v).reshape(B, 16, -1).sum(2)], dim=2).reshape(-1).cpu()   # (NCHW view: groups of cout/16 channels)
+    scale = exact.abs().max()
+    assert float((got - exact).abs().max()) <= 2e-6 * float(scale) + 2 * float((ref - exact).abs().max())
+    y2, again = run(True)
+    assert torch.equal(got, again)
