@@ -15,7 +15,7 @@ def family(name):
                      ("conv_patch_fwd", "conv patch fwd+dgrad"), ("conv_patch_wgrad", "conv patch wgrad"), ("conv_stem", "conv stem fwd+wgrad"),
                      ("pack_multi", "weight packs"), ("pack_weights", "weight packs"), ("unpack_wgrad", "wgrad unpack/reduce"), ("reduce_parts", "wgrad unpack/reduce"),
                      ("gn_", "GroupNorm+ELU"),
-                     ("pack3d", "conv3d pack/unpack"), ("unpack3d", "conv3d pack/unpack"), ("invdepth", "invdepth head"),
+                     ("pack3d", "conv3d pack/unpack"), ("unpack3d", "conv3d pack/unpack"), ("invdepth", "invdepth head"), ("tap_wgrad", "invdepth head"),
                      ("adam", "adam"), ("fillBuffer", "memset"), ("copyBuffer", "memcpy")):
         if key in n:
             return fam

@@ -24,4 +24,12 @@ python tools/trace_summary.py "$(find /tmp/trO -name '*kernel_trace.csv' | head 
 python tools/trace_summary.py "$(find /tmp/trS -name '*kernel_trace.csv' | head -1)" 7 60 > $out/r05_${tag}_train_T8_serial_trace_summary.txt
 python3 tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW 6 $out/r05_${tag}_pmc_traffic.json "profiles/r05_${tag}_pmc_traffic_T8.txt (round 5; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB)" > $out/r05_${tag}_pmc_traffic_T8.txt
 python bench.py --steps 20 --warmup 5 --dump-conv $out/r05_${tag}_conv_table.txt > $out/r05_${tag}_train_T8_bench.json 2> $out/r05_${tag}_bench.err
+# stamp the traffic figures with the API launch counts of the bench run they belong to (bench.py quotes `traffic` only while its own run counts the same)
+python3 - $out/r05_${tag}_pmc_traffic.json $out/r05_${tag}_train_T8_bench.json <<'PY'
+import json, sys
+t = json.load(open(sys.argv[1])); b = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+t["conv_family_api_launches_per_step"] = b["roofline"]["launches_per_step"]
+t["gn_family_api_launches_per_step"] = b["roofline_hbm"]["launches_per_step"]
+json.dump(t, open(sys.argv[1], "w"), indent=1)
+PY
 head -3 $out/r05_${tag}_train_T8_serial_trace_summary.txt; tail -c 600 $out/r05_${tag}_train_T8_bench.json
