@@ -131,6 +131,12 @@ long mte_conv2d_patch_fwd_gr_elems(int B, int H, int W, int N);
 int mte_conv2d_patch_fwd_gr(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N, int KH, int KW,
                             int accumulate, const void* v, long ldv, const double* stats, const float* gamma, const float* beta, float eps,
                             float* rec, long rec_elems, float* red, mte_stream_t stream);
+/* ... the same for mte_conv2d_patch_fwd_plus1x1 (a residual block's input gradient: conv1 and the 1x1 shortcut are the only consumers of the previous block's
+ * ELU(GN_t(t)), and that ONE launch stores its complete gradient). */
+int mte_conv2d_patch_fwd_plus1x1_gr(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
+                                    const void* x2, long ldx2, const void* wpatch2, int C2,
+                                    const void* v, long ldv, const double* stats, const float* gamma, const float* beta, float eps,
+                                    float* rec, long rec_elems, float* red, mte_stream_t stream);
 long mte_conv2d_patch_fwd_gn_elems(int B, int H, int W);
 int mte_conv2d_patch_fwd_gn(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N, int KH, int KW,
                             int accumulate, float* rec, long rec_elems, int* tiles_per_sample_out, mte_stream_t stream);

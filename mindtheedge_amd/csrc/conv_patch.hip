@@ -1215,14 +1215,13 @@ int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, cons
 // y = conv_3x3(x, wpatch) + conv_1x1(x2, wpatch2) + bias in ONE launch: the second term's C2 channels are further K-steps of every tile at the centre tap
 // (wpatch2: the fragment-block pack of the 1x1 weights for the same N).  Written for the data gradient of a residual block's input (reference layers01.py:55-73:
 // conv1 (3x3) and the 1x1 shortcut conv3 read the same x), dx = conv3x3^T(dy1) + conv1x1^T(dy3): instead of a 1x1 launch and an ACCUMULATING 3x3 launch.
-int mte_conv2d_patch_fwd_plus1x1(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
-                                 const void* x2, long ldx2, const void* wpatch2, int C2, hipStream_t stream) {
-    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!x || !wpatch || !y || !x2 || !wpatch2 || C2 < 8 || C2 % 8 != 0 || !patch_shape_ok(W, Cin_p, N, 3, 3)) return MTE_ERR_ARG;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, nullptr, nullptr, 0, (const bf16_t*)x2, ldx2, (const bf16_t*)wpatch2, C2};
-    const bool v2 = g_patch_fwd2 && (N <= 32 || Cin_p > 64) && (((long)B * H * W - 1) * ldx + Cin_p) * 2 < 0x7ff00000L && ((uintptr_t)bias & 15) == 0;   // (as launch_fwd)
+static int launch_plus1x1(const PatchArgs& a, hipStream_t stream, int* rows) {
+    const int B = a.B, H = a.H, W = a.W, N = a.N;
+    const bool v2 = g_patch_fwd2 && (N <= 32 || a.Cin_p > 64) && (((long)B * H * W - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((uintptr_t)a.bias & 15) == 0;   // (as launch_fwd)
+    *rows = TH;
     if (N <= 32) {
         if (g_patch_tall && H >= 16) {
+            *rows = 16;
             const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
             if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
@@ -1236,6 +1235,32 @@ int mte_conv2d_patch_fwd_plus1x1(const void* x, long ldx, const void* wpatch, co
         if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
     }
+    return mte_check_launch();
+}
+int mte_conv2d_patch_fwd_plus1x1(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
+                                 const void* x2, long ldx2, const void* wpatch2, int C2, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpatch || !y || !x2 || !wpatch2 || C2 < 8 || C2 % 8 != 0 || !patch_shape_ok(W, Cin_p, N, 3, 3)) return MTE_ERR_ARG;
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, nullptr, nullptr, 0, (const bf16_t*)x2, ldx2, (const bf16_t*)wpatch2, C2};
+    int rows;
+    return launch_plus1x1(a, stream, &rows);
+}
+// ... and with the first pass of the GroupNorm backward of the layer whose output gradient this launch writes (see mte_conv2d_patch_fwd_gr): a residual block's
+// input is the previous block's ELU(GN_t(t)), and conv1 + the 1x1 shortcut are its only consumers -- this ONE launch stores its complete gradient.
+int mte_conv2d_patch_fwd_plus1x1_gr(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
+                                    const void* x2, long ldx2, const void* wpatch2, int C2,
+                                    const void* v, long ldv, const double* stats, const float* gamma, const float* beta, float eps,
+                                    float* rec, long rec_elems, float* red, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpatch || !y || !x2 || !wpatch2 || C2 < 8 || C2 % 8 != 0 || !v || !stats || !gamma || !beta || !rec || !red || !patch_shape_ok(W, Cin_p, N, 3, 3)) return MTE_ERR_ARG;
+    if (N % 16 != 0) return MTE_ERR_UNSUPPORTED;
+    if (rec_elems < mte_conv2d_patch_fwd_gr_elems(B, H, W, N)) return MTE_ERR_ARG;
+    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, nullptr, nullptr, 0, (const bf16_t*)x2, ldx2, (const bf16_t*)wpatch2, C2, nullptr,
+                (const bf16_t*)v, ldv, stats, gamma, beta, eps, rec};
+    int rows;
+    const int rc = launch_plus1x1(a, stream, &rows);
+    if (rc != MTE_OK) return rc;
+    hipLaunchKernelGGL(patch_gr_finish_kernel, dim3((unsigned)B), dim3(1024), 0, stream, rec, (W / TW) * ((H + rows - 1) / rows), 2 * N, red);
     return mte_check_launch();
 }
 

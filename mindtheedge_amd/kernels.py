@@ -580,6 +580,11 @@ _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0
         "fuse_residual_tail": os.environ.get("MTE_FUSE_TAIL", "1") == "1",
         # round 5: the LDS-patch forward kernels leave the GroupNorm statistics of their output as per-tile records (no statistics pass over y)
         "gn_stats_in_conv": os.environ.get("MTE_GN_IN_CONV", "1") == "1",
+        # ... and, in the backward pass, the first pass of a GroupNorm's backward rides the store loop of the data-gradient launch that writes its output gradient
+        # (mte_conv2d_patch_fwd_gr / _plus1x1_gr + mte_gn_elu_bwd_red_ready).  OFF by default: same-box A/B (profiles/r05_gn_in_conv.txt) GroupNorm family
+        # -0.16 ms, LDS-patch launches +0.13 ms, step unchanged -- the pass it removes re-read dz from the Infinity Cache, and the network's structure (packs,
+        # skip concats, heads between most norms and a conv) leaves four of its 31 launches to fuse.  MTE_GN_BWD_IN_CONV=1 switches it on.
+        "gn_bwd_in_conv": os.environ.get("MTE_GN_BWD_IN_CONV", "0") == "1",
         # residual blocks: the 1x1 shortcut's FORWARD launch on the (idle) weight-gradient side stream, beside conv1 / conv2.  MTE_OVERLAP_SHORTCUT=0: in line
         # (measured same-box, round 5: 23.75 ms per step with it against 23.72 without -- the forward pass has no idle CUs for it to fill; OFF by default)
         "overlap_shortcut_fwd": os.environ.get("MTE_OVERLAP_SHORTCUT", "0") == "1"}
@@ -828,7 +833,7 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     return dw, dbias
 
 
-def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None, sunk=False, sites=None):
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None, sunk=False, sites=None, gn_src=None):
     """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations; sunk: they are views
     of the gradient sink (nothing on the backward chain reads them: the weight-gradient kernels may run on the side stream);
     fork_slot: see ForkFn -- the data gradient is accumulated into the gradient another consumer of x already produced"""
@@ -865,8 +870,21 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
                 del pend["pending"]
                 d3p, ldd3 = _pl(dy3)
                 dxp, lddx = _pl(target)
-                lib.mte_conv2d_patch_fwd_plus1x1(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
-                                                 d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1], st)
+                if (gn_src is not None and _cfg["gn_bwd_in_conv"] and fork_slot.get("parent") is None and Cp % 16 == 0
+                        and tuple(gn_src[0].shape) == (B, Cp, H, W) and gn_src[0].dtype == x.dtype):
+                    # conv1 and the shortcut are the only consumers of x = ELU(GN(v)) and this launch stores its complete gradient (see the plain launch below)
+                    v, vstats, vgamma, vbeta = gn_src
+                    vp, ldv = _pl(v)
+                    n = int(lib.mte_conv2d_patch_fwd_gr_elems(B, H, W, Cp))
+                    rec = torch.empty((n,), dtype=torch.float32, device=x.device)
+                    red = torch.empty((B, Cp, 2), dtype=torch.float32, device=x.device)
+                    lib.mte_conv2d_patch_fwd_plus1x1_gr(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
+                                                        d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1],
+                                                        vp, ldv, vstats.data_ptr(), vgamma.data_ptr(), vbeta.data_ptr(), GN_EPS, rec.data_ptr(), n, red.data_ptr(), st)
+                    _gn_red[target.data_ptr()] = (target, red)
+                else:
+                    lib.mte_conv2d_patch_fwd_plus1x1(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
+                                                     d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1], st)
                 fork_slot["buf"] = target
                 return target, dw, dbias
             _flush_pending(pend)
@@ -880,7 +898,19 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
             lib.mte_conv2d_igemm_sparse(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, _dt(x),
                                         sites.rows.data_ptr(), sites.count.data_ptr(), acc, st)
         elif _patch_ok(W, cout, Cp, kh, kw, x.dtype):
-            lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
+            if (gn_src is not None and _cfg["gn_bwd_in_conv"] and fork_slot is None and target is None and Cp % 16 == 0
+                    and tuple(gn_src[0].shape) == (B, Cp, H, W) and gn_src[0].dtype == x.dtype):
+                # x is the output of a GroupNorm + ELU layer and this launch writes its complete gradient: the first pass of that norm's backward rides the store loop
+                v, vstats, vgamma, vbeta = gn_src
+                vp, ldv = _pl(v)
+                n = int(lib.mte_conv2d_patch_fwd_gr_elems(B, H, W, Cp))
+                rec = torch.empty((n,), dtype=torch.float32, device=x.device)
+                red = torch.empty((B, Cp, 2), dtype=torch.float32, device=x.device)
+                lib.mte_conv2d_patch_fwd_gr(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc,
+                                            vp, ldv, vstats.data_ptr(), vgamma.data_ptr(), vbeta.data_ptr(), GN_EPS, rec.data_ptr(), n, red.data_ptr(), st)
+                _gn_red[dx.data_ptr()] = (dx, red)
+            else:
+                lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
         else:
             _, wb = pack.get(w, x.dtype, True)
             ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
@@ -926,10 +956,26 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, records=None):
     return z, stats
 
 
+counters = {"gn_red_ready": 0}      # how often a launch form was taken (tests assert that a path they mean to cover ran)
+_gn_red = {}        # data_ptr of a data gradient -> (that tensor, red [B][C][2]): the first pass of its GroupNorm backward came out of the launch that wrote it
+
+
+def _take_gn_red(dz):
+    """red of the GroupNorm backward whose output gradient is dz, if the data-gradient launch that produced dz left it (conv_backward(gn_src=...)).
+    The entry keeps the tensor alive, so an equal address means the same memory; shape and strides must match too (not a view of it)."""
+    e = _gn_red.pop(dz.data_ptr(), None) if _gn_red else None
+    if e is None or tuple(e[0].shape) != tuple(dz.shape) or e[0].stride() != dz.stride() or e[0].dtype != dz.dtype:
+        return None
+    return e[1]
+
+
 def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbias=False, dgamma=None, dbeta=None, dbias=None):
     B, C, H, W = y1.shape
+    red = _take_gn_red(dz) if y2 is None else None
     dz = as_act(dz, y1.dtype)
-    red = _zeros((B, C, 2), torch.float32, y1.device)
+    ready = red is not None
+    if not ready:
+        red = _zeros((B, C, 2), torch.float32, y1.device)
     d1 = new_act(B, C, H, W, y1.dtype, y1.device)
     d2 = new_act(B, C, H, W, y1.dtype, y1.device) if need_d2 else None
     # zero at entry (MTE_OPT_GN_PREZEROED covers dgamma / dbeta too: the single-pass kernels ADD per-sample parts into them)
@@ -942,8 +988,13 @@ def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbia
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     pd1, ld1 = _pl(d1)
     pd2, ld2 = _pl(d2) if d2 is not None else (0, 0)
-    lib.mte_gn_elu_bwd(pz, lz, p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
-                       pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), B, H * W, C, eps, _dt(y1), _stream())
+    if ready:                          # (round 5) only the apply pass
+        counters["gn_red_ready"] += 1
+        lib.mte_gn_elu_bwd_red_ready(pz, lz, p1, l1, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
+                                     pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), B, H * W, C, eps, _dt(y1), _stream())
+    else:
+        lib.mte_gn_elu_bwd(pz, lz, p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
+                           pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), B, H * W, C, eps, _dt(y1), _stream())
     if want_dbias:
         return d1, d2, dgamma, dbeta, dbias
     return d1, d2, dgamma, dbeta
@@ -976,6 +1027,7 @@ class ConvGnEluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, pack, out=None):
         ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
+        ctx.gn_src = getattr(x, "_mte_gn", None) if ctx.needs_input_grad[0] else None     # x is itself the output of a GroupNorm + ELU layer (see conv_backward)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
         recs = []
@@ -984,6 +1036,8 @@ class ConvGnEluFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
         ctx.bias = b
+        if out is None and any(ctx.needs_input_grad):
+            z._mte_gn = (y, stats, gamma, beta)              # for the consumer whose data gradient will write dz: the first pass of this norm's backward can ride it
         return z
 
     @staticmethod
@@ -996,7 +1050,7 @@ class ConvGnEluFn(torch.autograd.Function):
         gw, sw = _grad_dst(w)
         dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
                                                 dgamma=gg, dbeta=gb, dbias=gbias)
-        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw)
+        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw, gn_src=ctx.gn_src)
         return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None, None
 
 
@@ -1218,6 +1272,7 @@ class ConvResidualTailFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, w2, b2, gamma2, beta2, pack2, s, scale, gamma_t, beta_t, bias_s):
         ctx.fork_slot = getattr(x1, "_mte_fork_slot", None)
+        ctx.gn_src = getattr(x1, "_mte_gn", None) if ctx.needs_input_grad[0] else None      # x1 = conv1's ELU(GN(.)): see conv_backward(gn_src=...)
         wf, _ = pack2.get(w2, x1.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w2.shape
         recs = []
@@ -1246,6 +1301,8 @@ class ConvResidualTailFn(torch.autograd.Function):
         ctx.bias_s = bias_s
         ctx.bias2 = b2
         ctx.pack = pack2
+        if any(ctx.needs_input_grad):
+            z._mte_gn = (t, stats_t, gamma_t, beta_t)        # the outer norm, for the consumer whose data gradient will write dz
         return z
 
     @staticmethod
@@ -1272,7 +1329,8 @@ class ConvResidualTailFn(torch.autograd.Function):
         gw2, sw2 = _grad_dst(w2)
         dc2, _, dgamma2, dbeta2, db2 = _gn_backward(dt, c2, None, None, stats2, gamma2, beta2, GN_EPS, False, want_dbias=True,
                                                     dgamma=gg2, dbeta=gb2, dbias=gbias2)
-        dx1, dw2, _ = conv_backward(x1, dc2, w2, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw2, fork_slot=ctx.fork_slot, sunk=sw2)
+        dx1, dw2, _ = conv_backward(x1, dc2, w2, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw2, fork_slot=ctx.fork_slot, sunk=sw2,
+                                    gn_src=ctx.gn_src)
         return (dx1, _grad_ret(w2, dw2, sw2), _grad_ret(b2, db2, sbias2), _grad_ret(gamma2, dgamma2, sg2), _grad_ret(beta2, dbeta2, sb2), None,
                 ds if ctx.needs_input_grad[6] else None, None, _grad_ret(gamma_t, dgamma_t, sgt), _grad_ret(beta_t, dbeta_t, sbt),
                 _grad_ret(bias_s, dbs, sbs) if want_bs else None)
@@ -1764,6 +1822,9 @@ def fork(x):
     a, b = ForkFn.apply(x, slot)
     a._mte_fork_slot = slot
     b._mte_fork_slot = slot
+    src = getattr(x, "_mte_gn", None)
+    if src is not None:                                      # (the aliases are new tensor objects: carry the producer's norm along, see conv_backward(gn_src=...))
+        a._mte_gn = b._mte_gn = src
     return a, b
 
 
