@@ -424,3 +424,31 @@ def test_patch_forward_leaves_the_groupnorm_statistics_of_what_it_stores(shape):
     assert float((got - exact).abs().max()) <= 2e-6 * float(scale) + 2 * float((ref - exact).abs().max())
     y2, again = run(True)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("cin,cout,k,B,H,W", [(256, 256, 3, 2, 24, 64), (64, 64, 3, 1, 32, 64), (32, 32, 7, 1, 16, 64), (128, 128, 3, 1, 16, 96)])
+def test_weight_gradient_launch_width_follows_the_schedule_and_not_the_result(cin, cout, k, B, H, W):
+    """MTE_OPT_WGRAD_SHARES_CHIP (round 5): beside the data-gradient chain the MFMA weight-gradient kernels aim for half a chip of workgroups, alone for one per
+    CU.  The width only changes how many pixel splits there are: the gradients must agree to fp32 summation order, and each setting must reproduce itself bit
+    for bit (plain stores + fixed-order part sums: no atomics)."""
+    from mindtheedge_amd import kernels as K
+    K.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(cin + cout + k + W)
+    x = K.image_to_act((torch.rand(B, cin, H, W, generator=g) * 2 - 1).cuda())
+    dy = K.image_to_act((torch.rand(B, cout, H, W, generator=g) * 2 - 1).cuda())
+    w = torch.zeros(cout, cin, k, k, device="cuda")
+    out = {}
+    try:
+        for shared in (True, False, True, False):
+            K.use_wgrad_side_stream(shared)
+            dw, _ = K._conv_wgrad(x, dy, w, False, None, None)
+            torch.cuda.synchronize()
+            if shared in out:
+                assert torch.equal(out[shared], dw.cpu())
+            out[shared] = dw.cpu()
+    finally:
+        K.use_wgrad_side_stream(True)
+    ref = torch.nn.grad.conv2d_weight(x.float().double().contiguous(), (cout, cin, k, k), dy.float().double().contiguous(), padding=k // 2).cpu()
+    scale = float(ref.abs().max())
+    for shared in (True, False):
+        assert float((out[shared].double() - ref).abs().max()) < 2e-5 * scale
