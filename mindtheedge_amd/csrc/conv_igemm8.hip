@@ -59,7 +59,10 @@ __device__ __forceinline__ f32x4_t mma16(const u32x4_t& a, const u32x4_t& b, con
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-template <int BN>
+// SM: slice-major K order (ConvArgs.kslice) -- a template parameter, not a run-time flag: as a flag its bookkeeping sat in the tap-major loop as well (373 instead
+// of 267 instructions per K-tile of the 256 x 256 form, 325 instead of 213 of the 256 x 128 form, ~75 of them scalar; found at the end of round 5 by counting the
+// loop's instructions -- the loop is issue-bound, profiles/r05_wgrad9_steps.txt).  Only the development library instantiates SM = true.
+template <int BN, bool SM = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
     typedef bf16_t T;
     constexpr int BM = 256, HM = 128, HN = BN / 2;                  // tile, half-tile rows of A / B
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
     const int taps = a.KH * a.KW;
     const int cpt = a.Cin_p >> 3;                                    // 16-byte chunks per tap (a multiple of 4)
     const int ksteps_all = (taps * cpt) >> 2;
-    const bool sm = a.kslice != 0;                                   // slice-major K order (ConvArgs.kslice; cpt % 8 == 0): K-tile T = (slice T / taps, tap T % taps)
+    constexpr bool sm = SM;                                          // slice-major K order (ConvArgs.kslice; cpt % 8 == 0): K-tile T = (slice T / taps, tap T % taps)
     // tap-major: the split's range in K-steps of 32 channels; slice-major: in K-tiles of 64 (the same variables, one unit up)
     const int units_all = sm ? ksteps_all >> 1 : ksteps_all;
     const int per_split = (units_all + a.splits - 1) / a.splits;
@@ -420,15 +423,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
 }
 
 
-template <int BN> int launch8(const ConvArgs& a, hipStream_t st) {
+template <int BN, bool SM> int launch8(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * (4 * 128 * 64 + 4 * (BN / 2) * 64);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_igemm8_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)conv_igemm8_kernel<BN, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return MTE_ERR_LAUNCH;
         attr = true;
     }
     const long tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL(conv_igemm8_kernel<BN>, dim3((unsigned)(tiles * a.splits)), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((conv_igemm8_kernel<BN, SM>), dim3((unsigned)(tiles * a.splits)), dim3(512), LDS, st, a);
     return MTE_OK;
 }
 
@@ -439,7 +442,16 @@ int igemm8_launch(ConvArgs a, int bn, hipStream_t st) {
     if (a.out_f32 || a.rows || a.Cin_p % 32 != 0 || a.N % 8 != 0 || (a.splits > 1 && (!a.ws || a.N % 4 != 0))) return MTE_ERR_UNSUPPORTED;
     if (a.kslice && a.Cin_p % 64 != 0) return MTE_ERR_ARG;
     if (((a.M - 1) * a.ldx + a.Cin_p) * 2 >= 0x7ff00000L || (long)a.N * a.KH * a.KW * a.Cin_p * 2 >= 0x7ff00000L || a.M >= 0x7fffff00L) return MTE_ERR_UNSUPPORTED;
-    if (bn == 256) return launch8<256>(a, st);
-    if (bn == 128) return launch8<128>(a, st);
+#ifdef MTE_DEV
+    if (a.kslice) {                                                  // (measured slower: development library only -- tests, tools/igemm8_locality.py)
+        if (bn == 256) return launch8<256, true>(a, st);
+        if (bn == 128) return launch8<128, true>(a, st);
+        return MTE_ERR_UNSUPPORTED;
+    }
+#else
+    if (a.kslice) return MTE_ERR_UNSUPPORTED;
+#endif
+    if (bn == 256) return launch8<256, false>(a, st);
+    if (bn == 128) return launch8<128, false>(a, st);
     return MTE_ERR_UNSUPPORTED;
 }
