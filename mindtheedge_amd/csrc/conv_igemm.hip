@@ -1603,10 +1603,11 @@ extern "C" int mtei_set_gn(int which, int value);
 extern "C" int mtei_set_patch_tall(int v);
 extern "C" int mtei_set_tap_wgrad(int v);            // tap_wgrad.hip
 extern "C" int mtei_set_head_mfma(int v);
-extern int g_wgrad9, g_wgrad9_wgs;
+extern int g_wgrad9, g_wgrad9_wgs, g_igemm8_one;
 int mte_debug_set(int key, int value) {
     if (key == 26) { g_wgrad9 = value; return MTE_OK; }
     if (key == 27) { g_wgrad9_wgs = value; return MTE_OK; }
+    if (key == 28) { g_igemm8_one = value; return MTE_OK; }
     if (key == 30) return mtei_set_head_mfma(value);
     if (key == 31) return mtei_set_tap_wgrad(value);
     if (key == 0) { g_igemm_dma = value; return MTE_OK; }

@@ -62,8 +62,11 @@ __device__ __forceinline__ f32x4_t mma16(const u32x4_t& a, const u32x4_t& b, con
 // SM: slice-major K order (ConvArgs.kslice) -- a template parameter, not a run-time flag: as a flag its bookkeeping sat in the tap-major loop as well (373 instead
 // of 267 instructions per K-tile of the 256 x 256 form, 325 instead of 213 of the 256 x 128 form, ~75 of them scalar; found at the end of round 5 by counting the
 // loop's instructions -- the loop is issue-bound, profiles/r05_wgrad9_steps.txt).  Only the development library instantiates SM = true.
-template <int BN, bool SM = false>
+// ONE (tap-major only): Cin_p % 64 == 0 and the split starts on an even K-step, so the two K-halves of every K-tile sit in the same tap, 32 channels apart: one tap
+// state instead of two (the general form keeps them apart for Cin_p % 64 == 32 and for splits that start on an odd K-step).
+template <int BN, bool SM = false, bool ONE = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
+    static_assert(!(SM && ONE), "the slice-major order has its own single tap state");
     typedef bf16_t T;
     constexpr int BM = 256, HM = 128, HN = BN / 2;                  // tile, half-tile rows of A / B
     constexpr int WN = BN == 256 ? 4 : 2;                            // wave grid WM x WN (WM = 8 / WN)
@@ -179,6 +182,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
             sm_place();
             return;
         }
+        if constexpr (ONE) {                                         // both halves: tap of half 0, chunks st_cb[0] and st_cb[0] + 4 (see stageA)
+            st_s[0] += 2; st_cb[0] += 8;
+            st_live[0] = st_s[0] < s_end;                            // (an even count of K-steps: the halves live and die together)
+            if (st_cb[0] >= cpt) {                                   // wave-uniform; cpt % 8 == 0: exactly cpt
+                st_cb[0] = 0;
+                if (++st_tx[0] == a.KW) { st_tx[0] = 0; ++st_ty[0]; }
+                set_tap(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             st_s[kh] += 2; st_cb[kh] += 8;
@@ -209,8 +222,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            const unsigned vo = st_live[kh] ? voffT[kh][h] : OOB8;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + buf * BUF + (h * 2 + kh) * (HM * 64) + wv * 1024), 16, vo, st_cb[kh] * 16, 0, 0);
+            if constexpr (ONE) {
+                const unsigned vo = st_live[0] ? voffT[0][h] : OOB8;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + buf * BUF + (h * 2 + kh) * (HM * 64) + wv * 1024), 16, vo, (st_cb[0] + 4 * kh) * 16, 0, 0);
+            } else {
+                const unsigned vo = st_live[kh] ? voffT[kh][h] : OOB8;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + buf * BUF + (h * 2 + kh) * (HM * 64) + wv * 1024), 16, vo, st_cb[kh] * 16, 0, 0);
+            }
         }
 #endif
     };
@@ -220,13 +238,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
         if constexpr (BN == 256) {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
-                const bool live = sm ? b_t < s_end : b_t + kh < s_end;
+                const bool live = (sm || ONE) ? b_t < s_end : b_t + kh < s_end;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + buf * BUF + A_BYTES + (h * 2 + kh) * (HN * 64) + wv * 1024), 16,
                                                          live ? voffB[h] : OOB8, (b_sp0 + kh) * 64, 0, 0);
             }
         } else {
             const int kh = wv >> 2;
-            const bool live = sm ? b_t < s_end : b_t + kh < s_end;
+            const bool live = (sm || ONE) ? b_t < s_end : b_t + kh < s_end;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + buf * BUF + A_BYTES + (h * 2 + kh) * (HN * 64) + (wv & 3) * 1024), 16,
                                                      live ? voffB[h] : OOB8, (b_sp0 + kh) * 64, 0, 0);
         }
@@ -423,20 +441,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
 }
 
 
-template <int BN, bool SM> int launch8(const ConvArgs& a, hipStream_t st) {
+template <int BN, bool SM, bool ONE = false> int launch8(const ConvArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * (4 * 128 * 64 + 4 * (BN / 2) * 64);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_igemm8_kernel<BN, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return MTE_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)conv_igemm8_kernel<BN, SM, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return MTE_ERR_LAUNCH;
         attr = true;
     }
     const long tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm8_kernel<BN, SM>), dim3((unsigned)(tiles * a.splits)), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((conv_igemm8_kernel<BN, SM, ONE>), dim3((unsigned)(tiles * a.splits)), dim3(512), LDS, st, a);
     return MTE_OK;
 }
 
 }  // namespace
 
+int g_igemm8_one = 1;                                // development knob (mte_debug_set(28, v)): 0 = the two-state loop everywhere
 // a.splits is final (1, or the number of fp32 slabs the caller's finish kernel adds); a.kslice selects the K order (ConvArgs); the caller checks the launch.
 int igemm8_launch(ConvArgs a, int bn, hipStream_t st) {
     if (a.out_f32 || a.rows || a.Cin_p % 32 != 0 || a.N % 8 != 0 || (a.splits > 1 && (!a.ws || a.N % 4 != 0))) return MTE_ERR_UNSUPPORTED;
@@ -451,6 +470,13 @@ int igemm8_launch(ConvArgs a, int bn, hipStream_t st) {
 #else
     if (a.kslice) return MTE_ERR_UNSUPPORTED;
 #endif
+    // one tap state for both K-halves where they can never straddle a tap: 64-channel granularity and a split range that starts on an even K-step
+    const int ksteps = a.KH * a.KW * (a.Cin_p / 32);
+    const bool one = g_igemm8_one && a.Cin_p % 64 == 0 && (a.splits == 1 || ((ksteps + a.splits - 1) / a.splits) % 2 == 0);
+    if (one) {
+        if (bn == 256) return launch8<256, false, true>(a, st);
+        if (bn == 128) return launch8<128, false, true>(a, st);
+    }
     if (bn == 256) return launch8<256, false>(a, st);
     if (bn == 128) return launch8<128, false>(a, st);
     return MTE_ERR_UNSUPPORTED;

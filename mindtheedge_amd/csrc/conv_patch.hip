@@ -843,7 +843,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
     char* X = smem;
     char* Y = smem + XBYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slice = blockIdx.y;                                  // group of SL 32-channel slices
     const int tiles_x = a.W / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * a.B;
@@ -907,6 +907,24 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
     const int chb = 16 * (g & 1) + 4 * pp, pxb = 8 * (g >> 1) + q;
     const int nh = NH == 2 ? (wave & 1) : 0, slot = NH == 2 ? (wave >> 1) : wave;      // output half of this wave, its place among the half's waves
 
+    // Round 5 (end): the fragment addresses as ONE base per lane and unit, computed once, + a K-step offset that is a compile-time constant where the K-step loop
+    // is unrolled (3x3 kernels: no spills) and one scalar add where it is not.  The loop is issue-bound (profiles/r05_wgrad9_steps.txt): with the unit -> (tap,
+    // slice) division and the whole address recomputed per unit and K-step it spent 51 instructions per K-step on 6 MFMAs.
+    const char* yb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) yb[n] = Y + pxb * YRS + ((nh * NT + n) * 32 + chb) * 2;
+    const char* xb[TPW];
+    bool uok[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int u = slot + SLOTS * i;
+        uok[i] = u < UNITS;                                        // (wave-uniform)
+        const int uu = uok[i] ? u : 0, tap = uu / SL, sl = uu - tap * SL, dyy = tap / K, dxx = tap - dyy * K;
+        xb[i] = X + (dyy * PW + dxx + pxb) * XRS + sl * 64 + chb * 2;
+    }
+    constexpr bool UNROLL_KS = K == 3 && NH == 1;
+    constexpr int FULLU = UNITS / SLOTS;
+    const bool extra = uok[TPW - 1];                               // (only read where FULLU < TPW)
     if (t_begin < t_end) {
         load_tile(t_begin);
         for (int tile = t_begin; tile < t_end; ++tile) {
@@ -914,34 +932,45 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
             store_tile();
             __syncthreads();
             if (tile + 1 < t_end) load_tile(tile + 1);             // in flight (registers) while this tile is multiplied
-#pragma unroll 1
+#pragma unroll UNROLL_KS ? TH * 2 : 1
             for (int ks = 0; ks < TH * 2; ++ks) {                  // 16 pixels of one tile row per k-step
                 const int row = ks >> 1, col0 = (ks & 1) * 16;
+                const int yo = (row * TW + col0) * YRS, xo = (row * PW + col0) * XRS;
                 u32x4_t fy[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const char* base = Y + (row * TW + col0 + pxb) * YRS + ((nh * NT + n) * 32 + chb) * 2;
+                    const char* base = yb[n] + yo;
                     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
                     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * YRS));
                     uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                     fy[n] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
                 }
+                // every wave has FULLU units, the first UNITS % SLOTS waves of a half one more (wave-uniform): all fragment reads of the K-step first, then its MFMAs
+                u32x4_t fx[TPW];
+                auto read_x = [&](int i) {
+                    const char* base = xb[i] + xo;
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * XRS));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fx[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+                };
+                auto mma_x = [&](int i) {
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    const int u = slot + SLOTS * i;
-                    if (u < UNITS) {
-                        const int tap = u / SL, sl = u - tap * SL;
-                        const int dyy = tap / K, dxx = tap - dyy * K;
-                        const char* base = X + ((row + dyy) * PW + col0 + dxx + pxb) * XRS + sl * 64 + chb * 2;
-                        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
-                        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * XRS));
-                        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                        const u32x4_t fx = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+                    for (int n = 0; n < NT; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[n]),
+                                                                            __builtin_bit_cast(bf16x8_t, fx[i]), acc[i][n], 0, 0, 0);
+                };
+                if constexpr (NH == 1) {
 #pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fy[n]),
-                                                                                __builtin_bit_cast(bf16x8_t, fx), acc[i][n], 0, 0, 0);
-                    }
+                    for (int i = 0; i < FULLU; ++i) read_x(i);
+                    if constexpr (FULLU < TPW) { if (extra) read_x(FULLU); }
+#pragma unroll
+                    for (int i = 0; i < FULLU; ++i) mma_x(i);
+                    if constexpr (FULLU < TPW) { if (extra) mma_x(FULLU); }
+                } else {                                           // (the wide variant is at its register limit: one unit's fragment at a time)
+#pragma unroll
+                    for (int i = 0; i < FULLU; ++i) { read_x(i); mma_x(i); }
+                    if constexpr (FULLU < TPW) { if (extra) { read_x(FULLU); mma_x(FULLU); } }
                 }
             }
         }
