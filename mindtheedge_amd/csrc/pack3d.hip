@@ -1562,6 +1562,14 @@ __global__ __launch_bounds__(512) void conv3d_bwd_weight_mfma_kernel(P3LArgs a) 
     const int tapoff = (kh * PW + kw) * LDP(D) + 8 * half;                      // elements, relative to the item's pixel / depth pair
     const bool up1 = kd >= 1;
     const unsigned sh = kd == 1 ? 0u : 2u;
+    // constant operand lanes read constants: column 27 (the all-ones column that yields db3) from a run of bf16 ones, columns 28..31 and the A rows 4..31 from a
+    // run of zeros -- one address select per fragment instead of eight value selects (round 5, end: the loop is instruction-bound)
+    // (the runs are long enough for the whole round: the fragment of depth pair u sits u * 32 bytes further, as an immediate offset)
+    __shared__ __attribute__((aligned(16))) unsigned s_const[208];               // [0, 80): 0x3f803f80, [80, 208): 0
+    if (threadIdx.x < 208) s_const[threadIdx.x] = threadIdx.x < 80 ? 0x3f803f80u : 0u;
+    const bf16_t* const cpb = (const bf16_t*)(s_const + (r == 27 ? 4 : 84));    // (a 16-byte chunk with a word either side inside its run, + 7 x 32 bytes)
+    const char* const czero = (const char*)(s_const + 80);
+    const bool clane = r >= 27;
     if (threadIdx.x == 0) *(u32x4_t*)smem_ = u32x4_t{0u, 0u, 0u, 0u};
     for (int p = threadIdx.x; p < npix; p += blockDim.x) *(u32x4_t*)(tile + p * LDP(D) + D) = u32x4_t{0u, 0u, 0u, 0u};
     f32x16_t acc;
@@ -1593,8 +1601,11 @@ __global__ __launch_bounds__(512) void conv3d_bwd_weight_mfma_kernel(P3LArgs a) 
         const int rpp = (dpairs + U - 1) / U;                    // rounds per pixel
         const int npx = (a.TH * a.TW - wave + nwaves - 1) / nwaves;
         const int nrounds = npx * rpp;
-        auto fetch = [&](int k) -> u32x4_t {                     // this lane's 16 bytes of round k (zeros outside the image / depth range)
-            const int j = k / rpp, dp0 = (k - j * rpp) * U;
+        int fj = 0, fdp = 0;                                      // the fetcher's own position (it runs one round ahead): advanced by every call
+        auto fetch = [&](int) -> u32x4_t {                       // this lane's 16 bytes of the next round (zeros outside the image / depth range)
+            const int j = fj, dp0 = fdp;
+            fdp += U;
+            if (fdp >= rpp * U) { fdp = 0; ++fj; }
             const int p = wave + j * nwaves;
             const int pw = p & (a.TW - 1), ph = p >> a.tshift;   // (TW is a power of two in every tile table)
             const int h = h0 + ph, w = w0 + pw;
@@ -1613,39 +1624,41 @@ __global__ __launch_bounds__(512) void conv3d_bwd_weight_mfma_kernel(P3LArgs a) 
             return v;
         };
         u32x4_t cur = nrounds > 0 ? fetch(0) : u32x4_t{0u, 0u, 0u, 0u};
+        // (round 5, end: the round's pixel and depth-pair offset are carried along instead of being divided out of k twice per round -- with fetch(k + 1) that was
+        //  ~140 scalar instructions per round of 8 MFMAs; the loop is instruction-bound: 45-58 instructions per MFMA before, see profiles/README.md round 5)
+        int rj = 0, rdp = 0;                                      // k = rj * rpp + rdp / U
 #pragma unroll 1
         for (int k = 0; k < nrounds; ++k) {
             u32x4_t nxt = {0u, 0u, 0u, 0u};
             if (k + 1 < nrounds) nxt = fetch(k + 1);
-            const int j = k / rpp, dp0 = (k - j * rpp) * U;
+            const int j = rj, dp0 = rdp;
+            rdp += U;
+            if (rdp >= rpp * U) { rdp = 0; ++rj; }
             const int p = wave + j * nwaves;
             const int pw = p & (a.TW - 1), ph = p >> a.tshift;
             if (h0 + ph < H2 && w0 + pw < W2) {                  // wave-uniform
                 char* sc = scratch + (wave * 2 + (k & 1)) * 1024;
                 *(u32x4_t*)(sc + lane * 16) = cur;
-                const bf16_t* pb0 = tile + (ph * PW + pw) * LDP(D) + tapoff + dp0 * 16;
+                // (kd = 0 lanes start one word early: every lane then reads the five consecutive words w0 .. w4 its shifted fragment is cut from)
+                const unsigned* pw0 = (const unsigned*)(clane ? cpb : tile + (ph * PW + pw) * LDP(D) + tapoff + dp0 * 16) - (up1 ? 0 : 1);
+                const char* ga = r < 4 ? (UNPACK ? sc + r * 256 + half * 4 : sc + (r * 16 + half) * 16) : czero;     // this lane's part of the gradient block (rows >= 4: zeros)
                 const int nd = min(U, dpairs - dp0);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (u >= nd) break;                          // wave-uniform
-                    u32x4_t fa = {0u, 0u, 0u, 0u};
-                    if (r < 4) {
-                        if constexpr (UNPACK) {
-                            // depths d0 .. d0+7 of feature r: channels (d0 >> 2, + 1) at the four sub-pixel positions = word 2(u&1) + half of part u >> 1
-                            const char* g = sc + (r * 16 + (u >> 1)) * 16 + (2 * (u & 1) + half) * 4;
-                            const unsigned u0 = *(const unsigned*)g, u1 = *(const unsigned*)(g + 64), u2 = *(const unsigned*)(g + 128), u3 = *(const unsigned*)(g + 192);
-                            fa = u32x4_t{(u0 & 0xffffu) | (u1 << 16), (u2 & 0xffffu) | (u3 << 16), (u0 >> 16) | (u1 & 0xffff0000u), (u2 >> 16) | (u3 & 0xffff0000u)};
-                        } else {
-                            fa = *(const u32x4_t*)(sc + (r * 16 + 2 * u + half) * 16);
-                        }
+                    u32x4_t fa;
+                    if constexpr (UNPACK) {
+                        // depths d0 .. d0+7 of feature r: channels (d0 >> 2, + 1) at the four sub-pixel positions = word 2(u&1) + half of part u >> 1
+                        const char* g = ga + (u >> 1) * 16 + 2 * (u & 1) * 4;
+                        const unsigned u0 = *(const unsigned*)g, u1 = *(const unsigned*)(g + 64), u2 = *(const unsigned*)(g + 128), u3 = *(const unsigned*)(g + 192);
+                        fa = u32x4_t{(u0 & 0xffffu) | (u1 << 16), (u2 & 0xffffu) | (u3 << 16), (u0 >> 16) | (u1 & 0xffff0000u), (u2 >> 16) | (u3 & 0xffff0000u)};
+                    } else {
+                        fa = *(const u32x4_t*)(ga + u * 32);
                     }
-                    const bf16_t* pb = pb0 + u * 16;
-                    const u32x4_t c = *(const u32x4_t*)pb;
-                    const unsigned x0 = *(const unsigned*)(pb - 2), x5 = *(const unsigned*)(pb + 8);
-                    const unsigned y0 = up1 ? c[0] : x0, y1 = up1 ? c[1] : c[0], y2 = up1 ? c[2] : c[1], y3 = up1 ? c[3] : c[2], y4 = up1 ? x5 : c[3];
+                    const unsigned* wq = pw0 + u * 8;
+                    const unsigned y0 = wq[0], y1 = wq[1], y2 = wq[2], y3 = wq[3], y4 = wq[4];      // (word-aligned only: ds_read2_b32 pairs)
                     u32x4_t fb = {__builtin_amdgcn_alignbyte(y1, y0, sh), __builtin_amdgcn_alignbyte(y2, y1, sh),
                                   __builtin_amdgcn_alignbyte(y3, y2, sh), __builtin_amdgcn_alignbyte(y4, y3, sh)};
-                    if (r >= 27) fb = r == 27 ? u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : u32x4_t{0u, 0u, 0u, 0u};
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb), acc, 0, 0, 0);
                 }
             }
