@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         for (int d = 0; d < PD; ++d)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) bq[d][kk] = wsl[((d * 2 + kk) * NT + nsel) * 64];
-#pragma unroll 1
+#pragma unroll 1                                                   // (round 5, end: unrolled over the 3x3 taps this loop needs 254 instead of 167 VGPRs -- two workgroups per CU instead of
+                                                                   //  three -- and the 64 -> 64 @192x640 forward went from 92 to 107 us: latency-bound, not issue-bound)
         for (int t0 = 0; t0 < TAPS; t0 += PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
@@ -932,7 +933,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
             store_tile();
             __syncthreads();
             if (tile + 1 < t_end) load_tile(tile + 1);             // in flight (registers) while this tile is multiplied
-#pragma unroll UNROLL_KS ? TH * 2 : 1
+#pragma unroll UNROLL_KS ? TH * 2 : 1                              // (5x5 / 7x7: unrolled by two they measured 2-4 % SLOWER -- 1000+ TFLOP/s kernels, not issue-bound)
             for (int ks = 0; ks < TH * 2; ++ks) {                  // 16 pixels of one tile row per k-step
                 const int row = ks >> 1, col0 = (ks & 1) * 16;
                 const int yo = (row * TW + col0) * YRS, xo = (row * PW + col0) * XRS;
