@@ -1002,8 +1002,9 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
 // step times with the two-stream schedule, profiles/r05_side_queue_width.txt):
 // 512 -> 256 groups: 23.25 -> 23.16 ms per step (192: the same, 128: 23.60); the wide (65..128-output) variant 256 -> 128: a further -0.08 ms.  Fewer,
 // longer workgroups leave CUs to the data-gradient chain and halve the slabs the unpack pass adds up.
+// (end of round 5, after the kernel's instruction diet: 256 -> 22.75 ms per step, 192 -> 22.67, 160 -> 22.65, 128 -> 22.95 on one box; 23.24 / 23.13 / -- on another: 192)
 #ifndef MTE_PATCH_WGRAD_WGS
-#define MTE_PATCH_WGRAD_WGS 256
+#define MTE_PATCH_WGRAD_WGS 192
 #endif
 #ifndef MTE_PATCH_WGRAD_WIDE_WGS
 #define MTE_PATCH_WGRAD_WIDE_WGS 128
