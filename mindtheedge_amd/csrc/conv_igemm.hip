@@ -1252,7 +1252,9 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st, int parts_cap, int* parts_out)
     const bool fl = a.W % 32 == 0 || a.W >= 160;
     const long nblk = fl ? (long)a.B * a.H * ((a.W + 31) / 32) : (a.M + 31) / 32;
     const long base_wgs = (long)a.tiles_n * a.tiles_c * taps;
-    const long want = (long)g_wgrad_wgs * 256 / NTHR;           // ~4 workgroups of 256 threads (or 1 of 1024) per CU
+    // ~4 workgroups of 256 threads (or 1 of 1024) per CU; three quarters of that beside the data-gradient chain (MTE_OPT_WGRAD_SHARES_CHIP; end of round 5,
+    // same box, ms per step: 512 -> 22.85, 384 -> 22.70, 256 -> 22.79, 768 -> 22.77 -- profiles/r05_side_queue_width.txt)
+    const long want = (long)(g_mte_wgrad_shared ? g_wgrad_wgs * 3 / 4 : g_wgrad_wgs) * 256 / NTHR;
     long splits = (want + base_wgs - 1) / base_wgs;
     const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
     if (splits > max_splits) splits = max_splits;
