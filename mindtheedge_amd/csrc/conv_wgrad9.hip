@@ -286,8 +286,8 @@ int g_cus9 = 0;
 
 int g_wgrad9 = 1;                                    // development knob (mte_debug_set(26, v)): 0 = the generic per-tap kernel everywhere
 // Workgroups aimed for per launch when the caller runs the weight gradients BESIDE the data-gradient chain (MTE_OPT_WGRAD_SHARES_CHIP): HALF the chip.
-// With one workgroup per CU this kernel's 96 KB of LDS and 512 threads take every CU away from the main queue's MFMA kernels for its whole length and it
-// writes twice the slabs.  Same-box step times (profiles/r05_side_queue_width.txt): 256 -> 23.59 ms, 192 -> 23.50, 128 -> 23.26, 96 -> 23.35, 64 -> 23.79.
+// With one workgroup per CU this kernel's 96 KB of LDS, 512 threads and whole register file take every CU away from the main queue's kernels for its whole length
+// and it writes twice the slabs (what the main queue loses is less the CUs than the clock: profiles/r05_overlap_probe.txt).  Same-box step times (profiles/r05_side_queue_width.txt): 256 -> 23.59 ms, 192 -> 23.50, 128 -> 23.26, 96 -> 23.35, 64 -> 23.79.
 // Alone on the chip (option off: serial profiling runs, a binding without a second stream) it takes one workgroup per CU.
 #ifndef MTE_W9_WGS
 #define MTE_W9_WGS 128
@@ -324,7 +324,7 @@ __attribute__((visibility("hidden"))) int wgrad9_launch(const void* x, long ldx,
     a.tiles_c = Cin_p / 64;
     a.base = (N / 128) * a.tiles_c;
     a.units = (int)(M / 32);
-    // one workgroup per CU (72 KB of LDS, 512 threads): pixel splits so that tiles x splits ~ the CU count, at least 12 K-steps each
+    // one workgroup per CU (96 KB of LDS, 512 threads): pixel splits so that tiles x splits ~ the CU count, at least 12 K-steps each
     const int target = (g_mte_wgrad_shared && g_wgrad9_wgs > 0) ? g_wgrad9_wgs : g_cus9;
     long splits = (target + a.base / 2) / a.base;
     if (splits < 1) splits = 1;
