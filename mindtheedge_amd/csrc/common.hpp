@@ -90,6 +90,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// In-loop clock of the MFMA loops (diagnostic build only: -DMTE_CLOCK, tools/inloop_clock.py; no stamp executes in the product or the development library).
+// MI355X_MICROARCH.md 'DVFS give-back' item 6: shader clock = delta s_memtime / delta s_memrealtime x 100 MHz, stamped ONCE around the main loop; thread 0 of a
+// workgroup stores the two deltas into a buffer of the translation unit that no kernel reads.
+#ifdef MTE_CLOCK
+#define MTE_CLOCK_DEFINE(TAG)                                                                                                          \
+    static __device__ unsigned long long g_clk_##TAG[16384 * 2];                                                                       \
+    extern "C" int mtei_clk_##TAG(unsigned long long* host, int n) {                                                                   \
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk_##TAG), sizeof(unsigned long long) * n) != hipSuccess) return -1;               \
+        void* p_ = nullptr;                                          /* read and clear: a later launch with fewer workgroups leaves no stale entries */ \
+        if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_clk_##TAG)) != hipSuccess) return -1;                                                \
+        return hipMemset(p_, 0, sizeof(g_clk_##TAG)) == hipSuccess ? 0 : -1;                                                           \
+    }
+#define MTE_CLOCK_BEGIN()                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                 \
+    const unsigned long long clk_c0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime();                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define MTE_CLOCK_END(TAG)                                                                                                             \
+    {                                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        const unsigned long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 16384) {                                            \
+            g_clk_##TAG[2 * blockIdx.x] = c1_ - clk_c0_;                                                                               \
+            g_clk_##TAG[2 * blockIdx.x + 1] = r1_ - clk_r0_;                                                                           \
+        }                                                                                                                              \
+    }
+#else
+#define MTE_CLOCK_DEFINE(TAG)
+#define MTE_CLOCK_BEGIN()
+#define MTE_CLOCK_END(TAG)
+#endif
+
 // mte_set_option(MTE_OPT_GN_PREZEROED, 1): the caller hands over GroupNorm statistics / reduction / bias-gradient buffers
 // that are already zero (carved from one arena it clears with a single memset), so the library skips its ~140 tiny
 // per-layer hipMemsetAsync launches per training step.  Defined in norm_act.hip.

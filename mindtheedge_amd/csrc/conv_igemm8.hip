@@ -51,6 +51,8 @@ extern "C" int mtei_igemm8_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+MTE_CLOCK_DEFINE(igemm8)
+
 namespace {
 
 constexpr unsigned OOB8 = 0xfffffff0u;
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
 #else
 #define ST8(ACC)
 #endif
+    MTE_CLOCK_BEGIN()
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         const char* pb = smem + buf * BUF;
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(ConvArgs a) {
         MTE8_BARRIER();
         ST8(15)
     }
+    MTE_CLOCK_END(igemm8)
     if (grp == 0) MTE8_BARRIER();
 #ifdef MTE_STAMPS
     if (lane == 0 && blockIdx.x < 512) {

@@ -36,6 +36,8 @@ extern "C" int mtei_patch_stamps(unsigned long long* host, int n) {
 #define PATCH_STAMP()
 #endif
 
+MTE_CLOCK_DEFINE(patch)
+
 namespace {
 
 constexpr int TH = 8, TW = 32;                     // output tile (pixels)
@@ -233,7 +235,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     // of 78 KB of LDS per workgroup): the kernel holds 196-224 VGPRs, so two workgroups per CU is all it gets either way, and forcing
     // three or four waves per SIMD spills (72 -> 32 at 384x1280: 400 -> 694 us)
     constexpr int NBUF = (TALL && K > 3) ? 1 : 2;
-    constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES) ? NBUF * PBYTES : OBYTES);
+    // (+ 128: the 16 (mean, rstd) pairs of the gr epilogue live BEHIND the staged tile, inside the dead patch buffers -- as a __shared__ array of their own
+    //  they pushed the 3x3 tall second form from 81,920 to 82,048 bytes, i.e. from two workgroups per CU to one: round 5's regression on the 64 -> 32 layers)
+    constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES + 128) ? NBUF * PBYTES : OBYTES + 128);
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     __syncthreads();
     PATCH_STAMP();
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane;               // fragment block = 64 lanes x 16 B
+    MTE_CLOCK_BEGIN()
     for (int s = 0; s < nslices; ++s) {
         const char* P = smem + (s & 1) * PBYTES;
         if (s + 1 < nslices) load_patch(s + 1);
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         __syncthreads();
         PATCH_STAMP();
     }
+    MTE_CLOCK_END(patch)
     // ---- epilogue: stage the tile as bf16 [pixel][N] in LDS, then 16-byte coalesced stores
     constexpr int NB = NT * 64;                                    // bytes per pixel
     {
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
                 *(bf16_t*)(smem + ((mrow0 + m) * TW + px) * NB + ch * 2) = f2bf(acc[m][e] + bv);
             }
     }
-    __shared__ float s_gmr[32];
+    float* s_gmr = (float*)(smem + OBYTES);                       // (dead patch bytes behind the staged tile)
     patch_gr_group_stats(a, b, tid, s_gmr);
     __syncthreads();
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
@@ -442,10 +448,16 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
 //     the tile is staged with 16 ds_write_b64 per thread instead of 64 two-byte writes that all fell on two LDS banks.
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
-template <int K, int NT, bool TALL, bool R1 = false, bool ACC = false, bool EXTRA = false>
+// M16 (round 6): the same tile on v_mfma_f32_16x16x32_bf16 -- per tap and slice 4 MM instructions of 16 cycles instead of 2 MM of 32: equal matrix-pipe cycles,
+// but the chip HOLDS a higher clock on that shape (MI355X_MICROARCH.md 'DVFS give-back' item 7; measured here: profiles/r06_inloop_clock.txt).  A = weights
+// (16 channels x one whole 32-channel slice: lane (row, g) gathers its 16 bytes from the two fragment blocks of the 32x32x16 pack, K order = channel order),
+// B = 16 pixels (lane (column, g) reads chunk g of pixel column: one ds_read_b128; the patch image then takes the swizzle slot = chunk ^ 2 ((p >> 2) & 1),
+// conflict-free for that read at every alignment -- exhaustive check in tests/test_patch_swizzle.py), D: lane holds 4 consecutive channels of one pixel.
+template <int K, int NT, bool TALL, bool R1 = false, bool ACC = false, bool EXTRA = false, bool M16 = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
     static_assert(!R1 || K == 3, "the rank-1 term is a 3x3 stencil");
+    static_assert(!M16 || (!R1 && !EXTRA && K > 3), "the 16x16x32 form exists for the 5x5 / 7x7 loops");
     constexpr int TH = TALL ? 16 : 8;
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int PCH = PH * PW * 4;                               // 16-B chunks of one patch slice
@@ -454,8 +466,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     constexpr int NB = NT * 64, OSTR = NB + 16;                    // bytes per staged pixel, padded stride (b64 writes of 16 pixels: 2-way)
     constexpr int OBYTES = TH * TW * OSTR;
     constexpr int NBUF = (TALL && K > 3) ? 1 : 2;                  // tall 5x5 / 7x7 tiles: single-slice layers only
-    constexpr int LDS_BYTES = NBUF * PBYTES > OBYTES ? NBUF * PBYTES : OBYTES;
+    constexpr int LDS_BYTES = NBUF * PBYTES > OBYTES + 128 ? NBUF * PBYTES : OBYTES + 128;      // (+ 128: see the first form)
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    static_assert(!(K == 3 && TALL) || LDS_BYTES <= 81920, "the tall 3x3 form must keep two workgroups per CU");
     typedef __attribute__((address_space(3))) void* lptr_t;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
         const int idc = (i * 4 + wave) * 64 + lane;
-        const int p = idc >> 2, kc = (idc & 3) ^ ((p >> 2) & 3);
+        const int p = idc >> 2, kc = (idc & 3) ^ (M16 ? ((p >> 1) & 2) : ((p >> 2) & 3));
         const int py = p / PW, px = p - py * PW;
         const int iy = y0 + py - PAD, ix = x0 + px - PAD;
         const bool ok = idc < PCH && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -504,11 +517,19 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     constexpr int MM = (NT == 2 || TALL) ? 4 : 2;                  // pixel rows per wave
     const int nsel = NT == 2 ? wave >> 1 : 0;
     const int mrow0 = NT == 2 ? (wave & 1) * 4 : wave * MM;
-    f32x16_t acc[MM];
+    f32x16_t acc[M16 ? 1 : MM];
 #pragma unroll
-    for (int m = 0; m < MM; ++m)
+    for (int m = 0; m < (M16 ? 1 : MM); ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    const int c16 = lane & 15, g16 = lane >> 4;                    // M16: pixel column / channel row of the lane, its K group (and its four output channels 4 g16 ..)
+    f32x4_t acc16[M16 ? MM : 1][2][2];                              // [pixel row][16-channel half][16-pixel half]
+#pragma unroll
+    for (int m = 0; m < (M16 ? MM : 1); ++m)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) acc16[m][c][ph] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // ---- rank-1 term (R1): one more input channel given as a LOW-resolution map (the decoder's up-sampled inverse depth), as ONE 16-deep MFMA step that
     // initialises the accumulators.  The 3x3 window of the up-sampled map around a pixel covers only 2 x 2 pixels of the low-resolution map: for an even row
@@ -576,7 +597,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     // weight fragments: block (slice, tap, kk, nt) of 64 lanes x 16 B, straight from L2
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane + nsel * 64;
     const unsigned wlane = (unsigned)(lane + nsel * 64) * 16u;      // this lane's byte offset inside a fragment block
-    auto wfrag = [&](int s, int t, int kk) { return wl[((long)(s * TAPS + t) * 2 + kk) * (NT * 64)]; };
+    // M16: second index = 16-channel half c; lane (row, g) takes channel nsel * 32 + 16 c + row, K = 8 g .. 8 g + 7 of the slice = lane (g & 1) * 32 + 16 c + row of block kk = g >> 1
+    const unsigned w16off = (unsigned)((g16 >> 1) * NT * 1024 + nsel * 1024 + ((g16 & 1) * 32 + c16) * 16);
+    auto wfrag = [&](int s, int t, int kk) {
+        if constexpr (M16) return *(const u32x4_t*)((const char*)a.wp + (long)(s * TAPS + t) * (2 * NT * 1024) + w16off + kk * 256);
+        else return wl[((long)(s * TAPS + t) * 2 + kk) * (NT * 64)];
+    };
     // ring of fragments in VISITING order (tap column dx outer, tap row dy inner): the 3x3 / 1x1 kernels hold a whole slice (<= 72 VGPRs, all
     // requested before the next slice's DMA), the 5x5 / 7x7 kernels one tap column (slot dy, refilled with the next column right after use)
     constexpr bool WHOLE = TAPS <= 9;
@@ -591,6 +617,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WHOLE ? 0 : 2 * K) : "memory");     // the patch of slice 0 (the ring may still be in flight)
     __syncthreads();
     PATCH_STAMP();
+    MTE_CLOCK_BEGIN()
     rank1_step();
     if constexpr (EXTRA) {                                         // second K source (see extra_load; this form's MFMA takes the weights first)
         const int n2 = (a.C2 + 31) >> 5;
@@ -613,23 +640,36 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     f32x4_t bv4[4];
     auto load_bias = [&]() {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = nsel * 32 + 8 * g + 4 * h;             // (N % 8 == 0: a group of four is inside or outside as a whole)
+        for (int g = 0; g < (M16 ? 2 : 4); ++g) {
+            const int ch0 = M16 ? nsel * 32 + 16 * g + 4 * g16 : nsel * 32 + 8 * g + 4 * h;             // (N % 8 == 0: a group of four is inside or outside as a whole)
             const f32x4_t v = *(const f32x4_t*)((a.bias ? a.bias : (const float*)a.wp) + (ch0 < a.N ? ch0 : 0));
             bv4[g] = (a.bias && ch0 < a.N) ? v : f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     };
     // pixel row J of this wave's patch rows (tap column DX) -> window slot
 #define PF2_LDROW(J, SLOT, DX)                                                                                         \
-    {                                                                                                                  \
+    if constexpr (M16) {                                                                                               \
+        _Pragma("unroll") for (int ph = 0; ph < 2; ++ph) {                                                             \
+            const int p_ = (mrow0 + (J)) * PW + (DX) + 16 * ph + c16;                                                  \
+            win[SLOT][ph] = *(const u32x4_t*)(P + p_ * 64 + ((g16 ^ ((p_ >> 1) & 2)) << 4));                           \
+        }                                                                                                              \
+    } else {                                                                                                           \
         const int p_ = (mrow0 + (J)) * PW + (DX) + r;                                                                  \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) win[SLOT][kk] = *(const u32x4_t*)(P + swz_off(p_, 2 * kk + h)); \
     }
 #define PF2_MFMAS(DY, BQ)                                                                                              \
-    _Pragma("unroll") for (int m = 0; m < MM; ++m)                                                                     \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                               \
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (BQ)[kk]),                   \
-                                                             __builtin_bit_cast(bf16x8_t, win[((DY) + m) % WR][kk]), acc[m], 0, 0, 0);
+    if constexpr (M16) {                                                                                               \
+        _Pragma("unroll") for (int m = 0; m < MM; ++m)                                                                 \
+            _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                              \
+                _Pragma("unroll") for (int ph = 0; ph < 2; ++ph)                                                       \
+                    acc16[m][c][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, (BQ)[c]),   \
+                                          __builtin_bit_cast(bf16x8_t, win[((DY) + m) % WR][ph]), acc16[m][c][ph], 0, 0, 0); \
+    } else {                                                                                                           \
+        _Pragma("unroll") for (int m = 0; m < MM; ++m)                                                                 \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (BQ)[kk]),               \
+                                                                 __builtin_bit_cast(bf16x8_t, win[((DY) + m) % WR][kk]), acc[m], 0, 0, 0); \
+    }
     if constexpr (WHOLE) {
         // The compiler does not count LDS-DMA in its s_waitcnt bookkeeping, and beside a DMA it drains vmcnt(0) in front of every use of an
         // ordinary load: the fragment loads of these kernels are hidden from it in asm statements and waited for by hand.  Fragment pair Q of
@@ -707,9 +747,23 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     }
 #undef PF2_MFMAS
 #undef PF2_LDROW
+    MTE_CLOCK_END(patch)
 
     // ---- epilogue: lane (r, h) holds, for pixel r of row m, channels nsel*32 + 8g + 4h + (0..3) in acc[m][4g .. 4g+3]
-    {
+    // (M16: lane (c16, g16) holds, for pixel 16 ph + c16 of row m, channels nsel*32 + 16 c + 4 g16 + (0..3) in acc16[m][c][ph])
+    if constexpr (M16) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    u32x2_t v;
+                    v[0] = pack2bf(acc16[m][c][ph][0] + bv4[c][0], acc16[m][c][ph][1] + bv4[c][1]);
+                    v[1] = pack2bf(acc16[m][c][ph][2] + bv4[c][2], acc16[m][c][ph][3] + bv4[c][3]);
+                    *(u32x2_t*)(smem + ((mrow0 + m) * TW + 16 * ph + c16) * OSTR + (nsel * 32 + 16 * c + 4 * g16) * 2) = v;
+                }
+    } else {
 #pragma unroll
         for (int m = 0; m < MM; ++m)
 #pragma unroll
@@ -720,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
                 *(u32x2_t*)(smem + ((mrow0 + m) * TW + r) * OSTR + (nsel * 32 + 8 * g + 4 * h) * 2) = v;
             }
     }
-    __shared__ float s_gmr[32];
+    float* s_gmr = (float*)(smem + OBYTES);                       // (dead patch bytes behind the staged tile)
     patch_gr_group_stats(a, b, tid, s_gmr);
     __syncthreads();
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
@@ -926,6 +980,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
     constexpr bool UNROLL_KS = K == 3 && NH == 1;
     constexpr int FULLU = UNITS / SLOTS;
     const bool extra = uok[TPW - 1];                               // (only read where FULLU < TPW)
+    MTE_CLOCK_BEGIN()
     if (t_begin < t_end) {
         load_tile(t_begin);
         for (int tile = t_begin; tile < t_end; ++tile) {
@@ -976,6 +1031,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_wgrad_kernel(PatchWgradArg
             }
         }
     }
+    MTE_CLOCK_END(patch)
     // D[row = cout][col = cin]: col = lane&31 -> contiguous fp32 in the stage
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -1019,6 +1075,8 @@ int g_patch_fwd2 = 1;
 #endif
 //                               // development knob (mte_debug_set(11, 400 + v)): 0 = the first form of the forward kernel
 
+int g_patch_m16 = 1;                                 // development knob (mte_debug_set(11, 500 + v)): 0 = the 5x5 / 7x7 second form on v_mfma_f32_32x32x16_bf16 (round 5)
+
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int* tile_rows = nullptr) {
     // the second form addresses the input through a buffer descriptor (< 2 GiB)
     // Same-box A/B over the network's shapes (tools/conv_shape_bench.py): 7x7 -12..-15 %, 5x5 -8..-12 %, 3x3 with 32 outputs -4..-12 %, 3x3
@@ -1030,6 +1088,13 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int*
         if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
             if (tile_rows) *tile_rows = 16;
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
+            if constexpr (K >= 5) {
+                if (v2 && g_patch_m16) {
+                    if (a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+                    return mte_check_launch();
+                }
+            }
             if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
@@ -1039,6 +1104,13 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int*
     }
     if (tile_rows) *tile_rows = TH;
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
+    if constexpr (K >= 5) {
+        if (v2 && g_patch_m16) {
+            if (a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            return mte_check_launch();
+        }
+    }
     if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
@@ -1134,7 +1206,7 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 }  // namespace
 
 #ifdef MTE_DEV
-extern "C" int mtei_set_patch_tall(int v) { if (v >= 400 && v < 410) { g_patch_fwd2 = v - 400; return MTE_OK; } if (v >= 300 && v < 310) { g_patch_wgrad_wide = v - 300; return MTE_OK; } if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
+extern "C" int mtei_set_patch_tall(int v) { if (v >= 500 && v < 510) { g_patch_m16 = v - 500; return MTE_OK; } if (v >= 400 && v < 410) { g_patch_fwd2 = v - 400; return MTE_OK; } if (v >= 300 && v < 310) { g_patch_wgrad_wide = v - 300; return MTE_OK; } if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
 #endif
 
 extern "C" {

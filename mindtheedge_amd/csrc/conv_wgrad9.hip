@@ -46,6 +46,8 @@ struct Wgrad9Args {
     int units, units_per_split;         // K-steps of 32 pixels: all, per pixel split
 };
 
+MTE_CLOCK_DEFINE(wgrad9)
+
 namespace {
 
 constexpr unsigned OOB9 = 0xfffffff0u;
@@ -264,7 +266,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     // (no early exit from the unrolled body: with exits between the four K-steps the compiler no longer keeps the 144 accumulator registers in place
     //  -- 441 spilled registers; a split whose K-step count is not a multiple of four runs up to three K-steps on zero-filled slots instead, and the
     //  launcher deals multiples of four)
+    MTE_CLOCK_BEGIN()
     for (int it = 0; it < nst; it += 4) { kstep(W9_C(0)); kstep(W9_C(1)); kstep(W9_C(2)); kstep(W9_C(3)); }
+    MTE_CLOCK_END(wgrad9)
     if (wm == 0) W9_BARRIER()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero-filling pieces past the end)
 

@@ -29,6 +29,8 @@ SHAPES = [  # cin, cout, k, B, H, W
     (128, 128, 3, 2, 16, 64), (200, 128, 3, 1, 12, 32), (64, 128, 3, 2, 8, 64), (256, 128, 3, 1, 13, 32), (72, 96, 3, 2, 9, 32), (64, 72, 3, 1, 6, 96),
     # round 3: the second form of the LDS-patch forward -- tall (16-row) tiles with a ragged last tile, one / two / three slices, 5x5 and 7x7
     (32, 32, 3, 1, 24, 64), (72, 32, 3, 1, 20, 32), (32, 32, 5, 1, 40, 64), (40, 32, 5, 1, 20, 32), (32, 24, 7, 1, 21, 32), (136, 64, 3, 1, 11, 64),
+    # round 6: the 5x5 / 7x7 second form on v_mfma_f32_16x16x32_bf16 -- two 32-channel output tiles, several slices, ragged rows, channel tails
+    (256, 64, 5, 1, 12, 64), (48, 56, 5, 2, 9, 32), (128, 32, 7, 1, 18, 32),
 ]
 
 

@@ -49,7 +49,7 @@ for shp in shapes:
     arr = (ctypes.c_ulonglong * n)()
     assert raw.mtei_patch_stamps(arr, n) == 0
     ns = (cp + 31) // 32
-    nst = 2 + 2 * ns + 1
+    nst = min(2 + 2 * ns + 1, 16)                          # (the kernel keeps 16 stamps per workgroup: layers with more than six slices show the first ones)
     tall = cout <= 32 and (cp <= 32 or k <= 3) and H >= 16
     tiles = (W // 32) * ((H + 15) // 16 if tall else (H + 7) // 8) * B
     nb = min(tiles, 16384)
@@ -58,6 +58,6 @@ for shp in shapes:
     t0 = a[:, 0].min()
     print("%d -> %d k%d @%dx%d ld %d (%s form): %d workgroups, launch span %.1f us; phases of a workgroup, median ns:" % (
         cin, cout, k, H, W, ld, "first" if first == "v1" else "dispatched", nb, (a[:, -1].max() - t0) * 0.01))
-    names = ["prologue"] + sum([["taps s%d" % s, "wait+sync s%d" % s] for s in range(ns)], []) + ["epilogue"]
+    names = (["prologue"] + sum([["taps s%d" % s, "wait+sync s%d" % s] for s in range(ns)], []) + ["epilogue"])[:nst - 1]
     print("   " + "  ".join("%s %.0f" % (nm, np.median(d[:, i])) for i, nm in enumerate(names)))
     print("   workgroup total median %.0f ns" % (np.median(a[:, -1] - a[:, 0]) * 10))
