@@ -15,10 +15,16 @@ def infer_depth(model_wrapper, image):
     """image: fp32 [B,3,H,W] on the GPU, H and W multiples of 32 -> depth [B,1,H,W] fp32 (metres)."""
     import torch
     from mindtheedge_amd.utils.depth import inv2depth
+    from mindtheedge_amd import kernels as K
     model_wrapper.eval()
     with torch.no_grad():
         pred_inv_depth = model_wrapper.depth(image, rgb_edge=None)['inv_depths'][0][0]
-    return inv2depth(pred_inv_depth)
+    depth = inv2depth(pred_inv_depth)
+    # The eval forward runs the GroupNorm cluster kernels too (bounded inter-workgroup waits); the optimizer that polls the device error word on the
+    # training path never runs here.  The depth goes to the host next (save_depth), so waiting for the stream costs nothing that is not paid anyway.
+    torch.cuda.current_stream().synchronize()
+    K.check_device_errors()
+    return depth
 
 
 IMAGE_EXT = ('.png', '.jpg', '.jpeg', '.bmp', '.ppm')

@@ -41,6 +41,7 @@ MTE_CLOCK_DEFINE(patch)
 namespace {
 
 constexpr int TH = 8, TW = 32;                     // output tile (pixels)
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 __device__ __forceinline__ int swz_off(int p, int kc) { return p * 64 + ((kc ^ ((p >> 2) & 3)) << 4); }
 
@@ -217,11 +218,42 @@ __device__ __forceinline__ void extra_load(ExtraFrags<MM, Q>& f, const PatchArgs
     }
 }
 
+// the same for the 16x16x32 forms (round 6): px[q][m][ph] = chunk g16 (channels 32 sl + 8 g16 ..) of pixel x0 + 16 ph + c16, w[q][c] = the lane's 16 bytes of the
+// 16-channel half c (gathered from the two fragment blocks of the 32x32x16 pack: see conv_patch_fwd2_kernel, M16)
+template <int MM, int NT, int Q>
+__device__ __forceinline__ void extra_load16(ExtraFrags<MM, Q>& f, const PatchArgs& a, int s2, int b, int yrow0, int x0, int c16, int g16, unsigned w16off) {
+    const int cp2 = a.C2 >> 3, n2 = (a.C2 + 31) >> 5;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int sl = s2 + q;
+        const bool sok = sl < n2;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const u32x4_t wv = *(const u32x4_t*)((const char*)a.wp2 + (long)(sok ? sl : 0) * (2 * NT * 1024) + w16off + c * 256);
+            f.w[q][c] = sok ? wv : u32x4_t{0u, 0u, 0u, 0u};
+        }
+        const int cc = sl * 4 + g16;
+        const bool cok = sok && cc < cp2;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            const int yy = yrow0 + m;
+            const bool ok = cok && yy < a.H;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const u32x4_t v = *(const u32x4_t*)(a.x2 + (((long)b * a.H + (yy < a.H ? yy : a.H - 1)) * a.W + x0 + 16 * ph + c16) * a.ldx2 + (cok ? cc : 0) * 8);
+                f.px[q][m][ph] = ok ? v : u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+}
+
 // ---- forward / dgrad --------------------------------------------------------------------------------------
 // TALL (NT = 1, one 32-channel input slice): 16 x 32-pixel tile, four pixel rows per wave -- every weight fragment fetched
 // from L2 feeds twice the MFMAs (with two rows per wave the 7x7 full-resolution layers pulled 6 GB of weight fragments
 // per launch, ~10 TB/s of L2 bandwidth); the single slice needs only one patch buffer, so two workgroups still fit a CU.
-template <int K, int NT, bool TALL, bool ACC = false, bool EXTRA = false>
+// M16 (round 6): v_mfma_f32_16x16x32_bf16 with the operands the other way round (D = W X^T, as in the second form): a lane owns 4 consecutive output channels of
+// one pixel, so the tile is staged with 8-byte LDS writes instead of 64 two-byte ones; swizzle, fragment reads and weight gather as conv_patch_fwd2_kernel's M16.
+template <int K, int NT, bool TALL, bool ACC = false, bool EXTRA = false, bool M16 = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
     static_assert(!EXTRA || K == 3, "the 1x1 second source rides the 3x3 kernels");
@@ -230,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int PCH = PH * PW * 4;                               // 16-B chunks per patch slice
     constexpr int NCH = (PCH + 255) / 256;
     constexpr int PBYTES = PH * PW * 64;
-    constexpr int OBYTES = TH * TW * NT * 64;                      // output staging (bf16 [256 px][32*NT])
+    constexpr int OSTR = M16 ? NT * 64 + 16 : NT * 64;             // bytes per staged pixel (M16: padded, the 8-byte writes of 16 pixels then go 2-way)
+    constexpr int OBYTES = TH * TW * OSTR;                         // output staging (bf16 [256 px][32*NT])
     // patch buffers (tall 5x5 / 7x7 tiles: single-slice layers only).  Round 3 tried ONE buffer for the tall 3x3 tiles too (39 KB instead
     // of 78 KB of LDS per workgroup): the kernel holds 196-224 VGPRs, so two workgroups per CU is all it gets either way, and forcing
     // three or four waves per SIMD spills (72 -> 32 at 384x1280: 400 -> 694 us)
@@ -269,7 +302,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int idc = tid + i * 256;
-            if (PCH % 256 == 0 || idc < PCH) *(u32x4_t*)(smem + buf * PBYTES + swz_off(idc >> 2, idc & 3)) = st[i];
+            const int off = M16 ? (idc >> 2) * 64 + (((idc & 3) ^ ((idc >> 3) & 2)) << 4) : swz_off(idc >> 2, idc & 3);      // (M16: slot = chunk ^ 2 ((p >> 2) & 1))
+            if (PCH % 256 == 0 || idc < PCH) *(u32x4_t*)(smem + buf * PBYTES + off) = st[i];
         }
     };
 
@@ -279,11 +313,20 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     constexpr int MM = (NT == 2 || TALL) ? 4 : 2;
     const int nsel = NT == 2 ? wave >> 1 : 0;
     const int mrow0 = NT == 2 ? (wave & 1) * 4 : wave * MM;
-    f32x16_t acc[MM];
+    f32x16_t acc[M16 ? 1 : MM];
 #pragma unroll
-    for (int m = 0; m < MM; ++m)
+    for (int m = 0; m < (M16 ? 1 : MM); ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    const int c16 = lane & 15, g16 = lane >> 4;                    // M16: pixel column / channel row of the lane, its K group (and its four output channels 4 g16 ..)
+    const unsigned w16off = (unsigned)((g16 >> 1) * NT * 1024 + nsel * 1024 + ((g16 & 1) * 32 + c16) * 16);
+    f32x4_t acc16[M16 ? MM : 1][2][2];                              // [pixel row][16-channel half][16-pixel half]
+#pragma unroll
+    for (int m = 0; m < (M16 ? MM : 1); ++m)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) acc16[m][c][ph] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     PATCH_STAMP_DECL;
     PATCH_STAMP();
@@ -291,15 +334,29 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         // one slice in flight: with two, this form (167 VGPRs, three workgroups per CU) drops to two workgroups per CU
         const int n2 = (a.C2 + 31) >> 5;
         ExtraFrags<MM, 1> ef;
-        extra_load<MM, NT, 1>(ef, a, 0, b, y0 + mrow0, x0 + r, h, nsel, lane);
+        if constexpr (M16) extra_load16<MM, NT, 1>(ef, a, 0, b, y0 + mrow0, x0, c16, g16, w16off);
+        else extra_load<MM, NT, 1>(ef, a, 0, b, y0 + mrow0, x0 + r, h, nsel, lane);
         for (int s2 = 0; s2 < n2; ++s2) {
+            if constexpr (M16) {
 #pragma unroll
-            for (int m = 0; m < MM; ++m)
+                for (int m = 0; m < MM; ++m)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ef.px[0][m][kk]), __builtin_bit_cast(bf16x8_t, ef.w[0][kk]), acc[m], 0, 0, 0);
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph)
+                            acc16[m][c][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ef.w[0][c]), __builtin_bit_cast(bf16x8_t, ef.px[0][m][ph]), acc16[m][c][ph], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < MM; ++m)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ef.px[0][m][kk]), __builtin_bit_cast(bf16x8_t, ef.w[0][kk]), acc[m], 0, 0, 0);
+            }
             asm volatile("" ::: "memory");                         // (the next slice's loads stay behind these MFMAs: one set of fragment registers)
-            if (s2 + 1 < n2) extra_load<MM, NT, 1>(ef, a, s2 + 1, b, y0 + mrow0, x0 + r, h, nsel, lane);
+            if (s2 + 1 < n2) {
+                if constexpr (M16) extra_load16<MM, NT, 1>(ef, a, s2 + 1, b, y0 + mrow0, x0, c16, g16, w16off);
+                else extra_load<MM, NT, 1>(ef, a, s2 + 1, b, y0 + mrow0, x0 + r, h, nsel, lane);
+            }
         }
         asm volatile("" ::: "memory");                             // (the patch staging registers are not live beside the fragment set)
     }
@@ -316,10 +373,11 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         // weight fragments come straight from L2 (hundreds of cycles): keep PD taps in flight in a register ring
         constexpr int PD = TAPS < 4 ? TAPS : 4;
         u32x4_t bq[PD][2];
+        const char* wsl16 = (const char*)a.wp + (long)s * TAPS * (2 * NT * 1024) + w16off;      // M16: + tap * 2 NT KiB + half * 256
 #pragma unroll
         for (int d = 0; d < PD; ++d)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) bq[d][kk] = wsl[((d * 2 + kk) * NT + nsel) * 64];
+            for (int kk = 0; kk < 2; ++kk) bq[d][kk] = M16 ? *(const u32x4_t*)(wsl16 + d * (2 * NT * 1024) + kk * 256) : wsl[((d * 2 + kk) * NT + nsel) * 64];
 #pragma unroll 1                                                   // (round 5, end: unrolled over the 3x3 taps this loop needs 254 instead of 167 VGPRs -- two workgroups per CU instead of
                                                                    //  three -- and the 64 -> 64 @192x640 forward went from 92 to 107 us: latency-bound, not issue-bound)
         for (int t0 = 0; t0 < TAPS; t0 += PD) {
@@ -329,21 +387,39 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
                 if (t < TAPS) {                                    // wave-uniform
                     const int dy = t / K, dx = t - dy * K;
                     u32x4_t fa[MM][2];
+                    if constexpr (M16) {
 #pragma unroll
-                    for (int m = 0; m < MM; ++m) {
-                        const int p = (mrow0 + m + dy) * PW + dx + r;
+                        for (int m = 0; m < MM; ++m)
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
+                            for (int ph = 0; ph < 2; ++ph) {
+                                const int p = (mrow0 + m + dy) * PW + dx + 16 * ph + c16;
+                                fa[m][ph] = *(const u32x4_t*)(P + p * 64 + ((g16 ^ ((p >> 1) & 2)) << 4));
+                            }
+#pragma unroll
+                        for (int m = 0; m < MM; ++m)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                for (int ph = 0; ph < 2; ++ph)
+                                    acc16[m][c][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[d][c]),
+                                                                                              __builtin_bit_cast(bf16x8_t, fa[m][ph]), acc16[m][c][ph], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) {
+                            const int p = (mrow0 + m + dy) * PW + dx + r;
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
+                        }
+#pragma unroll
+                        for (int m = 0; m < MM; ++m)
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk)
+                                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]),
+                                                                                 __builtin_bit_cast(bf16x8_t, bq[d][kk]), acc[m], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int m = 0; m < MM; ++m)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]),
-                                                                             __builtin_bit_cast(bf16x8_t, bq[d][kk]), acc[m], 0, 0, 0);
                     if (t + PD < TAPS) {
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) bq[d][kk] = wsl[(((t + PD) * 2 + kk) * NT + nsel) * 64];
+                        for (int kk = 0; kk < 2; ++kk) bq[d][kk] = M16 ? *(const u32x4_t*)(wsl16 + (t + PD) * (2 * NT * 1024) + kk * 256) : wsl[(((t + PD) * 2 + kk) * NT + nsel) * 64];
                     }
                 }
             }
@@ -355,8 +431,25 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     }
     MTE_CLOCK_END(patch)
     // ---- epilogue: stage the tile as bf16 [pixel][N] in LDS, then 16-byte coalesced stores
-    constexpr int NB = NT * 64;                                    // bytes per pixel
-    {
+    constexpr int NB = OSTR;                                       // bytes per staged pixel
+    if constexpr (M16) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch0 = nsel * 32 + 16 * c + 4 * g16;          // (N % 8 == 0: the lane's four channels are inside or outside as a whole)
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (a.bias && ch0 < a.N) ? a.bias[ch0 + e] : 0.f;
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    u32x2_t v;
+                    v[0] = pack2bf(acc16[m][c][ph][0] + bv[0], acc16[m][c][ph][1] + bv[1]);
+                    v[1] = pack2bf(acc16[m][c][ph][2] + bv[2], acc16[m][c][ph][3] + bv[3]);
+                    *(u32x2_t*)(smem + ((mrow0 + m) * TW + 16 * ph + c16) * NB + ch0 * 2) = v;
+                }
+        }
+    } else {
         const int ch = nsel * 32 + r;
         const float bv = (a.bias && ch < a.N) ? a.bias[ch] : 0.f;
 #pragma unroll
@@ -446,8 +539,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
 //     ONE new row (2 ds_read_b128 instead of 2 MM), issued a whole tap ahead of its first MFMA;
 //   * the MFMA operands are swapped (D = W * X^T): a lane then owns 4 CONSECUTIVE output channels of one pixel per accumulator quad, so
 //     the tile is staged with 16 ds_write_b64 per thread instead of 64 two-byte writes that all fell on two LDS banks.
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-
 // M16 (round 6): the same tile on v_mfma_f32_16x16x32_bf16 -- per tap and slice 4 MM instructions of 16 cycles instead of 2 MM of 32: equal matrix-pipe cycles,
 // but the chip HOLDS a higher clock on that shape (MI355X_MICROARCH.md 'DVFS give-back' item 7; measured here: profiles/r06_inloop_clock.txt).  A = weights
 // (16 channels x one whole 32-channel slice: lane (row, g) gathers its 16 bytes from the two fragment blocks of the 32x32x16 pack, K order = channel order),
@@ -457,7 +548,6 @@ template <int K, int NT, bool TALL, bool R1 = false, bool ACC = false, bool EXTR
 __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     static_assert(!TALL || NT == 1, "tall tiles are for the 32-output kernels");
     static_assert(!R1 || K == 3, "the rank-1 term is a 3x3 stencil");
-    static_assert(!M16 || (!R1 && !EXTRA && K > 3), "the 16x16x32 form exists for the 5x5 / 7x7 loops");
     constexpr int TH = TALL ? 16 : 8;
     constexpr int PAD = K / 2, PH = TH + K - 1, PW = TW + K - 1, TAPS = K * K;
     constexpr int PCH = PH * PW * 4;                               // 16-B chunks of one patch slice
@@ -539,52 +629,75 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     // of the low-resolution one: H and W are even).  As a GEMM step: K index = (parity class) * 4 + (a * 2 + b) -- exactly 16 -- with the map's four values
     // in the slots of the pixel's own class and zeros elsewhere.  Loaded beside the first patch, consumed before the main loop: no register lives across it.
     constexpr int LR = MM / 2 + 2;                                  // low-resolution rows under the wave's MM pixel rows (y0 + mrow0 is even)
-    float r1t[R1 ? 9 : 1], r1m[R1 ? LR : 1][2];
+    // (M16: the lane's channel depends on the 16-channel half c, its pixel on the 16-pixel half ph: two sets each, index q)
+    constexpr int RQ = (R1 && M16) ? 2 : 1;
+    float r1t[RQ][R1 ? 9 : 1], r1m[RQ][R1 ? LR : 1][2];
     if constexpr (R1) {
-        const int n = nsel * 32 + r;
-        const float* wc = a.r1_w + (n < a.N ? (long)n * a.r1_ws : 0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) r1t[t] = wc[t];
-        const int hl = a.H >> 1, wl_ = a.W >> 1;
-        const int ly0 = ((y0 + mrow0) >> 1) - 1, lx0 = ((x0 + r + 1) >> 1) - 1;   // low pixel of window row / column -1 of the wave's first row / the lane's pixel
+        for (int q = 0; q < RQ; ++q) {
+            const int n = M16 ? nsel * 32 + 16 * q + c16 : nsel * 32 + r;
+            const float* wc = a.r1_w + (n < a.N ? (long)n * a.r1_ws : 0);
 #pragma unroll
-        for (int i = 0; i < LR; ++i)
+            for (int t = 0; t < 9; ++t) r1t[q][t] = wc[t];
+            const int hl = a.H >> 1, wl_ = a.W >> 1;
+            const int pxl = M16 ? 16 * q + c16 : r;
+            const int ly0 = ((y0 + mrow0) >> 1) - 1, lx0 = ((x0 + pxl + 1) >> 1) - 1;   // low pixel of window row / column -1 of the wave's first row / the lane's pixel
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ly = ly0 + i, lx = lx0 + j;
-                const bool ok = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl_;
-                const float v = a.r1_inv[ok ? ((long)b * hl + ly) * wl_ + lx : 0];
-                r1m[i][j] = ok ? v : 0.f;
-            }
+            for (int i = 0; i < LR; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ly = ly0 + i, lx = lx0 + j;
+                    const bool ok = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl_;
+                    const float v = a.r1_inv[ok ? ((long)b * hl + ly) * wl_ + lx : 0];
+                    r1m[q][i][j] = ok ? v : 0.f;
+                }
+        }
     }
     auto rank1_step = [&]() {
         if constexpr (R1) {
             // weights operand: lane (r, h) holds channel n, K slots 8 h .. 8 h + 7 = row parity h, column parity px = slot >> 2, (a, b) = slot & 3
-            float R[2][3];
+            // (M16: K = 32 with the 16 slots in K groups 0 and 1 -- the lane's row parity is g16 -- and zeros in groups 2 and 3)
+            const int hh = M16 ? (g16 & 1) : h;
+            const bool kreal = M16 ? g16 < 2 : true;
+            u32x4_t wf[RQ];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                R[0][kx] = r1t[kx] + (h ? r1t[3 + kx] : 0.f);          // low row a = 0: tap row 0 (+ tap row 1 on odd rows)
-                R[1][kx] = r1t[6 + kx] + (h ? 0.f : r1t[3 + kx]);      // low row a = 1: tap row 2 (+ tap row 1 on even rows)
-            }
-            const bool nok = nsel * 32 + r < a.N;
-            u32x4_t wf;
+            for (int q = 0; q < RQ; ++q) {
+                float R[2][3];
 #pragma unroll
-            for (int px = 0; px < 2; ++px)
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa) {
-                    const float c0 = px ? R[aa][0] + R[aa][1] : R[aa][0], c1 = px ? R[aa][2] : R[aa][1] + R[aa][2];
-                    wf[px * 2 + aa] = nok ? pack2bf(c0, c1) : 0u;
+                for (int kx = 0; kx < 3; ++kx) {
+                    R[0][kx] = r1t[q][kx] + (hh ? r1t[q][3 + kx] : 0.f);          // low row a = 0: tap row 0 (+ tap row 1 on odd rows)
+                    R[1][kx] = r1t[q][6 + kx] + (hh ? 0.f : r1t[q][3 + kx]);      // low row a = 1: tap row 2 (+ tap row 1 on even rows)
                 }
+                const bool nok = kreal && (M16 ? nsel * 32 + 16 * q + c16 : nsel * 32 + r) < a.N;
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa) {
+                        const float c0 = px ? R[aa][0] + R[aa][1] : R[aa][0], c1 = px ? R[aa][2] : R[aa][1] + R[aa][2];
+                        wf[q][px * 2 + aa] = nok ? pack2bf(c0, c1) : 0u;
+                    }
+            }
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
                 const int la = (m + 1) >> 1;
-                const unsigned w01 = pack2bf(r1m[la][0], r1m[la][1]), w23 = pack2bf(r1m[la + 1][0], r1m[la + 1][1]);
-                const bool mine = h == (m & 1);                      // the pixel row's parity class sits in this half of the K slots
-                const bool odd = r & 1;
-                u32x4_t uf;
-                uf[0] = (mine && !odd) ? w01 : 0u; uf[1] = (mine && !odd) ? w23 : 0u;
-                uf[2] = (mine && odd) ? w01 : 0u;  uf[3] = (mine && odd) ? w23 : 0u;
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, uf), acc[m], 0, 0, 0);
+                const bool mine = kreal && hh == (m & 1);            // the pixel row's parity class sits in this half of the K slots
+                const bool odd = (M16 ? c16 : r) & 1;
+                u32x4_t uf[RQ];
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    const unsigned w01 = pack2bf(r1m[q][la][0], r1m[q][la][1]), w23 = pack2bf(r1m[q][la + 1][0], r1m[q][la + 1][1]);
+                    uf[q][0] = (mine && !odd) ? w01 : 0u; uf[q][1] = (mine && !odd) ? w23 : 0u;
+                    uf[q][2] = (mine && odd) ? w01 : 0u;  uf[q][3] = (mine && odd) ? w23 : 0u;
+                }
+                if constexpr (M16) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph)
+                            acc16[m][c][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[c]), __builtin_bit_cast(bf16x8_t, uf[ph]), acc16[m][c][ph], 0, 0, 0);
+                } else {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[0]), __builtin_bit_cast(bf16x8_t, uf[0]), acc[m], 0, 0, 0);
+                }
             }
         }
     };
@@ -592,13 +705,16 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     PATCH_STAMP_DECL;
     PATCH_STAMP();
     ExtraFrags<EXTRA ? MM : 1, 2> ef;
-    if constexpr (EXTRA) extra_load<MM, NT, 2>(ef, a, 0, b, y0 + mrow0, x0 + r, h, nsel, lane);
+    const unsigned w16off = (unsigned)((g16 >> 1) * NT * 1024 + nsel * 1024 + ((g16 & 1) * 32 + c16) * 16);      // (M16: see wfrag)
+    if constexpr (EXTRA) {
+        if constexpr (M16) extra_load16<MM, NT, 2>(ef, a, 0, b, y0 + mrow0, x0, c16, g16, w16off);
+        else extra_load<MM, NT, 2>(ef, a, 0, b, y0 + mrow0, x0 + r, h, nsel, lane);
+    }
     dma_patch(0, 0);
     // weight fragments: block (slice, tap, kk, nt) of 64 lanes x 16 B, straight from L2
     const u32x4_t* wl = (const u32x4_t*)a.wp + lane + nsel * 64;
     const unsigned wlane = (unsigned)(lane + nsel * 64) * 16u;      // this lane's byte offset inside a fragment block
     // M16: second index = 16-channel half c; lane (row, g) takes channel nsel * 32 + 16 c + row, K = 8 g .. 8 g + 7 of the slice = lane (g & 1) * 32 + 16 c + row of block kk = g >> 1
-    const unsigned w16off = (unsigned)((g16 >> 1) * NT * 1024 + nsel * 1024 + ((g16 & 1) * 32 + c16) * 16);
     auto wfrag = [&](int s, int t, int kk) {
         if constexpr (M16) return *(const u32x4_t*)((const char*)a.wp + (long)(s * TAPS + t) * (2 * NT * 1024) + w16off + kk * 256);
         else return wl[((long)(s * TAPS + t) * 2 + kk) * (NT * 64)];
@@ -625,11 +741,23 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int m = 0; m < MM; ++m)
+                for (int m = 0; m < MM; ++m) {
+                    if constexpr (M16) {
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ef.w[q][kk]), __builtin_bit_cast(bf16x8_t, ef.px[q][m][kk]), acc[m], 0, 0, 0);
-            if (s2 + 2 < n2) extra_load<MM, NT, 2>(ef, a, s2 + 2, b, y0 + mrow0, x0 + r, h, nsel, lane);
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int ph = 0; ph < 2; ++ph)
+                                acc16[m][c][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ef.w[q][c]), __builtin_bit_cast(bf16x8_t, ef.px[q][m][ph]), acc16[m][c][ph], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ef.w[q][kk]), __builtin_bit_cast(bf16x8_t, ef.px[q][m][kk]), acc[m], 0, 0, 0);
+                    }
+                }
+            if (s2 + 2 < n2) {
+                if constexpr (M16) extra_load16<MM, NT, 2>(ef, a, s2 + 2, b, y0 + mrow0, x0, c16, g16, w16off);
+                else extra_load<MM, NT, 2>(ef, a, s2 + 2, b, y0 + mrow0, x0 + r, h, nsel, lane);
+            }
         }
     }
 
@@ -696,8 +824,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
                 _Pragma("unroll") for (int dy = 0; dy < K; ++dy)                                                       \
                     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                 \
                         /* scalar base of the fragment block + one per-lane byte offset for all of them (18 VGPR pointer pairs otherwise) */ \
-                        const char* blk = (const char*)a.wp + (((long)((S) * TAPS + dy * K + dx) * 2 + kk) * NT) * 1024;   \
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[dx * K + dy][kk]) : "v"(wlane), "s"(blk) : "memory"); \
+                        const char* blk = M16 ? (const char*)a.wp + (long)((S) * TAPS + dy * K + dx) * (2 * NT * 1024) + kk * 256 /* half kk of the tap's two blocks */ \
+                                              : (const char*)a.wp + (((long)((S) * TAPS + dy * K + dx) * 2 + kk) * NT) * 1024;   \
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[dx * K + dy][kk]) : "v"(M16 ? w16off : wlane), "s"(blk) : "memory"); \
                     }                                                                                                  \
             if (MORE) dma_patch((S) + 1, ((S) + 1) & 1);                                                               \
             PF2_COLUMN(0, MORE) PF2_COLUMN(1, MORE) PF2_COLUMN(2, MORE)                                                \
@@ -1076,6 +1205,8 @@ int g_patch_fwd2 = 1;
 //                               // development knob (mte_debug_set(11, 400 + v)): 0 = the first form of the forward kernel
 
 int g_patch_m16 = 1;                                 // development knob (mte_debug_set(11, 500 + v)): 0 = the 5x5 / 7x7 second form on v_mfma_f32_32x32x16_bf16 (round 5)
+ int g_patch_m16_3 = 1;                               // development knob (mte_debug_set(11, 700 + v)): 0 = the 3x3 / 1x1 second form on v_mfma_f32_32x32x16_bf16 (round 5)
+int g_patch_m16_f1 = 1;                              // development knob (mte_debug_set(11, 600 + v)): 0 = the first form on v_mfma_f32_32x32x16_bf16 (round 5)
 
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int* tile_rows = nullptr) {
     // the second form addresses the input through a buffer descriptor (< 2 GiB)
@@ -1088,8 +1219,8 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int*
         if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
             if (tile_rows) *tile_rows = 16;
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
-            if constexpr (K >= 5) {
-                if (v2 && g_patch_m16) {
+            if constexpr (K >= 1) {
+                if (v2 && (K >= 5 ? g_patch_m16 : g_patch_m16_3)) {
                     if (a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
                     else hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
                     return mte_check_launch();
@@ -1097,6 +1228,8 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int*
             }
             if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (a.accum && g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             return mte_check_launch();
@@ -1104,8 +1237,8 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int*
     }
     if (tile_rows) *tile_rows = TH;
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
-    if constexpr (K >= 5) {
-        if (v2 && g_patch_m16) {
+    if constexpr (K >= 1) {
+        if (v2 && (K >= 5 ? g_patch_m16 : g_patch_m16_3)) {
             if (a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             return mte_check_launch();
@@ -1113,6 +1246,8 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int*
     }
     if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else if (a.accum && g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     return mte_check_launch();
@@ -1206,7 +1341,7 @@ inline bool patch_shape_ok(int W, int Cin_p, int N, int KH, int KW) {
 }  // namespace
 
 #ifdef MTE_DEV
-extern "C" int mtei_set_patch_tall(int v) { if (v >= 500 && v < 510) { g_patch_m16 = v - 500; return MTE_OK; } if (v >= 400 && v < 410) { g_patch_fwd2 = v - 400; return MTE_OK; } if (v >= 300 && v < 310) { g_patch_wgrad_wide = v - 300; return MTE_OK; } if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
+extern "C" int mtei_set_patch_tall(int v) { if (v >= 700 && v < 710) { g_patch_m16_3 = v - 700; return MTE_OK; } if (v >= 600 && v < 610) { g_patch_m16_f1 = v - 600; return MTE_OK; } if (v >= 500 && v < 510) { g_patch_m16 = v - 500; return MTE_OK; } if (v >= 400 && v < 410) { g_patch_fwd2 = v - 400; return MTE_OK; } if (v >= 300 && v < 310) { g_patch_wgrad_wide = v - 300; return MTE_OK; } if (v >= 200 && v < 210) { g_patch_wgrad_8w = v - 200; return MTE_OK; } if (v >= 100) { g_patch_wgrad_wgs = v; return MTE_OK; } g_patch_tall = v; return MTE_OK; }
 #endif
 
 extern "C" {
@@ -1303,14 +1438,17 @@ int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, cons
     if (N <= 32) {
         if (g_patch_tall && H >= 16) {
             const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
-            hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         } else {
             const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-            hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         }
     } else {
         const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-        hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        if (g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
     }
     return mte_check_launch();
 }
@@ -1326,16 +1464,22 @@ static int launch_plus1x1(const PatchArgs& a, hipStream_t stream, int* rows) {
         if (g_patch_tall && H >= 16) {
             *rows = 16;
             const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
-            if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (v2 && g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         } else {
             const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-            if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (v2 && g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         }
     } else {
         const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-        if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        if (v2 && g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
     }
     return mte_check_launch();

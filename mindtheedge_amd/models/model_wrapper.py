@@ -181,6 +181,8 @@ class ModelWrapper(nn.Module):
         if float(count) == 0.0:
             return {}
         mean = (total / count).cpu()
+        from .. import kernels as K
+        K.check_device_errors()                              # the validation forwards of the epoch have finished (host read above)
         out = {'{}-{}{}'.format(self.metrics_name, key, mode): float(mean[i, j])
                for i, mode in enumerate(self.metrics_modes) for j, key in enumerate(self.metrics_keys)}
         edge_rows = [o['edges'] for o in output_data_batch if 'edges' in o]
@@ -199,7 +201,13 @@ class ModelWrapper(nn.Module):
         return out
 
     def depth(self, *args, **kwargs):
-        return self.model.depth_net(*args, **kwargs)
+        out = self.model.depth_net(*args, **kwargs)
+        if not self.model.depth_net.training:
+            # inference has no optimizer step to poll the device error word (a GroupNorm cluster wait that gave up): one read of host memory, no
+            # synchronisation -- a give-up of THIS forward surfaces at the latest at the next call (infer_edges.infer_depth waits and polls itself)
+            from .. import kernels as K
+            K.check_device_errors()
+        return out
 
     def forward(self, *args, **kwargs):
         return self.model(*args, **kwargs)

@@ -103,6 +103,50 @@ def test_infer_depth_function_matches_wrapper_depth(tmp_path):
         K.set_compute_dtype("bf16")
 
 
+def test_inference_reports_a_cluster_wait_that_gave_up(tmp_path):
+    """round-5 verdict: the GroupNorm cluster kernels run in the eval forward too, but only FusedAdam.step() polled the device error word -- on the
+    inference path a bounded inter-workgroup wait that gave up stayed silent.  infer_edges.infer_depth now waits for its stream and polls;
+    ModelWrapper.depth polls without waiting (a give-up surfaces at the next call at the latest).  Development knob 25 = 1000 bounds the arrival poll to
+    zero tries at the benchmark geometry (B = 8, 384x1280: the 512-channel 24x80 layers take the cluster route)."""
+    sys.path.insert(0, ROOT)
+    import infer_edges
+    from mindtheedge_amd.models.model_wrapper import ModelWrapper
+    from mindtheedge_amd.utils.config import load_config
+    from mindtheedge_amd import kernels as K
+    from mindtheedge_amd._lib import dev_library, MteError
+    try:
+        w = ModelWrapper(load_config(_yaml(tmp_path, 384, 1280))).cuda()
+        img = torch.rand(8, 3, 384, 1280, generator=torch.Generator().manual_seed(2)).cuda()
+        with dev_library() as lib:
+            K.check_device_errors()
+            assert lib.mte_gn_fwd_is_single_pass_b(8, 24 * 80, 512, 0, 0) == 1
+            depth = infer_edges.infer_depth(w, img)              # the normal bound: no report
+            assert bool(torch.isfinite(depth).all())
+            lib.mte_debug_set(25, 1000)
+            try:
+                with pytest.raises(MteError, match="device error word"):
+                    infer_edges.infer_depth(w, img)
+                K.check_device_errors()                          # cleared by the poll
+                w.eval()
+                reported = False
+                try:
+                    with torch.no_grad():
+                        w.depth(img, rgb_edge=None)              # queued; its own poll (no wait) may come too early to see the report ...
+                except MteError:
+                    reported = True
+                torch.cuda.synchronize()
+                if not reported:
+                    with pytest.raises(MteError, match="device error word"):
+                        K.check_device_errors()                  # ... then the next poll does
+            finally:
+                lib.mte_debug_set(25, 1000 + (1 << 24))
+            depth2 = infer_edges.infer_depth(w, img)
+            assert torch.equal(depth2, depth)
+    finally:
+        K.set_grad_sink(None)
+        K.set_compute_dtype("bf16")
+
+
 def test_infer_edges_png_input_is_resized_and_written_as_npy_and_png(tmp_path, capsys):
     """config #1's plumbing end to end: an image FILE of another size -> LANCZOS resize to the configured shape -> depth files."""
     from PIL import Image

@@ -7,6 +7,8 @@
   the north-star's 1e-3, gradient energy to bf16 tolerance);
 * the LDS-patch conv family against the generic implicit GEMM on a full training step;
 * the weight-gradient side stream against single-stream execution (the schedule must not change the result)."""
+import os
+
 import pytest
 import torch
 
@@ -77,10 +79,22 @@ def test_frames_of_a_batch_are_independent_at_full_size():
         K.set_compute_dtype("bf16")
 
 
+# Measured on MI355X (profiles/r06_t8_pin.txt): worst max-norm 2.2e-2, worst mean 5.1e-3, worst 32x32-block mean 5.8e-3 of the map's mean value, no map
+# bit-identical (the GroupNorm record count and the split-K slab count depend on B: other fp32 summation orders, then ~60 layers of bf16 rounding).
+# Bounds: 1.5x the measured max-norm and mean; 2x the measured block mean -- the differences are spread evenly over a map (worst block = 1.15x the map's
+# mean), whereas a wrong tile in one corner of one map is a block at O(0.1 .. 1) of the mean value: that is what the block bound catches.
+T8_PIN_MAX, T8_PIN_MEAN, T8_PIN_BLOCK = 3.3e-2, 7.7e-3, 1.2e-2
+
+
 def _frame_vs_batch(one, full, i):
-    """(max-norm relative error, mean relative error, bit-identical?) of frame i alone against the same frame inside the batch"""
+    """(max-norm relative error, mean relative error, bit-identical?, worst 32x32 block) of frame i alone against the same frame inside the batch.
+    worst block = the largest mean |difference| over a 32x32-pixel block (16x16 from the third scale on) relative to the map's mean |value|: rounding noise is
+    spread over the map, a wrong tile (the failure this test exists for) is not"""
     a, b = one.float(), full[i:i + 1].float()
-    return rel_err(a.cpu(), b.cpu()), float((a - b).abs().mean()) / float(b.abs().mean()), bool(torch.equal(one, full[i:i + 1]))
+    blk = 32 if a.shape[-1] >= 640 else 16
+    d = torch.nn.functional.avg_pool2d((a - b).abs(), blk)
+    return (rel_err(a.cpu(), b.cpu()), float((a - b).abs().mean()) / float(b.abs().mean()), bool(torch.equal(one, full[i:i + 1])),
+            float(d.max()) / float(b.abs().mean()))
 
 
 def test_benchmark_batch_of_8_pins_every_frame_to_the_frame_run_alone():
@@ -96,6 +110,7 @@ def test_benchmark_batch_of_8_pins_every_frame_to_the_frame_run_alone():
         net, _ = _model("bf16")
         rgb = _batch(8, seed=23)["rgb"]
         exact = total = 0
+        worst = {}
         for mode in ("eval", "train"):
             net.train(mode == "train")
             with torch.no_grad():
@@ -107,11 +122,19 @@ def test_benchmark_batch_of_8_pins_every_frame_to_the_frame_run_alone():
                     one = o[0] if mode == "eval" else o
                     for s in range(4):
                         assert tuple(one[s].shape) == (1, 1, H >> s, W >> s)
-                        mx, mean, same = _frame_vs_batch(one[s], full[s], i)
+                        mx, mean, same, blk = _frame_vs_batch(one[s], full[s], i)
                         exact += same
                         total += 1
-                        assert mx < 4e-2 and mean < 8e-3, (mode, i, s, mx, mean)
-        print("B=8 vs single frame: %d of %d maps bit-identical" % (exact, total))
+                        w = worst.setdefault(mode, [0.0, 0.0, 0, 0.0])
+                        w[0], w[1], w[2], w[3] = max(w[0], mx), max(w[1], mean), w[2] + same, max(w[3], blk)
+                        assert mx < T8_PIN_MAX and mean < T8_PIN_MEAN and blk < T8_PIN_BLOCK, (mode, i, s, mx, mean, blk)
+        report = "B=8 vs single frame: %d of %d maps bit-identical; " % (exact, total) + "; ".join(
+            "%s: worst max-norm %.3e, worst mean %.3e, worst block mean %.3e, %d of 32 bit-identical" % (m, w[0], w[1], w[3], w[2]) for m, w in worst.items())
+        print(report)
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out):                                   # (the measured numbers go on record: profiles/r06_t8_pin.txt)
+            with open(os.path.join(out, "t8_pin.txt"), "w") as f:
+                f.write(report + "\n")
     finally:
         K.set_compute_dtype("bf16")
 
