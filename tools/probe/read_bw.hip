@@ -72,16 +72,16 @@ int main() {
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
     char nm[128];
     for (int g : {1024, 2048, 4096, 8192, 16384}) {
-        snprintf(nm, 128, "read 1 stream  U=4  grid %d", g);  TIME(nm, bytes, (hipLaunchKernelGGL((read_kernel<4, 1, false>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "read 1 stream  U=8  grid %d", g);  TIME(nm, bytes, (hipLaunchKernelGGL((read_kernel<8, 1, false>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "read 1 stream  U=16 grid %d", g);  TIME(nm, bytes, (hipLaunchKernelGGL((read_kernel<16, 1, false>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "read 1 stream  U=8  nt grid %d", g);  TIME(nm, bytes, (hipLaunchKernelGGL((read_kernel<8, 1, true>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "read 2 streams U=4  grid %d", g);  TIME(nm, 2 * bytes, (hipLaunchKernelGGL((read_kernel<4, 2, false>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "read 2 streams U=8  grid %d", g);  TIME(nm, 2 * bytes, (hipLaunchKernelGGL((read_kernel<8, 2, false>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "read 2 streams U=4  chunked grid %d", g);  TIME(nm, 2 * bytes, (hipLaunchKernelGGL((read_chunk_kernel<4, 2>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "read 2 streams U=8  chunked grid %d", g);  TIME(nm, 2 * bytes, (hipLaunchKernelGGL((read_chunk_kernel<8, 2>), dim3(g), dim3(256), 0, 0, a, b, n, out)))
-        snprintf(nm, 128, "copy (read + write) U=4 grid %d", g);  TIME(nm, 2 * bytes, (hipLaunchKernelGGL((copy_kernel<4>), dim3(g), dim3(256), 0, 0, a, c, n)))
-        snprintf(nm, 128, "copy (read + write) U=8 grid %d", g);  TIME(nm, 2 * bytes, (hipLaunchKernelGGL((copy_kernel<8>), dim3(g), dim3(256), 0, 0, a, c, n)))
+        snprintf(nm, 128, "read 1 stream  U=4  grid %d", g);  TIME(nm, bytes, hipLaunchKernelGGL((read_kernel<4, 1, false>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "read 1 stream  U=8  grid %d", g);  TIME(nm, bytes, hipLaunchKernelGGL((read_kernel<8, 1, false>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "read 1 stream  U=16 grid %d", g);  TIME(nm, bytes, hipLaunchKernelGGL((read_kernel<16, 1, false>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "read 1 stream  U=8  nt grid %d", g);  TIME(nm, bytes, hipLaunchKernelGGL((read_kernel<8, 1, true>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "read 2 streams U=4  grid %d", g);  TIME(nm, 2 * bytes, hipLaunchKernelGGL((read_kernel<4, 2, false>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "read 2 streams U=8  grid %d", g);  TIME(nm, 2 * bytes, hipLaunchKernelGGL((read_kernel<8, 2, false>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "read 2 streams U=4  chunked grid %d", g);  TIME(nm, 2 * bytes, hipLaunchKernelGGL((read_chunk_kernel<4, 2>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "read 2 streams U=8  chunked grid %d", g);  TIME(nm, 2 * bytes, hipLaunchKernelGGL((read_chunk_kernel<8, 2>), dim3(g), dim3(256), 0, 0, a, b, n, out))
+        snprintf(nm, 128, "copy (read + write) U=4 grid %d", g);  TIME(nm, 2 * bytes, hipLaunchKernelGGL((copy_kernel<4>), dim3(g), dim3(256), 0, 0, a, c, n))
+        snprintf(nm, 128, "copy (read + write) U=8 grid %d", g);  TIME(nm, 2 * bytes, hipLaunchKernelGGL((copy_kernel<8>), dim3(g), dim3(256), 0, 0, a, c, n))
     }
     return 0;
 }
