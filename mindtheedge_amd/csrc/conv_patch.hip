@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     };
     // pixel row J of this wave's patch rows (tap column DX) -> window slot
 #define PF2_LDROW(J, SLOT, DX)                                                                                         \
-    if constexpr (M16) {                                                                                               \
+    { if constexpr (M16) {                                                                                               \
         _Pragma("unroll") for (int ph = 0; ph < 2; ++ph) {                                                             \
             const int p_ = (mrow0 + (J)) * PW + (DX) + 16 * ph + c16;                                                  \
             win[SLOT][ph] = *(const u32x4_t*)(P + p_ * 64 + ((g16 ^ ((p_ >> 1) & 2)) << 4));                           \
@@ -784,9 +784,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     } else {                                                                                                           \
         const int p_ = (mrow0 + (J)) * PW + (DX) + r;                                                                  \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) win[SLOT][kk] = *(const u32x4_t*)(P + swz_off(p_, 2 * kk + h)); \
-    }
+    } }
 #define PF2_MFMAS(DY, BQ)                                                                                              \
-    if constexpr (M16) {                                                                                               \
+    { if constexpr (M16) {                                                                                               \
         _Pragma("unroll") for (int m = 0; m < MM; ++m)                                                                 \
             _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                              \
                 _Pragma("unroll") for (int ph = 0; ph < 2; ++ph)                                                       \
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
             _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (BQ)[kk]),               \
                                                                  __builtin_bit_cast(bf16x8_t, win[((DY) + m) % WR][kk]), acc[m], 0, 0, 0); \
-    }
+    } }
     if constexpr (WHOLE) {
         // The compiler does not count LDS-DMA in its s_waitcnt bookkeeping, and beside a DMA it drains vmcnt(0) in front of every use of an
         // ordinary load: the fragment loads of these kernels are hidden from it in asm statements and waited for by hand.  Fragment pair Q of
