@@ -61,7 +61,7 @@ class ConvTimer:
         for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad",
                      "mte_conv2d_stem_fwd", "mte_conv2d_stem_wgrad", "mte_conv2d_patch_fwd_rank1", "mte_conv2d_patch_fwd_plus1x1"):
             self._orig[name] = getattr(lib, name)
-        self._optional = ("mte_gn_tail_fwd", "mte_gn_stats_from_records", "mte_conv2d_patch_fwd_gn", "mte_gn_elu_bwd_red_ready", "mte_conv2d_patch_fwd_gr", "mte_conv2d_patch_fwd_plus1x1_gr")   # (entry points an older build of the library lacks: same-box A/B of two trees with ONE bench.py)
+        self._optional = ("mte_gn_tail_fwd", "mte_gn_stats_from_records", "mte_conv2d_patch_fwd_gn", "mte_gn_elu_bwd_red_ready", "mte_conv2d_patch_fwd_gr", "mte_conv2d_patch_fwd_plus1x1_gr")   # (the last three: round-5 builds only)   # (entry points an older build of the library lacks: same-box A/B of two trees with ONE bench.py)
         for name in ("mte_conv2d_patch_fwd_gn", "mte_conv2d_patch_fwd_gr", "mte_conv2d_patch_fwd_plus1x1_gr"):   # round 5: LDS-patch launches that also leave GroupNorm records
             try:
                 self._orig[name] = getattr(lib, name)

@@ -121,22 +121,6 @@ int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, f
  * mte_conv2d_patch_fwd_gn_elems(B, H, W) floats; *tiles_per_sample_out records per sample were written (tile height depends on the kernel form).
  * mte_gn_stats_from_records (below) adds them in tile order into the buffer mte_gn_stats would have filled: the stand-alone statistics pass over y
  * (252 MB per full-resolution layer at B = 8) is not run.  N % 16 == 0, else MTE_ERR_UNSUPPORTED.  Bit-reproducible (no atomics). */
-/* round 5 -- mte_conv2d_patch_fwd as the DATA GRADIENT of the consumer of a GroupNorm(16) + ELU layer z = ELU(GN(v)) (reference layers01.py:32-38; autograd runs
- * cuDNN's GroupNorm backward over dz and v after the consumer's data gradient wrote dz): y = dz is stored as always, and the FIRST pass of that norm's backward
- * (red[b][c] = (sum dz ELU'(u), sum dz ELU'(u) xhat) over the pixels of sample b) comes out of the store loop, which reads v at the pixels it stores:
- * per-tile records in `rec` (mte_conv2d_patch_fwd_gr_elems(B, H, W, N) floats of scratch), added in tile order into red [B][N][2] by a small second launch.
- * The caller then runs mte_gn_elu_bwd_red_ready (the apply pass alone).  v / stats / gamma / beta / eps: that norm's input, statistics buffer and affine.
- * With accumulate the records describe the sums this launch stores (the complete gradient).  N % 16 == 0, else MTE_ERR_UNSUPPORTED. */
-long mte_conv2d_patch_fwd_gr_elems(int B, int H, int W, int N);
-int mte_conv2d_patch_fwd_gr(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N, int KH, int KW,
-                            int accumulate, const void* v, long ldv, const double* stats, const float* gamma, const float* beta, float eps,
-                            float* rec, long rec_elems, float* red, mte_stream_t stream);
-/* ... the same for mte_conv2d_patch_fwd_plus1x1 (a residual block's input gradient: conv1 and the 1x1 shortcut are the only consumers of the previous block's
- * ELU(GN_t(t)), and that ONE launch stores its complete gradient). */
-int mte_conv2d_patch_fwd_plus1x1_gr(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
-                                    const void* x2, long ldx2, const void* wpatch2, int C2,
-                                    const void* v, long ldv, const double* stats, const float* gamma, const float* beta, float eps,
-                                    float* rec, long rec_elems, float* red, mte_stream_t stream);
 long mte_conv2d_patch_fwd_gn_elems(int B, int H, int W);
 int mte_conv2d_patch_fwd_gn(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N, int KH, int KW,
                             int accumulate, float* rec, long rec_elems, int* tiles_per_sample_out, mte_stream_t stream);
@@ -185,17 +169,12 @@ int mte_gn_elu_fwd(const void* y1, long ld1, const void* y2, long ld2, const flo
                    const float* gamma, const float* beta, void* z, long ldz,
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
 /* mte_gn_elu_bwd: y2 = NULL with scale2 and d2 given (round 5, the backward of mte_gn_tail_fwd's outer norm): ONE input tensor, but the
- * gradient leaves twice -- d1 = dv and d2 = scale2[b,c] * dv -- and dbias, if asked, is the column sum of d2. */
+ * gradient leaves twice -- d1 = dv and d2 = scale2[b,c] * dv -- and dbias, if asked, is the column sum of d2.  d2 without y2 AND without scale2 is
+ * MTE_ERR_ARG (there is no factor to form it with). */
 int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const void* y2, long ld2, const float* scale2,
                    const double* stats, const float* gamma, const float* beta, float* red,
                    void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,
                    int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
-/* round 5: mte_gn_elu_bwd whose first pass is already done -- red [B][C][2] was filled by mte_conv2d_patch_fwd_gr.  One input tensor (no y2; scale2 / d2 as in
- * mte_gn_elu_bwd's second-output mode: d2 = scale2[b,c] * d1, dbias = column sums of d2). */
-int mte_gn_elu_bwd_red_ready(const void* dz, long lddz, const void* y1, long ld1, const float* scale2,
-                             const double* stats, const float* gamma, const float* beta, const float* red,
-                             void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,
-                             int B, int HW, int C, float eps, int dtype, mte_stream_t stream);
 /* Round 5 -- the tail of a residual block in two launches: ResidualConv.forward's `self.activ(self.normalize(x_out + shortcut))` with
  * x_out = conv2's GroupNorm + ELU applied on the fly (layers01.py:35-38 and :69-73).
  *   y1 = conv2's CONVOLUTION output (+ bias), stats1 = its sums (mte_gn_stats), gamma1 / beta1 = conv2.normalize;

@@ -23,7 +23,7 @@ class MteError(RuntimeError):
 
 RETURNS = {}
 # entry points that return a value (capability / size queries) instead of an error code
-QUERIES = ("mte_conv2d_patch_supported", "mte_conv2d_stem_supported", "mte_conv2d_patch_wgrad_supported", "mte_conv2d_wgrad_nine_tap", "mte_conv2d_patch_fwd_gn_elems", "mte_conv2d_patch_fwd_gr_elems", "mte_conv2d_patch_pack_elems", "mte_depth_metrics_workspace_bytes",
+QUERIES = ("mte_conv2d_patch_supported", "mte_conv2d_stem_supported", "mte_conv2d_patch_wgrad_supported", "mte_conv2d_wgrad_nine_tap", "mte_conv2d_patch_fwd_gn_elems", "mte_conv2d_patch_pack_elems", "mte_depth_metrics_workspace_bytes",
            "mte_chamfer_workspace_bytes", "mte_edge_loss_sums_elems", "mte_gn_fwd_is_single_pass", "mte_gn_fwd_is_single_pass_b",
            "mte_edge_loss_work_elems", "mte_rank1_conv_bwd_records_elems", "mte_conv2d_patch_fwd_rank1_ok", "mte_gn_stats_elems", "mte_device_error_poll", "mte_invdepth_bwd_weight_workspace_elems", "mte_sparse_site_list_workspace_elems")
 

@@ -136,7 +136,6 @@ extern int g_mte_loss_prezeroed;
 // (the kernels then only give up).  Codes are bit flags so that several kernels of a step can report.
 #define MTE_DEVERR_GN_CLUSTER_FWD 1u
 #define MTE_DEVERR_GN_CLUSTER_BWD 2u
-#define MTE_DEVERR_GN_TAIL_FWD 4u
 extern unsigned* g_mte_err_dev;
 __device__ __forceinline__ void mte_report_device_error(unsigned* err, unsigned code) {
     // (load | store rather than an atomic OR: the word lives in host memory and a lost flag of a second, simultaneous reporter does not matter --

@@ -60,12 +60,6 @@ struct PatchArgs {
     // round 5 (mte_conv2d_patch_fwd_gn): GroupNorm(16) statistics of the tile AS STORED, one record of 32 floats (sum, sum of squares per group) per tile at
     // gn_rec + ((b * tiles_y + ty) * tiles_x + tx) * 32 -- the consumer's stand-alone statistics pass over y (252 MB at full resolution) is not needed
     float* gn_rec;
-    // round 5 (mte_conv2d_patch_fwd_gr): this launch stores the OUTPUT GRADIENT dz of a GroupNorm(16) + ELU layer z = ELU(GN(v)) (it is the data gradient of that
-    // layer's consumer).  With gr_rec set the store loop also reads v (gr_v: the tensor that norm normalises, same pixels and channels as y) and leaves the first
-    // pass of the norm's backward -- per channel r1 = sum dyh, r2 = sum dyh * xhat, dyh = dz * ELU'(u) -- as one record of [N][2] floats per tile:
-    // gn_elu_bwd_reduce_kernel's two tensor reads (dz again, v) become one (v), inside a launch that is matrix-core-bound
-    const bf16_t* gr_v; long gr_ldv; const double* gr_stats; const float* gr_gamma; const float* gr_beta; float gr_eps;
-    float* gr_rec;
 };
 
 // ---- GroupNorm statistics in the store loop (round 5) ----------------------------------------------------------------------------------------------------------
@@ -105,88 +99,6 @@ __device__ __forceinline__ void patch_gn_record(const PatchArgs& a, float* s, fl
     }
 }
 
-
-// ---- first pass of the consumer's GroupNorm backward in the store loop (round 5; see PatchArgs.gr_rec) --------------------------------------------------------
-struct GrConsts { float ka[8], kb[8], xa[8], xb[8]; };
-__device__ __forceinline__ float patch_elu_grad(float u) { return u > 0.f ? 1.f : __expf(u); }      // (norm_act.hip: elu_grad)
-// mean / rstd of the 16 groups of sample b (the arithmetic of norm_act.hip: block_group_stats), by threads 0..15 BEFORE the barrier in front of the store loop
-__device__ __forceinline__ void patch_gr_group_stats(const PatchArgs& a, int b, int tid, float* s_gmr) {
-    if (a.gr_rec && tid < 16) {
-        const double* sp = a.gr_stats + ((long)b * 16 + tid) * 2;
-        const double n = (double)a.H * a.W * (a.N >> 4);
-        const double m = sp[0] / n;
-        double var = sp[1] / n - m * m;
-        if (var < 0.0) var = 0.0;
-        s_gmr[2 * tid] = (float)m;
-        s_gmr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)a.gr_eps));
-    }
-}
-__device__ __forceinline__ void patch_gr_consts(const PatchArgs& a, const float* s_gmr, int c, bool live, GrConsts& k) {
-    const int gs = a.N >> 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int ch = live ? c * 8 + i : 0, g = ch / gs;
-        const float mean = s_gmr[2 * g], rstd = s_gmr[2 * g + 1], gm = a.gr_gamma[ch];
-        k.xa[i] = rstd; k.xb[i] = -mean * rstd;
-        k.ka[i] = rstd * gm; k.kb[i] = a.gr_beta[ch] - mean * rstd * gm;
-    }
-}
-__device__ __forceinline__ void patch_gr_add(const u32x4_t& dzv, const u32x4_t& vv, bool ok, const GrConsts& k, float* r1, float* r2) {
-    float g[8], v[8];
-    unpack16<bf16_t>(dzv, g);
-    unpack16<bf16_t>(vv, v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float dyh = ok ? g[i] * patch_elu_grad(fmaf(v[i], k.ka[i], k.kb[i])) : 0.f;
-        r1[i] += dyh; r2[i] = fmaf(dyh, fmaf(v[i], k.xa[i], k.xb[i]), r2[i]);
-    }
-}
-// record of the tile: [N][2] floats at gr_rec + tile * 2 N (lanes that share a chunk column by xor butterflies, waves in order: bit-reproducible)
-template <int NT>
-__device__ __forceinline__ void patch_gr_record(const PatchArgs& a, float* r1, float* r2, int tid, long tile, char* smem) {
-    constexpr int NC = NT * 4;
-    const int lane = tid & 63, wave = tid >> 6, c = tid % NC;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int off = NC; off < 64; off <<= 1) { r1[k] += __shfl_xor(r1[k], off, 64); r2[k] += __shfl_xor(r2[k], off, 64); }
-    __syncthreads();                                               // the staged tile has been read by everybody
-    float* sred = (float*)smem;                                    // [4 waves][NC][16]
-    if (lane < NC) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { sred[(wave * NC + c) * 16 + k] = r1[k]; sred[(wave * NC + c) * 16 + 8 + k] = r2[k]; }
-    }
-    __syncthreads();
-    if (tid < 2 * a.N) {
-        const int ch = tid >> 1, which = tid & 1;
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) t += sred[(w * NC + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
-        a.gr_rec[tile * (2 * a.N) + tid] = t;
-    }
-}
-// red[b][ch][2] = the tiles of sample b added in tile order: 2 N values x 1024 / (2 N) tile lanes per workgroup
-__global__ __launch_bounds__(1024) void patch_gr_finish_kernel(const float* __restrict__ rec, int nrec, int N2, float* __restrict__ red) {
-    __shared__ float s_p[1024];
-    const int b = blockIdx.x, lanes = 1024 / N2, v = threadIdx.x % N2, k = threadIdx.x / N2;
-    float acc = 0.f;
-    if (k < lanes) {
-        const float* r = rec + (long)b * nrec * N2 + v;
-        int j = k;
-        for (; j + 3 * lanes < nrec; j += 4 * lanes) {
-            const float t0 = r[(long)j * N2], t1 = r[(long)(j + lanes) * N2], t2 = r[(long)(j + 2 * lanes) * N2], t3 = r[(long)(j + 3 * lanes) * N2];
-            acc += t0; acc += t1; acc += t2; acc += t3;
-        }
-        for (; j < nrec; j += lanes) acc += r[(long)j * N2];
-    }
-    s_p[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x < N2) {
-        float t = 0.f;
-        for (int i = 0; i < lanes; ++i) t += s_p[i * N2 + threadIdx.x];
-        red[(long)b * N2 + threadIdx.x] = t;
-    }
-}
 
 // ---- second K source at the centre tap (EXTRA; mte_conv2d_patch_fwd_plus1x1) ---------------------------------------------------------------------------------
 // y += conv_1x1(x2, wp2): for a 1x1 every input element meets the MFMA exactly once per 32-column tile, so its fragments need no LDS patch -- lane (r, h) of
@@ -268,9 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
     // of 78 KB of LDS per workgroup): the kernel holds 196-224 VGPRs, so two workgroups per CU is all it gets either way, and forcing
     // three or four waves per SIMD spills (72 -> 32 at 384x1280: 400 -> 694 us)
     constexpr int NBUF = (TALL && K > 3) ? 1 : 2;
-    // (+ 128: the 16 (mean, rstd) pairs of the gr epilogue live BEHIND the staged tile, inside the dead patch buffers -- as a __shared__ array of their own
-    //  they pushed the 3x3 tall second form from 81,920 to 82,048 bytes, i.e. from two workgroups per CU to one: round 5's regression on the 64 -> 32 layers)
-    constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES + 128) ? NBUF * PBYTES : OBYTES + 128);
+    constexpr int LDS_BYTES = ((NBUF * PBYTES > OBYTES) ? NBUF * PBYTES : OBYTES);
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -460,28 +370,14 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
                 *(bf16_t*)(smem + ((mrow0 + m) * TW + px) * NB + ch * 2) = f2bf(acc[m][e] + bv);
             }
     }
-    float* s_gmr = (float*)(smem + OBYTES);                       // (dead patch bytes behind the staged tile)
-    patch_gr_group_stats(a, b, tid, s_gmr);
     __syncthreads();
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
     const int c = tid % (NT * 4);
     const bool gnrec = a.gn_rec != nullptr;                        // (wave-uniform)
-    const bool grrec = a.gr_rec != nullptr;                        // (wave-uniform; then gs_ / gq_ carry r1 / r2 of the norm's backward)
     float gs_[8], gq_[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { gs_[k] = 0.f; gq_[k] = 0.f; }
-    GrConsts grk;
-    u32x4_t grv[OCH / 256];                                        // the norm's input at this thread's pixels, all requested before the first use
-    if (grrec) {
-        patch_gr_consts(a, s_gmr, c, c < cpp, grk);
-#pragma unroll
-        for (int i = 0; i < OCH / 256; ++i) {
-            const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
-            const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
-            grv[i] = *(const u32x4_t*)(a.gr_v + (((long)b * a.H + (yy < a.H ? yy : a.H - 1)) * a.W + xx) * a.gr_ldv + (c < cpp ? c : 0) * 8);
-        }
-    }
     if constexpr (ACC) {
         // accumulating: branch-free, every LDS and global read of the thread's pixels issued before the first use (see the second form's epilogue;
         // same-box A/B, 32 -> 64 at 384 x 1280: the guarded read -> wait -> add -> store loop cost 100 us over the plain store)
@@ -509,7 +405,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
             const u32x4_t pk = pack16<bf16_t>(vn);
             if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pk;
             if (gnrec) patch_gn_add(pk, ok[i], gs_, gq_);
-            if (grrec) patch_gr_add(pk, grv[i], ok[i], grk, gs_, gq_);
         }
     } else {
 #pragma unroll
@@ -519,12 +414,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
             const u32x4_t pk = *(const u32x4_t*)(smem + pix * NB + c * 16);
             if (yy < a.H && c < cpp) *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = pk;
             if (gnrec) patch_gn_add(pk, yy < a.H && c < cpp, gs_, gq_);
-            if (grrec) patch_gr_add(pk, grv[i], yy < a.H && c < cpp, grk, gs_, gq_);
             asm volatile("" ::: "memory");                         // one read -> store per iteration: with the reads hoisted the stores leave in one burst (2-4 % slower)
         }
     }
     if (gnrec) patch_gn_record<NT>(a, gs_, gq_, tid, ((long)b * tiles_y + ty_) * tiles_x + tx_, smem);
-    if (grrec) patch_gr_record<NT>(a, gs_, gq_, tid, ((long)b * tiles_y + ty_) * tiles_x + tx_, smem);
     PATCH_STAMP();
 }
 
@@ -556,8 +449,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
     constexpr int NB = NT * 64, OSTR = NB + 16;                    // bytes per staged pixel, padded stride (b64 writes of 16 pixels: 2-way)
     constexpr int OBYTES = TH * TW * OSTR;
     constexpr int NBUF = (TALL && K > 3) ? 1 : 2;                  // tall 5x5 / 7x7 tiles: single-slice layers only
-    constexpr int LDS_BYTES = NBUF * PBYTES > OBYTES + 128 ? NBUF * PBYTES : OBYTES + 128;      // (+ 128: see the first form)
+    constexpr int LDS_BYTES = NBUF * PBYTES > OBYTES ? NBUF * PBYTES : OBYTES;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    // (round 5 added a 128-byte __shared__ array beside this buffer: 82,048 bytes no longer fit twice into a CU's 163,840 and every 64 -> 32 / 72 -> 32 3x3
+    //  launch ran at ONE workgroup per CU -- profiles/r06_lds_fix.txt)
     static_assert(!(K == 3 && TALL) || LDS_BYTES <= 81920, "the tall 3x3 form must keep two workgroups per CU");
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -903,28 +798,14 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
                 *(u32x2_t*)(smem + ((mrow0 + m) * TW + r) * OSTR + (nsel * 32 + 8 * g + 4 * h) * 2) = v;
             }
     }
-    float* s_gmr = (float*)(smem + OBYTES);                       // (dead patch bytes behind the staged tile)
-    patch_gr_group_stats(a, b, tid, s_gmr);
     __syncthreads();
     constexpr int OCH = TH * TW * NT * 4;                          // 16-B chunks of the tile
     const int cpp = a.N >> 3;                                      // valid chunks per pixel
     const int c = tid % (NT * 4);
     const bool gnrec = a.gn_rec != nullptr;                        // (wave-uniform)
-    const bool grrec = a.gr_rec != nullptr;                        // (wave-uniform; then gs_ / gq_ carry r1 / r2 of the norm's backward)
     float gs_[8], gq_[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { gs_[k] = 0.f; gq_[k] = 0.f; }
-    GrConsts grk;
-    u32x4_t grv[OCH / 256];                                        // the norm's input at this thread's pixels, all requested before the first use
-    if (grrec) {
-        patch_gr_consts(a, s_gmr, c, c < cpp, grk);
-#pragma unroll
-        for (int i = 0; i < OCH / 256; ++i) {
-            const int pix = tid / (NT * 4) + i * (256 / (NT * 4));
-            const int yy = y0 + pix / TW, xx = x0 + (pix & (TW - 1));
-            grv[i] = *(const u32x4_t*)(a.gr_v + (((long)b * a.H + (yy < a.H ? yy : a.H - 1)) * a.W + xx) * a.gr_ldv + (c < cpp ? c : 0) * 8);
-        }
-    }
     if constexpr (ACC) {
         // accumulating (a consumer's gradient added onto another's, or onto a term written first; an instantiation of its own: as a run-time branch beside
         // the plain loop it cost the tall plain kernels 2 %): branch-free, with the LDS and global reads of all of the
@@ -955,7 +836,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
             const u32x4_t pk = pack16<bf16_t>(vn);
             if (ok[i]) *(u32x4_t*)(a.y + off[i]) = pk;
             if (gnrec) patch_gn_add(pk, ok[i], gs_, gq_);
-            if (grrec) patch_gr_add(pk, grv[i], ok[i], grk, gs_, gq_);
         }
     } else {
 #pragma unroll
@@ -965,12 +845,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
             const u32x4_t pk = *(const u32x4_t*)(smem + pix * OSTR + c * 16);
             if (yy < a.H && c < cpp) *(u32x4_t*)(a.y + (((long)b * a.H + yy) * a.W + xx) * a.ldy + c * 8) = pk;
             if (gnrec) patch_gn_add(pk, yy < a.H && c < cpp, gs_, gq_);
-            if (grrec) patch_gr_add(pk, grv[i], yy < a.H && c < cpp, grk, gs_, gq_);
             asm volatile("" ::: "memory");                         // one read -> store per iteration (see the first form)
         }
     }
     if (gnrec) patch_gn_record<NT>(a, gs_, gq_, tid, ((long)b * tiles_y + ty_) * tiles_x + tx_, smem);
-    if (grrec) patch_gr_record<NT>(a, gs_, gq_, tid, ((long)b * tiles_y + ty_) * tiles_x + tx_, smem);
     PATCH_STAMP();
 }
 
@@ -1204,9 +1082,38 @@ int g_patch_fwd2 = 1;
 #endif
 //                               // development knob (mte_debug_set(11, 400 + v)): 0 = the first form of the forward kernel
 
-int g_patch_m16 = 1;                                 // development knob (mte_debug_set(11, 500 + v)): 0 = the 5x5 / 7x7 second form on v_mfma_f32_32x32x16_bf16 (round 5)
- int g_patch_m16_3 = 1;                               // development knob (mte_debug_set(11, 700 + v)): 0 = the 3x3 / 1x1 second form on v_mfma_f32_32x32x16_bf16 (round 5)
-int g_patch_m16_f1 = 1;                              // development knob (mte_debug_set(11, 600 + v)): 0 = the first form on v_mfma_f32_32x32x16_bf16 (round 5)
+// Round 6: every forward form runs on v_mfma_f32_16x16x32_bf16 (M16); the 32x32x16 forms of rounds 1-5 are instantiated in the development library only
+// (knobs below; tests/test_gpu_conv_variants.py compares the two).  Same-box A/B per layer: profiles/r06_m16_ab.txt, profiles/r06_inloop_clock.txt.
+int g_patch_m16 = 1;                                 // development knob (mte_debug_set(11, 500 + v)): 0 = the 5x5 / 7x7 second form on v_mfma_f32_32x32x16_bf16
+int g_patch_m16_3 = 1;                               // development knob (mte_debug_set(11, 700 + v)): 0 = the 3x3 / 1x1 second form on v_mfma_f32_32x32x16_bf16
+int g_patch_m16_f1 = 1;                              // development knob (mte_debug_set(11, 600 + v)): 0 = the first form on v_mfma_f32_32x32x16_bf16
+
+// one forward launch: second (F2) or first form of the kernel; accumulating or not (a.accum; never with R1 / EXTRA); MFMA shape
+template <bool F2, int K, int NT, bool TALL, bool R1 = false, bool EXTRA = false>
+static void launch_form(const PatchArgs& a, long tiles, hipStream_t st, bool m16) {
+    const dim3 g((unsigned)tiles), b(256);
+    static_assert(F2 || !R1, "the rank-1 term rides the second form");
+#ifdef MTE_DEV
+    if (!m16) {
+        if constexpr (F2) {
+            if constexpr (!R1 && !EXTRA) { if (a.accum) { hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, TALL, false, true>), g, b, 0, st, a); return; } }
+            hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, TALL, R1, false, EXTRA>), g, b, 0, st, a);
+        } else {
+            if constexpr (!EXTRA) { if (a.accum) { hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, TALL, true>), g, b, 0, st, a); return; } }
+            hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, TALL, false, EXTRA>), g, b, 0, st, a);
+        }
+        return;
+    }
+#endif
+    (void)m16;
+    if constexpr (F2) {
+        if constexpr (!R1 && !EXTRA) { if (a.accum) { hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, TALL, false, true, false, true>), g, b, 0, st, a); return; } }
+        hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, TALL, R1, false, EXTRA, true>), g, b, 0, st, a);
+    } else {
+        if constexpr (!EXTRA) { if (a.accum) { hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, TALL, true, false, true>), g, b, 0, st, a); return; } }
+        hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, TALL, false, EXTRA, true>), g, b, 0, st, a);
+    }
+}
 
 template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int* tile_rows = nullptr) {
     // the second form addresses the input through a buffer descriptor (< 2 GiB)
@@ -1215,41 +1122,20 @@ template <int K, int NT> int launch_fwd(const PatchArgs& a, hipStream_t st, int*
     // against 244), and the 1x1 layers are HBM-bound either way
     const bool v2 = g_patch_fwd2 && (K >= 5 || (K == 3 && (NT == 1 || a.Cin_p > 64))) &&
                     (((long)a.B * a.H * a.W - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((uintptr_t)a.bias & 15) == 0;   // (it reads the bias in 16-byte groups)
+    const bool m16 = v2 ? (K >= 5 ? g_patch_m16 : g_patch_m16_3) != 0 : g_patch_m16_f1 != 0;
     if constexpr (NT == 1) {
         if (g_patch_tall && (a.Cin_p <= 32 || K <= 3) && a.H >= 16) {
             if (tile_rows) *tile_rows = 16;
             const long tiles = (long)(a.W / TW) * ((a.H + 15) / 16) * a.B;
-            if constexpr (K >= 1) {
-                if (v2 && (K >= 5 ? g_patch_m16 : g_patch_m16_3)) {
-                    if (a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-                    else hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-                    return mte_check_launch();
-                }
-            }
-            if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (a.accum && g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            if (v2) launch_form<true, K, NT, true>(a, tiles, st, m16);
+            else launch_form<false, K, NT, true>(a, tiles, st, m16);
             return mte_check_launch();
         }
     }
     if (tile_rows) *tile_rows = TH;
     const long tiles = (long)(a.W / TW) * ((a.H + TH - 1) / TH) * a.B;
-    if constexpr (K >= 1) {
-        if (v2 && (K >= 5 ? g_patch_m16 : g_patch_m16_3)) {
-            if (a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            return mte_check_launch();
-        }
-    }
-    if (v2 && a.accum) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-    else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-    else if (a.accum && g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-    else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-    else if (a.accum) hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_patch_fwd_kernel<K, NT, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    if (v2) launch_form<true, K, NT, false>(a, tiles, st, m16);
+    else launch_form<false, K, NT, false>(a, tiles, st, m16);
     return mte_check_launch();
 }
 template <int NT> int dispatch_fwd(const PatchArgs& a, int K, hipStream_t st, int* tile_rows = nullptr) {
@@ -1397,28 +1283,6 @@ int mte_conv2d_patch_fwd_gn(const void* x, long ldx, const void* wpatch, const f
     return rc;
 }
 
-// mte_conv2d_patch_fwd as the DATA GRADIENT of the consumer of a GroupNorm(16) + ELU layer z = ELU(GN(v)) (round 5): y = dz is stored as always, and the first pass of
-// that norm's backward (red[b][c] = (sum dz ELU'(u), sum dz ELU'(u) xhat) over the pixels, what gn_elu_bwd_reduce_kernel computes from dz and v) comes out of the
-// store loop: per-tile records, added in tile order into red [B][N][2] by a small second launch.  The caller then runs mte_gn_elu_bwd_red_ready (apply pass only).
-// v: the tensor the norm normalises (its conv output, or the residual tail's stored sum), stats / gamma / beta / eps: that norm's; rec: scratch of
-// mte_conv2d_patch_fwd_gr_elems(B, H, W, N) floats.  With accumulate the records describe the sums this launch stores (the complete gradient).  N % 16 == 0.
-long mte_conv2d_patch_fwd_gr_elems(int B, int H, int W, int N) { return (long)B * (W / TW) * ((H + TH - 1) / TH) * 2 * N; }
-int mte_conv2d_patch_fwd_gr(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N, int KH, int KW,
-                            int accumulate, const void* v, long ldv, const double* stats, const float* gamma, const float* beta, float eps,
-                            float* rec, long rec_elems, float* red, hipStream_t stream) {
-    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!x || !wpatch || !y || !v || !stats || !gamma || !beta || !rec || !red || !patch_shape_ok(W, Cin_p, N, KH, KW)) return MTE_ERR_ARG;
-    if (N % 16 != 0) return MTE_ERR_UNSUPPORTED;
-    if (rec_elems < mte_conv2d_patch_fwd_gr_elems(B, H, W, N)) return MTE_ERR_ARG;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, accumulate ? 1 : 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr,
-                (const bf16_t*)v, ldv, stats, gamma, beta, eps, rec};
-    int rows = TH;
-    const int rc = N <= 32 ? dispatch_fwd<1>(a, KH, stream, &rows) : dispatch_fwd<2>(a, KH, stream, &rows);
-    if (rc != MTE_OK) return rc;
-    hipLaunchKernelGGL(patch_gr_finish_kernel, dim3((unsigned)B), dim3(1024), 0, stream, rec, (W / TW) * ((H + rows - 1) / rows), 2 * N, red);
-    return mte_check_launch();
-}
-
 // The 3x3 forward with ONE MORE input channel given as a low-resolution map: y = conv_3(x, wpatch) + bias + conv_1(nearest_up2(inv), w1).  inv [B][H/2][W/2] fp32;
 // element (n, tap) of the extra channel's weights at w1[n * w1_stride + tap] (channel C-1 of an OIHW tensor: w1 = w + (C-1)*9, w1_stride = C*9).
 // The term is formed in the store loop of the tile from LDS tables (the map under the tile + halo, the 9 x N weights): no pass over y before, no read of y.
@@ -1436,19 +1300,10 @@ int mte_conv2d_patch_fwd_rank1(const void* x, long ldx, const void* wpatch, cons
     if (!mte_conv2d_patch_fwd_rank1_ok(bias, ldx, B, H, W, Cin_p, N)) return MTE_ERR_UNSUPPORTED;
     PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, inv, w1, w1_stride, nullptr, 0, nullptr, 0};
     if (N <= 32) {
-        if (g_patch_tall && H >= 16) {
-            const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
-            if (g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-        } else {
-            const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-            if (g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-        }
+        if (g_patch_tall && H >= 16) launch_form<true, 3, 1, true, true>(a, (long)(W / TW) * ((H + 15) / 16) * B, stream, g_patch_m16_3 != 0);
+        else launch_form<true, 3, 1, false, true>(a, (long)(W / TW) * ((H + TH - 1) / TH) * B, stream, g_patch_m16_3 != 0);
     } else {
-        const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-        if (g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        launch_form<true, 3, 2, false, true>(a, (long)(W / TW) * ((H + TH - 1) / TH) * B, stream, g_patch_m16_3 != 0);
     }
     return mte_check_launch();
 }
@@ -1460,27 +1315,22 @@ static int launch_plus1x1(const PatchArgs& a, hipStream_t stream, int* rows) {
     const int B = a.B, H = a.H, W = a.W, N = a.N;
     const bool v2 = g_patch_fwd2 && (N <= 32 || a.Cin_p > 64) && (((long)B * H * W - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L && ((uintptr_t)a.bias & 15) == 0;   // (as launch_fwd)
     *rows = TH;
+    const bool m16 = v2 ? g_patch_m16_3 != 0 : g_patch_m16_f1 != 0;
     if (N <= 32) {
         if (g_patch_tall && H >= 16) {
             *rows = 16;
             const long tiles = (long)(W / TW) * ((H + 15) / 16) * B;
-            if (v2 && g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (v2) launch_form<true, 3, 1, true, false, true>(a, tiles, stream, m16);
+            else launch_form<false, 3, 1, true, false, true>(a, tiles, stream, m16);
         } else {
             const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-            if (v2 && g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 1, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 1, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+            if (v2) launch_form<true, 3, 1, false, false, true>(a, tiles, stream, m16);
+            else launch_form<false, 3, 1, false, false, true>(a, tiles, stream, m16);
         }
     } else {
         const long tiles = (long)(W / TW) * ((H + TH - 1) / TH) * B;
-        if (v2 && g_patch_m16_3) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-        else if (v2) hipLaunchKernelGGL((conv_patch_fwd2_kernel<3, 2, false, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-        else if (g_patch_m16_f1) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 2, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+        if (v2) launch_form<true, 3, 2, false, false, true>(a, tiles, stream, m16);
+        else launch_form<false, 3, 2, false, false, true>(a, tiles, stream, m16);
     }
     return mte_check_launch();
 }
@@ -1492,25 +1342,6 @@ int mte_conv2d_patch_fwd_plus1x1(const void* x, long ldx, const void* wpatch, co
     int rows;
     return launch_plus1x1(a, stream, &rows);
 }
-// ... and with the first pass of the GroupNorm backward of the layer whose output gradient this launch writes (see mte_conv2d_patch_fwd_gr): a residual block's
-// input is the previous block's ELU(GN_t(t)), and conv1 + the 1x1 shortcut are its only consumers -- this ONE launch stores its complete gradient.
-int mte_conv2d_patch_fwd_plus1x1_gr(const void* x, long ldx, const void* wpatch, const float* bias, void* y, long ldy, int B, int H, int W, int Cin_p, int N,
-                                    const void* x2, long ldx2, const void* wpatch2, int C2,
-                                    const void* v, long ldv, const double* stats, const float* gamma, const float* beta, float eps,
-                                    float* rec, long rec_elems, float* red, hipStream_t stream) {
-    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!x || !wpatch || !y || !x2 || !wpatch2 || C2 < 8 || C2 % 8 != 0 || !v || !stats || !gamma || !beta || !rec || !red || !patch_shape_ok(W, Cin_p, N, 3, 3)) return MTE_ERR_ARG;
-    if (N % 16 != 0) return MTE_ERR_UNSUPPORTED;
-    if (rec_elems < mte_conv2d_patch_fwd_gr_elems(B, H, W, N)) return MTE_ERR_ARG;
-    PatchArgs a{(const bf16_t*)x, ldx, (const bf16_t*)wpatch, bias, (bf16_t*)y, ldy, B, H, W, Cin_p, N, 0, nullptr, nullptr, 0, (const bf16_t*)x2, ldx2, (const bf16_t*)wpatch2, C2, nullptr,
-                (const bf16_t*)v, ldv, stats, gamma, beta, eps, rec};
-    int rows;
-    const int rc = launch_plus1x1(a, stream, &rows);
-    if (rc != MTE_OK) return rc;
-    hipLaunchKernelGGL(patch_gr_finish_kernel, dim3((unsigned)B), dim3(1024), 0, stream, rec, (W / TW) * ((H + rows - 1) / rows), 2 * N, red);
-    return mte_check_launch();
-}
-
 // dw_stage[N][KH*KW][Cin_p] fp32 (overwritten) for C_out <= 64; bf16 only.
 int mte_conv2d_patch_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw_stage, int stage_parts, int* parts_out,
                            int B, int H, int W, int Cin_p, int N, int KH, int KW, hipStream_t stream) {

@@ -56,7 +56,6 @@ struct GnArgs {
     unsigned* err;                     // device error word (common.hpp) or null
     int fences;                        // MTE_OPT_HANDOFF_FENCES
     unsigned spin_max;                 // bound of the cluster kernels' arrival poll
-    int red_ready;                     // round 5: `red` is already filled (mte_conv2d_patch_fwd_gr): only the apply pass runs
 };
 
 // Pixel rows are processed in batches of GN_U: all 16-byte loads of a batch are issued before any of its stores, so a
@@ -1116,7 +1115,7 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
     const int m2 = a.y2 ? 1 : (a.scale2 && a.d2 ? 2 : 0);
     if (m2 != 1) a.y2 = nullptr;
     if (m2 == 0) { a.scale2 = nullptr; a.d2 = nullptr; }
-    if (n > 0 && n <= GN_SLAB_MAX && m2 != 2 && !a.red_ready) {
+    if (n > 0 && n <= GN_SLAB_MAX && m2 != 2) {
         a.cps_shift = sh;
         // the slab kernels ADD this sample's part of dgamma / dbeta (the stream kernels overwrite them): clear them first (prezeroed callers did)
         if (!g_mte_gn_prezeroed && (mte_memset_async(a.dgamma, 0, sizeof(float) * a.C, stream) != hipSuccess ||
@@ -1127,7 +1126,7 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
         else done = launch_bwd_slab<T, 0, false>(a, n, stream);
         if (done) return mte_check_launch();
     }
-    if (n > GN_SLAB_MAX && !a.red_ready) {                  // (round 5: also the tail with a bias gradient -- the kernels scale the column sums now)
+    if (n > GN_SLAB_MAX) {                  // (round 5: also the tail with a bias gradient -- the kernels scale the column sums now)
         int nch = 0, pl = 0;
         const int cl = cluster_plan(a.B, a.HW, a.C, n, sh, a.y2 ? 3 : 2, &nch, &pl);
         if (cl) {
@@ -1153,8 +1152,7 @@ template <typename T> int run_bwd(GnArgs& a, int dtype, hipStream_t stream) {
         if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 1, true>), grid, dim3(256), ldb, stream, a2);
         else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 1, false>), grid, dim3(256), 0, stream, a2);
     } else {
-        // (red_ready: the first pass came out of the store loop of the launch that produced dz -- mte_conv2d_patch_fwd_gr, round 5)
-        if (!a.red_ready) hipLaunchKernelGGL((gn_elu_bwd_reduce_kernel<T, false>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((gn_elu_bwd_reduce_kernel<T, false>), grid, dim3(256), lds, stream, a);
         if (m2 == 2) {
             if (a.dbias) hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 2, true>), grid, dim3(256), ldb, stream, a2);
             else hipLaunchKernelGGL((gn_elu_bwd_apply_kernel<T, 2, false>), grid, dim3(256), 0, stream, a2);
@@ -1279,6 +1277,7 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
                    int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
     (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
     if (!dz || !y1 || !stats || !gamma || !beta || !red || !d1 || !dgamma || !dbeta || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
+    if (d2 && !y2 && !scale2) return MTE_ERR_ARG;      // a second output needs its factor (with one input d2 = scale2 * d1): never MTE_OK with d2 left unwritten
     if (!g_mte_gn_prezeroed) {
         if (mte_memset_async(red, 0, sizeof(float) * (size_t)B * C * 2, stream) != hipSuccess) return MTE_ERR_LAUNCH;
         if (dbias && mte_memset_async(dbias, 0, sizeof(float) * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
@@ -1286,22 +1285,6 @@ int mte_gn_elu_bwd(const void* dz, long lddz, const void* y1, long ld1, const vo
     GnArgs a{}; a.dbias = dbias; a.dgamma = dgamma; a.dbeta = dbeta; a.y1 = y1; a.ld1 = ld1; a.y2 = y2; a.ld2 = ld2; a.scale2 = scale2; a.stats = (double*)stats;
     a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;
     a.B = B; a.HW = HW; a.C = C; a.eps = eps;
-    gn_common(a);
-    return dtype == MTE_DT_BF16 ? run_bwd<bf16_t>(a, dtype, stream) : run_bwd<float>(a, dtype, stream);
-}
-
-// mte_gn_elu_bwd whose first pass is already done: red [B][C][2] holds (sum dyh, sum dyh * xhat) per sample and channel (mte_conv2d_patch_fwd_gr left it there).
-// One input tensor only (no y2; scale2 / d2 as in mte_gn_elu_bwd's second-output mode).
-int mte_gn_elu_bwd_red_ready(const void* dz, long lddz, const void* y1, long ld1, const float* scale2,
-                             const double* stats, const float* gamma, const float* beta, const float* red,
-                             void* d1, long ldd1, void* d2, long ldd2, float* dgamma, float* dbeta, float* dbias,
-                             int B, int HW, int C, float eps, int dtype, hipStream_t stream) {
-    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
-    if (!dz || !y1 || !stats || !gamma || !beta || !red || !d1 || !dgamma || !dbeta || !gn_shape_ok(C, dtype)) return MTE_ERR_ARG;
-    if (!g_mte_gn_prezeroed && dbias && mte_memset_async(dbias, 0, sizeof(float) * C, stream) != hipSuccess) return MTE_ERR_LAUNCH;
-    GnArgs a{}; a.dbias = dbias; a.dgamma = dgamma; a.dbeta = dbeta; a.y1 = y1; a.ld1 = ld1; a.scale2 = scale2; a.stats = (double*)stats;
-    a.gamma = gamma; a.beta = beta; a.dz = dz; a.lddz = lddz; a.red = (float*)red; a.d1 = d1; a.ldd1 = ldd1; a.d2 = d2; a.ldd2 = ldd2;
-    a.B = B; a.HW = HW; a.C = C; a.eps = eps; a.red_ready = 1;
     gn_common(a);
     return dtype == MTE_DT_BF16 ? run_bwd<bf16_t>(a, dtype, stream) : run_bwd<float>(a, dtype, stream);
 }

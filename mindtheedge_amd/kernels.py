@@ -318,11 +318,14 @@ def _device_errors_init():
 def check_device_errors():
     """Raise if a kernel of this process reported through the device error word since the last call (a bounded inter-workgroup wait that gave up:
     its results are wrong by construction).  Costs one read of host memory, no synchronisation: the trainer and the optimizer call it once per
-    step, so an error surfaces at the end of the step that caused it or of the next one."""
+    step, so an error surfaces at the end of the step that caused it or of the next one -- FusedAdam.step() polls AFTER it has queued the update and the
+    weight re-pack, so by then the parameters carry the failed step: the caller restores its last checkpoint.  The inference entry points poll too
+    (infer_edges.infer_depth after waiting for its stream, ModelWrapper.depth without waiting)."""
     code = int(lib.mte_device_error_poll()) if _device_errors_init() else 0
     if code:
         what = "; ".join(v for k, v in _DEVERR_NAMES.items() if code & k) or "code %d" % code
-        raise MteError("device error word set (0x%x): %s -- the results of that step are invalid" % (code, what))
+        raise MteError("device error word set (0x%x): %s -- the results of that step are invalid; when this is raised by the optimizer, the parameter "
+                       "update of the failed step has already been applied: restore the last checkpoint" % (code, what))
 
 
 def begin_graph_capture():
@@ -369,8 +372,7 @@ class WeightPack:
             if waited.get(cur.cuda_stream) is not self._event:
                 cur.wait_event(self._event)
                 waited[cur.cuda_stream] = self._event
-            if not _side.get("band_active"):                  # (a band chain runs beside the main chain, which may ask for this pack next)
-                self._event = None
+            self._event = None
 
     def _patch_pack(self, w, which):
         wf, wb = self.wf, self.wb
@@ -579,15 +581,10 @@ _cfg = {"patch_kernels": True, "pack_folding": True, "pack_fold_max_overhead": 0
         # (ConvResidualTailFn / mte_gn_tail_fwd).  MTE_FUSE_TAIL=0: the round-4 form (ConvGnEluFn + ResidualTailFn over two tensors)
         "fuse_residual_tail": os.environ.get("MTE_FUSE_TAIL", "1") == "1",
         # round 5: the LDS-patch forward kernels leave the GroupNorm statistics of their output as per-tile records (no statistics pass over y)
-        "gn_stats_in_conv": os.environ.get("MTE_GN_IN_CONV", "1") == "1",
-        # ... and, in the backward pass, the first pass of a GroupNorm's backward rides the store loop of the data-gradient launch that writes its output gradient
-        # (mte_conv2d_patch_fwd_gr / _plus1x1_gr + mte_gn_elu_bwd_red_ready).  OFF by default: same-box A/B (profiles/r05_gn_in_conv.txt) GroupNorm family
-        # -0.16 ms, LDS-patch launches +0.13 ms, step unchanged -- the pass it removes re-read dz from the Infinity Cache, and the network's structure (packs,
-        # skip concats, heads between most norms and a conv) leaves four of its 31 launches to fuse.  MTE_GN_BWD_IN_CONV=1 switches it on.
-        "gn_bwd_in_conv": os.environ.get("MTE_GN_BWD_IN_CONV", "0") == "1",
-        # residual blocks: the 1x1 shortcut's FORWARD launch on the (idle) weight-gradient side stream, beside conv1 / conv2.  MTE_OVERLAP_SHORTCUT=0: in line
-        # (measured same-box, round 5: 23.75 ms per step with it against 23.72 without -- the forward pass has no idle CUs for it to fill; OFF by default)
-        "overlap_shortcut_fwd": os.environ.get("MTE_OVERLAP_SHORTCUT", "0") == "1"}
+        "gn_stats_in_conv": os.environ.get("MTE_GN_IN_CONV", "1") == "1"}
+        # (round 5 also built the first pass of a GroupNorm's BACKWARD inside the data-gradient launch that writes its output gradient, and the 1x1 shortcut's
+        #  forward launch on the side stream: both measured neutral -- profiles/r05_gn_in_conv.txt, DESIGN 7 -- and were removed in round 6)
+
 
 
 def use_pack_folding(flag):
@@ -652,7 +649,10 @@ def conv_forward(x, wf, bias, cout, kh, kw, out=None, pack=None, w=None, accumul
         lib.mte_conv2d_stem_fwd(xp, ldx, wf.data_ptr(), _ptr(bias), yp, ldy, B, H, W, cout, kh, kw, _stream())
         return out
     if pack is not None and _patch_ok(W, Cp, cout, kh, kw, x.dtype):
-        if gn_records is not None and _cfg["gn_stats_in_conv"] and cout % 16 == 0:
+        # (not where the norm that follows holds its (sample, group) slabs on chip and takes the statistics itself -- the single-pass slab / cluster kernels of
+        #  the low-resolution layers would ignore the records: round-5 advisor)
+        if (gn_records is not None and _cfg["gn_stats_in_conv"] and cout % 16 == 0
+                and lib.mte_gn_fwd_is_single_pass_b(B, H * W, cout, 0, _dt(x)) != 1):
             n = int(lib.mte_conv2d_patch_fwd_gn_elems(B, H, W))
             rec = torch.empty((n,), dtype=torch.float32, device=x.device)
             tiles = ctypes.c_int(0)
@@ -681,7 +681,7 @@ _CONV_SOLO = 2      # MTE_CONV_SOLO: the forward pass has no weight-gradient ker
 # (bucketed all-reduce).
 _side = {"enabled": True, "streams": [], "next": 0, "keep": [], "keep_bytes": 0, "callback_queued": False, "dirty": False}
 lib.set_option(3, 1, lazy=True)
-_SIDE_STREAMS = int(os.environ.get("MTE_SIDE_STREAMS", "1"))
+_SIDE_STREAMS = 1      # (round 5 measured two weight-gradient streams no faster than one: profiles/r05_side_queue_width.txt; the option is gone)
 _SIDE_KEEP_LIMIT = 24 << 30          # bytes of (x, dy) kept alive for the side stream before a forced join
 
 
@@ -691,55 +691,22 @@ def use_wgrad_side_stream(flag):
 
 
 class _BandChain:
-    """The exact-border band chain of a folded pack layer (thin strips: 16 x 5 x 640 pixels and the like, launches that fill a
-    fraction of the chip) on a stream of its own, beside the layer's full-size kernels: `with chain:` forks from the current
-    stream, `chain.join()` makes the current stream wait for everything the block enqueued.  With the side streams switched
-    off (serial profiling), or without MTE_BAND_STREAM=1 (the default, see _BAND_STREAM), it does nothing and the chain stays on the
-    current stream."""
-
-    def __init__(self):
-        self.stream = None
-        self.done = None
-        if _side["enabled"] and _BAND_STREAM:
-            if _side.get("band") is None:
-                _side["band"] = torch.cuda.Stream()
-            self.stream = _side["band"]
+    """The exact-border band chain of a folded pack layer (thin strips: 16 x 5 x 640 pixels and the like).  Rounds 3-5 could run it on a third stream beside the
+    layer's full-size kernels (MTE_BAND_STREAM=1: +0.4 % on one GPU, but 25.4 -> 35.1 ms per step as soon as RCCL's streams exist and the third stream shares a
+    hardware queue with one of the other two -- profiles/r03_band_stream_ab.txt); it lost that A/B and the option was removed in round 6.  What is left is the
+    bracket around the chain in PackFoldedConvGnEluFn: the chain runs on the current stream, `mark` / `join` are no-ops."""
 
     def __enter__(self):
-        if self.stream is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.stream.wait_event(ev)
-            self._ctx = torch.cuda.stream(self.stream)
-            self._ctx.__enter__()
-            _side["band_active"] = True
         return self
 
-    def mark(self):
-        """event at this point of the chain (None when the chain runs on the current stream)"""
-        if self.stream is None:
-            return None
-        ev = torch.cuda.Event()
-        ev.record()
-        return ev
-
     def __exit__(self, *exc):
-        if self.stream is not None:
-            self.done = self.mark()
-            _side["band_active"] = False
-            self._ctx.__exit__(*exc)
         return False
 
-    def join(self, ev="done"):
-        ev = self.done if ev == "done" else ev
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+    def mark(self):
+        return None
 
-
-# OFF by default: on one GPU without a process group the third stream is worth +0.4 % (profiles/r03_band_stream_ab.txt), but as soon as RCCL's
-# streams exist it shares a hardware queue with the main chain or the weight-gradient stream and the step goes from 25.4 to 35.1 ms
-# (bench.py under MTE_BENCH_DIST_SELFTEST=1, GPU_MAX_HW_QUEUES 8 or 16 alike) -- the multi-GPU path must not pay for it.  MTE_BAND_STREAM=1 turns it on.
-_BAND_STREAM = bool(os.environ.get("MTE_BAND_STREAM")) and not os.environ.get("MTE_NO_BAND_STREAM")
+    def join(self, ev=None):
+        return None
 
 
 def join_side_stream():
@@ -833,7 +800,7 @@ def _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out):
     return dw, dbias
 
 
-def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None, sunk=False, sites=None, gn_src=None):
+def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out=None, dbias_out=None, fork_slot=None, sunk=False, sites=None):
     """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations; sunk: they are views
     of the gradient sink (nothing on the backward chain reads them: the weight-gradient kernels may run on the side stream);
     fork_slot: see ForkFn -- the data gradient is accumulated into the gradient another consumer of x already produced"""
@@ -870,21 +837,8 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
                 del pend["pending"]
                 d3p, ldd3 = _pl(dy3)
                 dxp, lddx = _pl(target)
-                if (gn_src is not None and _cfg["gn_bwd_in_conv"] and fork_slot.get("parent") is None and Cp % 16 == 0
-                        and tuple(gn_src[0].shape) == (B, Cp, H, W) and gn_src[0].dtype == x.dtype):
-                    # conv1 and the shortcut are the only consumers of x = ELU(GN(v)) and this launch stores its complete gradient (see the plain launch below)
-                    v, vstats, vgamma, vbeta = gn_src
-                    vp, ldv = _pl(v)
-                    n = int(lib.mte_conv2d_patch_fwd_gr_elems(B, H, W, Cp))
-                    rec = torch.empty((n,), dtype=torch.float32, device=x.device)
-                    red = torch.empty((B, Cp, 2), dtype=torch.float32, device=x.device)
-                    lib.mte_conv2d_patch_fwd_plus1x1_gr(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
-                                                        d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1],
-                                                        vp, ldv, vstats.data_ptr(), vgamma.data_ptr(), vbeta.data_ptr(), GN_EPS, rec.data_ptr(), n, red.data_ptr(), st)
-                    _gn_red[target.data_ptr()] = (target, red)
-                else:
-                    lib.mte_conv2d_patch_fwd_plus1x1(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
-                                                     d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1], st)
+                lib.mte_conv2d_patch_fwd_plus1x1(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
+                                                 d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1], st)
                 fork_slot["buf"] = target
                 return target, dw, dbias
             _flush_pending(pend)
@@ -898,19 +852,7 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
             lib.mte_conv2d_igemm_sparse(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, _dt(x),
                                         sites.rows.data_ptr(), sites.count.data_ptr(), acc, st)
         elif _patch_ok(W, cout, Cp, kh, kw, x.dtype):
-            if (gn_src is not None and _cfg["gn_bwd_in_conv"] and fork_slot is None and target is None and Cp % 16 == 0
-                    and tuple(gn_src[0].shape) == (B, Cp, H, W) and gn_src[0].dtype == x.dtype):
-                # x is the output of a GroupNorm + ELU layer and this launch writes its complete gradient: the first pass of that norm's backward rides the store loop
-                v, vstats, vgamma, vbeta = gn_src
-                vp, ldv = _pl(v)
-                n = int(lib.mte_conv2d_patch_fwd_gr_elems(B, H, W, Cp))
-                rec = torch.empty((n,), dtype=torch.float32, device=x.device)
-                red = torch.empty((B, Cp, 2), dtype=torch.float32, device=x.device)
-                lib.mte_conv2d_patch_fwd_gr(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc,
-                                            vp, ldv, vstats.data_ptr(), vgamma.data_ptr(), vbeta.data_ptr(), GN_EPS, rec.data_ptr(), n, red.data_ptr(), st)
-                _gn_red[dx.data_ptr()] = (dx, red)
-            else:
-                lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
+            lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
         else:
             _, wb = pack.get(w, x.dtype, True)
             ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
@@ -956,26 +898,10 @@ def _gn_forward(y1, y2, scale2, gamma, beta, eps, out=None, records=None):
     return z, stats
 
 
-counters = {"gn_red_ready": 0}      # how often a launch form was taken (tests assert that a path they mean to cover ran)
-_gn_red = {}        # data_ptr of a data gradient -> (that tensor, red [B][C][2]): the first pass of its GroupNorm backward came out of the launch that wrote it
-
-
-def _take_gn_red(dz):
-    """red of the GroupNorm backward whose output gradient is dz, if the data-gradient launch that produced dz left it (conv_backward(gn_src=...)).
-    The entry keeps the tensor alive, so an equal address means the same memory; shape and strides must match too (not a view of it)."""
-    e = _gn_red.pop(dz.data_ptr(), None) if _gn_red else None
-    if e is None or tuple(e[0].shape) != tuple(dz.shape) or e[0].stride() != dz.stride() or e[0].dtype != dz.dtype:
-        return None
-    return e[1]
-
-
 def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbias=False, dgamma=None, dbeta=None, dbias=None):
     B, C, H, W = y1.shape
-    red = _take_gn_red(dz) if y2 is None else None
     dz = as_act(dz, y1.dtype)
-    ready = red is not None
-    if not ready:
-        red = _zeros((B, C, 2), torch.float32, y1.device)
+    red = _zeros((B, C, 2), torch.float32, y1.device)
     d1 = new_act(B, C, H, W, y1.dtype, y1.device)
     d2 = new_act(B, C, H, W, y1.dtype, y1.device) if need_d2 else None
     # zero at entry (MTE_OPT_GN_PREZEROED covers dgamma / dbeta too: the single-pass kernels ADD per-sample parts into them)
@@ -988,13 +914,8 @@ def _gn_backward(dz, y1, y2, scale2, stats, gamma, beta, eps, need_d2, want_dbia
     p2, l2 = _pl(y2) if y2 is not None else (0, 0)
     pd1, ld1 = _pl(d1)
     pd2, ld2 = _pl(d2) if d2 is not None else (0, 0)
-    if ready:                          # (round 5) only the apply pass
-        counters["gn_red_ready"] += 1
-        lib.mte_gn_elu_bwd_red_ready(pz, lz, p1, l1, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
-                                     pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), B, H * W, C, eps, _dt(y1), _stream())
-    else:
-        lib.mte_gn_elu_bwd(pz, lz, p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
-                           pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), B, H * W, C, eps, _dt(y1), _stream())
+    lib.mte_gn_elu_bwd(pz, lz, p1, l1, p2, l2, _ptr(scale2), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), red.data_ptr(),
+                       pd1, ld1, pd2, ld2, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), B, H * W, C, eps, _dt(y1), _stream())
     if want_dbias:
         return d1, d2, dgamma, dbeta, dbias
     return d1, d2, dgamma, dbeta
@@ -1027,7 +948,6 @@ class ConvGnEluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, pack, out=None):
         ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
-        ctx.gn_src = getattr(x, "_mte_gn", None) if ctx.needs_input_grad[0] else None     # x is itself the output of a GroupNorm + ELU layer (see conv_backward)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
         recs = []
@@ -1036,8 +956,6 @@ class ConvGnEluFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
         ctx.pack = pack
         ctx.bias = b
-        if out is None and any(ctx.needs_input_grad):
-            z._mte_gn = (y, stats, gamma, beta)              # for the consumer whose data gradient will write dz: the first pass of this norm's backward can ride it
         return z
 
     @staticmethod
@@ -1050,7 +968,7 @@ class ConvGnEluFn(torch.autograd.Function):
         gw, sw = _grad_dst(w)
         dy, _, dgamma, dbeta, db = _gn_backward(dz, y, None, None, stats, gamma, beta, GN_EPS, False, want_dbias=True,
                                                 dgamma=gg, dbeta=gb, dbias=gbias)
-        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw, gn_src=ctx.gn_src)
+        dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw)
         return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), _grad_ret(gamma, dgamma, sg), _grad_ret(beta, dbeta, sb), None, None
 
 
@@ -1168,34 +1086,13 @@ class ConvFn(torch.autograd.Function):
     """Plain conv + bias (the 1x1 shortcut of ResidualConv, layers01.py:61)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, pack, bias_grad=True, overlap=False):
+    def forward(ctx, x, w, b, pack, bias_grad=True):
         """bias_grad=False: the consumer produces the bias gradient (ResidualTailFn: the column sums of this conv's output gradient fall
-        out of the GroupNorm backward pass that computes it -- no stand-alone column-sum launch).
-        overlap=True (round 5): the launch goes to the weight-gradient side stream, which is idle during the forward pass -- a residual block's 1x1
-        shortcut depends only on the block's input and is not needed before the block's tail, so its HBM-bound launch (54-150 TFLOP/s) runs beside
-        conv1 / conv2 instead of between them.  The result carries the event its consumer must wait for (`wait_ready`); the backward pass is unchanged
-        (autograd sees one op on the main stream)."""
+        out of the GroupNorm backward pass that computes it -- no stand-alone column-sum launch)."""
         ctx.fork_slot = getattr(x, "_mte_fork_slot", None)
         wf, _ = pack.get(w, x.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w.shape
-        if overlap and _side["enabled"] and _cfg["overlap_shortcut_fwd"] and not torch.cuda.is_current_stream_capturing():
-            B, _, H, W = x.shape
-            y = new_act(B, cout, H, W, x.dtype, x.device)            # (allocated on the main stream: its memory is recycled in main-stream order)
-            if pack is not None and _patch_ok(W, x.shape[1], cout, kh, kw, x.dtype):
-                pack.get_patch(w, 'f')                               # (its re-pack, if due, stays on the main stream)
-            if not _side["streams"]:
-                _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
-            side = _side["streams"][0]
-            ev = torch.cuda.Event()
-            ev.record()
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                conv_forward(x, wf, b, cout, kh, kw, out=y, pack=pack, w=w)
-                done = torch.cuda.Event()
-                done.record(side)
-            y._mte_ready = done
-        else:
-            y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
+        y = conv_forward(x, wf, b, cout, kh, kw, pack=pack, w=w)
         ctx.save_for_backward(x, w)
         ctx.pack = pack
         ctx.bias = b
@@ -1210,19 +1107,11 @@ class ConvFn(torch.autograd.Function):
         gw, sw = _grad_dst(w)
         if not ctx.bias_grad:
             dx, dw, _ = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw, fork_slot=ctx.fork_slot, sunk=sw)
-            return dx, _grad_ret(w, dw, sw), None, None, None, None
+            return dx, _grad_ret(w, dw, sw), None, None, None
         gbias, sbias = _grad_dst(b)
         dx, dw, db = conv_backward(x, dy, w, ctx.pack, ctx.needs_input_grad[0], dw_out=gw, dbias_out=gbias, fork_slot=ctx.fork_slot,
                                    sunk=sw and sbias)
-        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None, None, None
-
-
-def wait_ready(t):
-    """make the current stream wait for a result that was produced on the side stream (ConvFn overlap=True); a no-op otherwise"""
-    ev = getattr(t, "_mte_ready", None)
-    if ev is not None:
-        torch.cuda.current_stream().wait_event(ev)
-        t._mte_ready = None
+        return dx, _grad_ret(w, dw, sw), _grad_ret(b, db, sbias), None, None
 
 
 class ResidualTailFn(torch.autograd.Function):
@@ -1233,7 +1122,6 @@ class ResidualTailFn(torch.autograd.Function):
         """bias_s: the bias parameter of the conv that produced `s` (the block's 1x1 shortcut).  Its value is already inside `s`; it is an
         input here only so that its GRADIENT -- sum of ds over batch and pixels -- can come out of this op's backward pass, where ds is
         formed anyway (the shortcut conv is then built with bias_grad=False)."""
-        wait_ready(s)
         z, stats = _gn_forward(a, s, scale, gamma, beta, GN_EPS)
         ctx.save_for_backward(a, s, stats, gamma, beta)
         ctx.scale = scale
@@ -1272,7 +1160,6 @@ class ConvResidualTailFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, w2, b2, gamma2, beta2, pack2, s, scale, gamma_t, beta_t, bias_s):
         ctx.fork_slot = getattr(x1, "_mte_fork_slot", None)
-        ctx.gn_src = getattr(x1, "_mte_gn", None) if ctx.needs_input_grad[0] else None      # x1 = conv1's ELU(GN(.)): see conv_backward(gn_src=...)
         wf, _ = pack2.get(w2, x1.dtype, bool(ctx.needs_input_grad[0]))
         cout, cin, kh, kw = w2.shape
         recs = []
@@ -1288,7 +1175,6 @@ class ConvResidualTailFn(torch.autograd.Function):
             lib.mte_gn_stats_from_records(recs[0][0].data_ptr(), recs[0][1], stats2.data_ptr(), B, st)
         else:
             lib.mte_gn_stats(p1, l1, 0, 0, 0, stats2.data_ptr(), B, H * W, C, _dt(c2), st)
-        wait_ready(s)
         stats_t = gn_stats_buffer(B, c2.device)
         t = new_act(B, C, H, W, c2.dtype, c2.device)
         z = new_act(B, C, H, W, c2.dtype, c2.device)
@@ -1301,8 +1187,6 @@ class ConvResidualTailFn(torch.autograd.Function):
         ctx.bias_s = bias_s
         ctx.bias2 = b2
         ctx.pack = pack2
-        if any(ctx.needs_input_grad):
-            z._mte_gn = (t, stats_t, gamma_t, beta_t)        # the outer norm, for the consumer whose data gradient will write dz
         return z
 
     @staticmethod
@@ -1329,8 +1213,7 @@ class ConvResidualTailFn(torch.autograd.Function):
         gw2, sw2 = _grad_dst(w2)
         dc2, _, dgamma2, dbeta2, db2 = _gn_backward(dt, c2, None, None, stats2, gamma2, beta2, GN_EPS, False, want_dbias=True,
                                                     dgamma=gg2, dbeta=gb2, dbias=gbias2)
-        dx1, dw2, _ = conv_backward(x1, dc2, w2, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw2, fork_slot=ctx.fork_slot, sunk=sw2,
-                                    gn_src=ctx.gn_src)
+        dx1, dw2, _ = conv_backward(x1, dc2, w2, ctx.pack, ctx.needs_input_grad[0], need_dbias=False, dw_out=gw2, fork_slot=ctx.fork_slot, sunk=sw2)
         return (dx1, _grad_ret(w2, dw2, sw2), _grad_ret(b2, db2, sbias2), _grad_ret(gamma2, dgamma2, sg2), _grad_ret(beta2, dbeta2, sb2), None,
                 ds if ctx.needs_input_grad[6] else None, None, _grad_ret(gamma_t, dgamma_t, sgt), _grad_ret(beta_t, dbeta_t, sbt),
                 _grad_ret(bias_s, dbs, sbs) if want_bs else None)
@@ -1822,9 +1705,6 @@ def fork(x):
     a, b = ForkFn.apply(x, slot)
     a._mte_fork_slot = slot
     b._mte_fork_slot = slot
-    src = getattr(x, "_mte_gn", None)
-    if src is not None:                                      # (the aliases are new tensor objects: carry the producer's norm along, see conv_backward(gn_src=...))
-        a._mte_gn = b._mte_gn = src
     return a, b
 
 
@@ -1914,151 +1794,7 @@ def image_to_act(rgb, flip=False, dtype=None):
 # --------------------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------------------
-class EdgeLossFn(torch.autograd.Function):
-    """weight * class-balanced BCE of sigmoid(directional Sobel(depth) - thresh) against soft edge labels.
-    GradLoss.forward ('cross_entropy'), grad_loss.py:122-219, fused with inv2depth when from_inv."""
-
-    @staticmethod
-    def forward(ctx, pred, edge, normal, mask, weight, pos_to_neg, from_inv, is_grad, is_sigmoid, thresh, want_gmap):
-        B, _, H, W = edge.shape
-        pred, edge = pred.contiguous().float(), edge.contiguous().float()
-        normal = None if normal is None else normal.contiguous().float()
-        mask = None if mask is None else mask.contiguous().float()
-        dev = pred.device
-        sums = _zeros((lib.mte_edge_loss_sums_elems(B, H, W),), torch.float64, dev)
-        coef = torch.empty((2 * B + 1,), dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        gmap = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_gmap else None
-        st = _stream()
-        lib.mte_edge_loss_fwd(pred.data_ptr(), edge.data_ptr(), _ptr(normal), _ptr(mask), sums.data_ptr(), _ptr(gmap),
-                              B, H, W, int(from_inv), int(is_grad), int(is_sigmoid), float(thresh), st)
-        lib.mte_edge_loss_finalize(sums.data_ptr(), B, edge.numel(), float(weight), float(pos_to_neg), int(mask is not None),
-                                   1.0, 0, loss.data_ptr(), coef.data_ptr(), st)
-        ctx.save_for_backward(pred, edge, normal, mask, coef)
-        ctx.cfg = (B, H, W, int(from_inv), int(is_grad), int(is_sigmoid), float(thresh))
-        if want_gmap:
-            ctx.mark_non_differentiable(gmap)
-        return loss, gmap
-
-    @staticmethod
-    def backward(ctx, gloss, _g):
-        pred, edge, normal, mask, coef = ctx.saved_tensors
-        B, H, W, from_inv, is_grad, is_sigmoid, thresh = ctx.cfg
-        dpred = torch.empty_like(pred)
-        gl = gloss.contiguous().float()
-        lib.mte_edge_loss_bwd(pred.data_ptr(), edge.data_ptr(), _ptr(normal), _ptr(mask), coef.data_ptr(), gl.data_ptr(),
-                              dpred.data_ptr(), B, H, W, from_inv, is_grad, is_sigmoid, thresh, _stream())
-        return (dpred,) + (None,) * 10
 
 
-class BilinearResizeFn(torch.autograd.Function):
-    """F.interpolate(x, size=(H, W), mode='bilinear') for fp32 [B,1,h,w] maps -- the resize GradLoss.forward applies when the
-    prediction and the label differ in size (grad_loss.py:127)."""
-
-    @staticmethod
-    def forward(ctx, x, H, W):
-        x = x.contiguous().float()
-        B, C, h, w = x.shape
-        y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-        lib.mte_resize_bilinear_fwd(x.data_ptr(), y.data_ptr(), B * C, h, w, H, W, _stream())
-        ctx.geom = (B, C, h, w, H, W)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        B, C, h, w, H, W = ctx.geom
-        dy = dy.contiguous().float()
-        dx = torch.empty((B, C, h, w), dtype=torch.float32, device=dy.device)
-        lib.mte_resize_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), B * C, h, w, H, W, _stream())
-        return dx, None, None
-
-
-class _EdgeScale(ctypes.Structure):       # mte_edge_scale of include/mte_kernels.h
-    _fields_ = [("pred", ctypes.c_void_p), ("edge", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("mask", ctypes.c_void_p),
-                ("gmap", ctypes.c_void_p), ("dpred", ctypes.c_void_p), ("H", ctypes.c_int), ("W", ctypes.c_int)]
-
-
-class DepthLossesFn(torch.autograd.Function):
-    """Every loss term of SemiSupEdgeModel.forward (models/SemiSupEdgeModel.py:137-151) in ONE forward and ONE backward launch:
-    the depth-edge loss of all scales (compute_edge_loss_with_all_scales, :164-198; GradLoss 'cross_entropy' fused with
-    inv2depth) and, when `gt_depth` is given, the sparse silog loss of scale 0 -- both read the same inverse-depth maps.
-    -> fp32 [S] (+1): weight * balanced BCE per scale, then the silog loss when gt_depth is given."""
-
-    @staticmethod
-    def forward(ctx, weight, pos_to_neg, thresh, from_inv, mask, gt_depth, edges, normals, *preds):
-        S = len(preds)
-        B = preds[0].shape[0]
-        dev = preds[0].device
-        preds = [p.contiguous().float() for p in preds]
-        edges = [e.contiguous().float() for e in edges]
-        normals = [None if n is None else n.contiguous().float() for n in normals]
-        mask = None if mask is None else mask.contiguous().float()
-        if mask is not None and any(tuple(mask.shape[-2:]) != tuple(p.shape[-2:]) for p in preds):
-            raise MteError("one full-resolution mask for every scale is an upstream bug that only works with mask=None")
-        gt = None if gt_depth is None else gt_depth.contiguous().float()
-        arr = (_EdgeScale * S)()
-        for o, p, e, n in zip(arr, preds, edges, normals):
-            if tuple(p.shape) != tuple(e.shape) or (n is not None and tuple(n.shape) != tuple(e.shape)):
-                raise MteError("prediction / label shapes differ: %s vs %s" % (tuple(p.shape), tuple(e.shape)))
-            o.pred, o.edge, o.normal, o.mask = p.data_ptr(), e.data_ptr(), _ptr(n), _ptr(mask)
-            o.gmap = o.dpred = None
-            o.H, o.W = p.shape[-2], p.shape[-1]
-        work = _zeros((lib.mte_edge_loss_work_elems(ctypes.addressof(arr), S, B),), torch.float64, dev)
-        losses = torch.empty((S + (1 if gt is not None else 0),), dtype=torch.float32, device=dev)
-        coef = torch.empty((S * (2 * B + 1),), dtype=torch.float32, device=dev)
-        aux = torch.empty((2,), dtype=torch.float32, device=dev) if gt is not None else None
-        lib.mte_edge_loss_multi_fwd(ctypes.addressof(arr), S, B, int(from_inv), 1, 1, float(thresh), float(weight), float(pos_to_neg),
-                                    _ptr(gt), work.data_ptr(), losses.data_ptr(), coef.data_ptr(),
-                                    losses.data_ptr() + 4 * S if gt is not None else 0, _ptr(aux), _stream())
-        ctx.save_for_backward(coef, mask, gt, aux, *preds, *edges, *[n for n in normals if n is not None])
-        ctx.cfg = (S, B, int(from_inv), float(thresh), [n is not None for n in normals])
-        return losses
-
-    @staticmethod
-    def backward(ctx, glosses):
-        S, B, from_inv, thresh, has_n = ctx.cfg
-        coef, mask, gt, aux = ctx.saved_tensors[:4]
-        rest = ctx.saved_tensors[4:]
-        preds, edges, nrm = rest[:S], rest[S:2 * S], list(rest[2 * S:])
-        normals = [nrm.pop(0) if h else None for h in has_n]
-        dpreds = [torch.empty_like(p) for p in preds]
-        arr = (_EdgeScale * S)()
-        for o, p, e, n, d in zip(arr, preds, edges, normals, dpreds):
-            o.pred, o.edge, o.normal, o.mask, o.gmap, o.dpred = p.data_ptr(), e.data_ptr(), _ptr(n), _ptr(mask), None, d.data_ptr()
-            o.H, o.W = p.shape[-2], p.shape[-1]
-        gl = glosses.contiguous().float()
-        lib.mte_edge_loss_multi_bwd(ctypes.addressof(arr), S, B, from_inv, 1, 1, thresh, coef.data_ptr(), gl.data_ptr(), _ptr(gt),
-                                    _ptr(aux), gl.data_ptr() + 4 * S if gt is not None else 0, _stream())
-        return (None,) * 8 + tuple(dpreds)
-
-
-class SilogFn(torch.autograd.Function):
-    """10*sqrt(mean(d^2) - 0.85*mean(d)^2), d = log(10(inv+1e-5)) - log(10/depth) over depth > 0
-    (SupervisedLoss 'sparse-silog' at scale 0: supervised_loss.py:57-69,155-216 + depth2inv)."""
-
-    @staticmethod
-    def forward(ctx, inv, depth):
-        inv, depth = inv.contiguous().float(), depth.contiguous().float()
-        dev = inv.device
-        sums = torch.empty((3,), dtype=torch.float64, device=dev)
-        aux = torch.empty((2,), dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        lib.mte_silog_fwd(inv.data_ptr(), depth.data_ptr(), inv.numel(), sums.data_ptr(), 1.0, 0, loss.data_ptr(), aux.data_ptr(), _stream())
-        ctx.save_for_backward(inv, depth, aux)
-        return loss
-
-    @staticmethod
-    def backward(ctx, gloss):
-        inv, depth, aux = ctx.saved_tensors
-        dinv = torch.empty_like(inv)
-        gl = gloss.contiguous().float()
-        lib.mte_silog_bwd(inv.data_ptr(), depth.data_ptr(), aux.data_ptr(), gl.data_ptr(), dinv.data_ptr(), inv.numel(), 0, _stream())
-        return dinv, None
-
-
-def adam_step_flat(p, g, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, gscale=1.0):
-    """In-place fused Adam over flat fp32 device buffers."""
-    _require_gpu(p)
-    lib.mte_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]),
-                      float(eps), int(step), float(gscale), _stream())
-    bump_weights_epoch()
+# ---- the loss-side / optimizer-side bindings live in kernels_loss.py (round 6); re-exported so that `kernels.<name>` keeps working
+from .kernels_loss import EdgeLossFn, BilinearResizeFn, DepthLossesFn, SilogFn, _EdgeScale, adam_step_flat  # noqa: E402,F401

@@ -110,8 +110,8 @@ class ResidualConv(nn.Module):
         x = _enter(x, sc.in_channels)
         xa, xb = K.fork(x)
         y1 = self.conv1(xa)
-        # (its bias gradient comes out of the tail's backward pass; the launch itself runs beside conv1 / conv2 on the side stream)
-        s = K.ConvFn.apply(xb, sc.weight, sc.bias, sc.pack, False, torch.is_grad_enabled() and self.training)
+        # (its bias gradient comes out of the tail's backward pass)
+        s = K.ConvFn.apply(xb, sc.weight, sc.bias, sc.pack, False)
         if channel_scale is None and self.dropout and self.training:
             channel_scale = K.dropout2d_scale(x.shape[0], sc.out_channels, self.dropout, x.device)
         B, _, H, W = x.shape

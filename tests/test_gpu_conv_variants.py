@@ -66,6 +66,30 @@ def test_patch_kernels_match_generic_igemm(shape):
     assert rel_err(a["db"], r["db"]) < 1e-5
 
 
+PATCH_M16_SHAPES = [(32, 32, 7, 2, 16, 64), (128, 32, 7, 1, 18, 32), (256, 64, 5, 1, 12, 64), (48, 56, 5, 2, 9, 32), (64, 64, 3, 2, 16, 32), (32, 64, 1, 2, 8, 64),
+                    (72, 32, 3, 1, 20, 32), (136, 64, 3, 1, 11, 64), (65, 32, 3, 1, 9, 96), (64, 32, 3, 2, 10, 32)]
+
+
+@pytest.mark.parametrize("shape", PATCH_M16_SHAPES)
+def test_patch_forward_mfma_shapes_agree(shape, devlib):
+    """round 6: every LDS-patch forward form runs on v_mfma_f32_16x16x32_bf16; the 32x32x16 forms of rounds 1-5 live on in the development library (knobs
+    11 = 500 / 600 / 700).  Same products, fp32 sums in another order inside the instruction: outputs and data gradients within one bf16 rounding."""
+    cin, cout, k, B, H, W = shape
+
+    def run(m16):
+        for base in (500, 600, 700):
+            devlib.mte_debug_set(11, base + m16)
+        try:
+            return _run(cin, cout, k, B, H, W, patch=True)
+        finally:
+            for base in (500, 600, 700):
+                devlib.mte_debug_set(11, base + 1)
+
+    a, r = run(1), run(0)
+    assert rel_err(a["y"], r["y"]) < 8e-3
+    assert rel_err(a["dx"], r["dx"]) < 8e-3
+
+
 @pytest.mark.parametrize("shape", SHAPES[:6] + [(512, 512, 3, 2, 4, 8), (256, 8, 3, 1, 6, 10)])
 def test_generic_igemm_fp32_matches_torch_cpu(shape):
     r = _run(*shape, patch=False, dtype="fp32")
@@ -260,7 +284,8 @@ def test_eight_phase_igemm_against_the_128x128_tile(devlib, shape, order):
     23 = 7, 24 = 1), repeatedly (a stale LDS slot or a fragment read that overtakes its DMA shows on some repetitions only), with and without
     accumulation into the output and through a channel-slice output.
       tap-major (knob bit 5: the K order of every other tile form): the same K-steps in the same order -> the 4-wave 128 x 128 kernel BIT FOR BIT;
-      slice-major (round 5, the product's order where Cin_p % 64 == 0: 64-channel slice outer, taps inner): bit-identical from run to run, and to the
+      slice-major (round 5, a DEVELOPMENT option -- the shipped default is tap-major, knob 23 = 51, and the product library returns MTE_ERR_UNSUPPORTED for
+      ConvArgs.kslice; 64-channel slice outer, taps inner, where Cin_p % 64 == 0): bit-identical from run to run, and to the
       128 x 128 kernel within one bf16 rounding of the output (another order of the same fp32 sum); shapes whose channels do not allow it run tap-major.
     Split-K (another grouping of the fp32 sums): bitwise against itself, one bf16 rounding against the unsplit result."""
     from mindtheedge_amd import kernels as K
@@ -313,6 +338,45 @@ def test_eight_phase_igemm_against_the_128x128_tile(devlib, shape, order):
     finally:
         K._splitk_workspace = saved
         devlib.mte_debug_set(23, 51); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
+        K.use_patch_kernels(True)
+
+
+@pytest.mark.parametrize("shape", [s_ for s_ in IGEMM8_SHAPES if ((s_[0] + 7) // 8 * 8) % 64 == 0])
+def test_eight_phase_one_tap_state_loop_matches_the_two_state_loop(devlib, shape):
+    """round-5 advisor: the shipped default of conv_igemm8_kernel where Cin_p % 64 == 0 is the ONE form (both K-halves of a K-tile from one tap state,
+    g_igemm8_one = 1) -- it had no on / off test of its own.  Development knob 28 = 0 runs the general two-state loop on the same launch: the same K-steps in
+    the same order, so the outputs must be bit-identical -- unsplit, accumulating, and under split-K (where the ONE form also needs an even K-step count per
+    split: the launcher's own rule decides, the test only flips the knob)."""
+    from mindtheedge_amd import kernels as K
+    cin, cout, k, B, H, W, ldx = shape
+    K.set_compute_dtype("bf16")
+    K.use_patch_kernels(False)
+    saved = K._splitk_workspace
+    try:
+        g = torch.Generator().manual_seed(5 + cin + cout)
+        w = ((torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * (3.0 / (cin * k * k)) ** 0.5).cuda()
+        b = (torch.rand(cout, generator=g) - 0.5).cuda()
+        buf = K.new_act(B, ldx or cin, H, W)
+        buf.copy_((torch.rand(B, ldx or cin, H, W, generator=g) * 2 - 1).cuda())
+        x = K.channel_slice(buf, 0, cin) if ldx else buf
+        wf, _ = K.WeightPack().get(w, x.dtype, True)
+        y0 = K.new_act(B, cout, H, W)
+        y0.copy_(torch.randn(B, cout, H, W, generator=g).cuda())
+        devlib.mte_debug_set(23, 7 | 32); devlib.mte_debug_set(6, 0)
+
+        def run(one, split, accumulate):
+            devlib.mte_debug_set(28, one); devlib.mte_debug_set(24, 1000000 if split else 1)
+            K._splitk_workspace = (lambda M, N, dev: (torch.empty((8 * M * N,), dtype=torch.float32, device=dev), 8 * M * N)) if split else (lambda *a: (None, 0))
+            out = y0.clone()
+            K.conv_forward(x, wf, b, cout, k, k, out=out, accumulate=accumulate)
+            torch.cuda.synchronize()
+            return out
+
+        for split, accumulate in ((False, False), (False, True), (True, False)):
+            assert torch.equal(run(1, split, accumulate), run(0, split, accumulate)), (shape, split, accumulate)
+    finally:
+        K._splitk_workspace = saved
+        devlib.mte_debug_set(28, 1); devlib.mte_debug_set(23, 51); devlib.mte_debug_set(24, 200); devlib.mte_debug_set(6, 3)
         K.use_patch_kernels(True)
 
 

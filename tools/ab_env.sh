@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of one environment switch of the host side (development aid): ab_env.sh VAR [reps]   e.g. ab_env.sh MTE_GN_BWD_IN_CONV 2
+# same-box A/B of one environment switch of the host side (development aid): ab_env.sh VAR [reps]   e.g. ab_env.sh MTE_GN_IN_CONV 2
 v=$1; n=${2:-2}
 for i in $(seq 1 $n); do for f in 0 1; do
   env $v=$f python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
