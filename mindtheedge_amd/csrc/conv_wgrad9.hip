@@ -112,19 +112,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
         voffY = (unsigned)((((long)dr * a.W + dc) * a.ldy + n0 + c * 8) * 2);
     }
     unsigned voffX[2];
-    bool realX[2], rowTop[2], rowBot[2], colL[2], colR[2];
+    // wave-uniform flags of the two patch pieces, 5 bits each, in ONE scalar register (round 6: as ten bools the compiler kept per-lane copies of their products
+    // with the lane halves in VGPRs -- the kernel sits at exactly 256 -- and SPILLED them: three scratch reloads, each behind an s_waitcnt vmcnt(0) that drained
+    // the DMA ring, on every K-step that re-classifies its lanes: 3 of a column's 12-24):
+    //   bit 0 real piece | 1 / 2 the patch row above / below the K-step's own rows | 3 / 4 the piece holds the patch's left / right alignment columns (its lanes
+    //   (lane >> 3) < 4 resp. >= 4 lie left / right of the K-step's own columns + 1)
+    unsigned fl = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pc = wv + 8 * j;                    // patch piece
-        realX[j] = pc < NX;
         const int pr = pc / PB, pb = pc - pr * PB;
         const int px = pb * 8 + (lane >> 3), c = (lane & 7) ^ swz_x(px);
-        rowTop[j] = pr == 0; rowBot[j] = pr == PR - 1;                 // the patch rows above / below the K-step's own rows (wave-uniform)
-        colL[j] = pb == 0; colR[j] = pb == PB - 1;                     // the pieces that hold the patch's alignment columns (wave-uniform): their lanes
-                                                                        // (lane >> 3) < 4 resp. >= 4 lie left / right of the K-step's own columns + 1
+        fl |= ((unsigned)(pc < NX) | ((unsigned)(pr == 0) << 1) | ((unsigned)(pr == PR - 1) << 2) | ((unsigned)(pb == 0) << 3) | ((unsigned)(pb == PB - 1) << 4)) << (8 * j);
         // (the descriptor's base sits (W + 4) pixels in front of the tensor: every lane offset is non-negative)
         voffX[j] = (unsigned)((((long)pr * a.W + px) * a.ldx + c0 + c * 8) * 2);
     }
+    fl = (unsigned)__builtin_amdgcn_readfirstlane((int)fl);
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) void* lptr_t;
     const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((((long)a.B * a.H * a.W - 1) * a.ldy + a.N) * 2), 0x00020000);
@@ -148,9 +151,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
         voY = live ? voffY : OOB9;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            // (bitwise on purpose: `||` over lane-varying operands becomes divergent control flow)
-            const bool bad = (!live) | (!realX[j]) | (top & rowTop[j]) | (bot & rowBot[j]) | (left & colL[j] & (lane < 32)) | (right & colR[j] & (lane >= 32));
-            voX[j] = bad ? OOB9 : voffX[j];
+            // scalar: the whole piece, its lower / upper lane half; then ONE 64-bit lane mask and a shift per lane (no per-lane state beside `lane`)
+            const unsigned f = fl >> (8 * j);
+            const bool all_bad = (!live) | (!(f & 1u)) | (top & (bool)((f >> 1) & 1u)) | (bot & (bool)((f >> 2) & 1u));
+            const bool lo_bad = left & (bool)((f >> 3) & 1u), hi_bad = right & (bool)((f >> 4) & 1u);
+            const unsigned long long m = all_bad ? ~0ull : ((lo_bad ? 0x00000000ffffffffull : 0ull) | (hi_bad ? 0xffffffff00000000ull : 0ull));
+            voX[j] = ((m >> lane) & 1ull) ? OOB9 : voffX[j];
         }
     };
     locate(); classify();

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void gn_elu_bwd_reduce_kernel(GnArgs a) {
 // M2: 0 = one input; 1 = v = y1 + scale2 * y2 (HAS2: the second tensor is read); 2 (round 5) = one input, but the gradient leaves twice:
 //     d1 = dv and d2 = scale2[b,c] * dv (and dbias = column sums of d2) -- the residual tail after mte_gn_tail_fwd, whose input is the stored sum.
 template <typename T, int M2, bool HASDB>
-__global__ __launch_bounds__(256) void gn_elu_bwd_apply_kernel(GnArgs a) {
+__global__ __launch_bounds__(256, M2 == 1 ? 3 : 4) void gn_elu_bwd_apply_kernel(GnArgs a) {      // (4: left alone, the two-output form M2 = 2 took 144 VGPRs = three waves per SIMD; the two-input form would spill at 128)
     constexpr bool HAS2 = M2 == 1, SCL = M2 != 0;
     GN_THREAD_MAP();
     extern __shared__ float s_db[];                       // [C] when HASDB
