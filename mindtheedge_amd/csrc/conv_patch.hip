@@ -270,67 +270,78 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd_kernel(PatchArgs a) {
         }
         asm volatile("" ::: "memory");                             // (the patch staging registers are not live beside the fragment set)
     }
+    const u32x4_t* wl = (const u32x4_t*)a.wp + lane;               // fragment block = 64 lanes x 16 B
+    // weight fragments come straight from L2 (hundreds of cycles): PD taps in flight in a register ring; fragment kk (M16: 16-channel half) of tap t of slice s
+    constexpr int PD = TAPS < 4 ? TAPS : 4;
+    u32x4_t bq[PD][2];
+    auto wload = [&](int s, int t, int kk) {
+        if constexpr (M16) return *(const u32x4_t*)((const char*)a.wp + (long)(s * TAPS + t) * (2 * NT * 1024) + w16off + kk * 256);
+        else return wl[(((long)(s * TAPS + t) * 2 + kk) * NT + nsel) * 64];
+    };
+    // one tap: fragments of the MM pixel rows at the tap's shift, MM x 2 (M16: x 4) MFMAs against ring slot d
+    auto tap_mfmas = [&](const char* P, int t, int d) {
+        const int dy = t / K, dx = t - dy * K;
+        u32x4_t fa[MM][2];
+        if constexpr (M16) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int p = (mrow0 + m + dy) * PW + dx + 16 * ph + c16;
+                    fa[m][ph] = *(const u32x4_t*)(P + p * 64 + ((g16 ^ ((p >> 1) & 2)) << 4));
+                }
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+                        acc16[m][c][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[d][c]),
+                                                                                  __builtin_bit_cast(bf16x8_t, fa[m][ph]), acc16[m][c][ph], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const int p = (mrow0 + m + dy) * PW + dx + r;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
+            }
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]),
+                                                                     __builtin_bit_cast(bf16x8_t, bq[d][kk]), acc[m], 0, 0, 0);
+        }
+    };
     load_patch(0);
     store_patch(0);
     __syncthreads();
     PATCH_STAMP();
-    const u32x4_t* wl = (const u32x4_t*)a.wp + lane;               // fragment block = 64 lanes x 16 B
     MTE_CLOCK_BEGIN()
     for (int s = 0; s < nslices; ++s) {
         const char* P = smem + (s & 1) * PBYTES;
         if (s + 1 < nslices) load_patch(s + 1);
-        const u32x4_t* wsl = wl + (long)s * TAPS * 2 * NT * 64;
-        // weight fragments come straight from L2 (hundreds of cycles): keep PD taps in flight in a register ring
-        constexpr int PD = TAPS < 4 ? TAPS : 4;
-        u32x4_t bq[PD][2];
-        const char* wsl16 = (const char*)a.wp + (long)s * TAPS * (2 * NT * 1024) + w16off;      // M16: + tap * 2 NT KiB + half * 256
 #pragma unroll
         for (int d = 0; d < PD; ++d)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) bq[d][kk] = M16 ? *(const u32x4_t*)(wsl16 + d * (2 * NT * 1024) + kk * 256) : wsl[((d * 2 + kk) * NT + nsel) * 64];
+            for (int kk = 0; kk < 2; ++kk) bq[d][kk] = wload(s, d, kk);
+        if constexpr (TAPS > PD) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1                                                   // (round 5, end: unrolled over the 3x3 taps this loop needs 254 instead of 167 VGPRs -- two workgroups per CU instead of
-                                                                   //  three -- and the 64 -> 64 @192x640 forward went from 92 to 107 us: latency-bound, not issue-bound)
+                                                                   //  three -- and the 64 -> 64 @192x640 forward went from 92 to 107 us; round 6 tried again with pinned loads: 248)
         for (int t0 = 0; t0 < TAPS; t0 += PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
                 const int t = t0 + d;
-                if (t < TAPS) {                                    // wave-uniform
-                    const int dy = t / K, dx = t - dy * K;
-                    u32x4_t fa[MM][2];
-                    if constexpr (M16) {
+                if (t < TAPS) tap_mfmas(P, t, d);                  // wave-uniform
+                // Refill, UNCONDITIONAL and pinned here (round 6, tools/loopaudit.py on the round-5 loop): inside the `t + PD < TAPS` branch the compiler could not
+                // count the load and waited for vmcnt(1) / vmcnt(0) at the head of every group of PD taps -- the ring bought no prefetch across groups.  Past the
+                // last tap the slot re-reads the last tap's fragment (an L2 hit nobody waits for).
+                if constexpr (TAPS > PD) {                         // (a 1x1 has nothing to refill)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int tn = t + PD < TAPS ? t + PD : TAPS - 1;
 #pragma unroll
-                        for (int m = 0; m < MM; ++m)
-#pragma unroll
-                            for (int ph = 0; ph < 2; ++ph) {
-                                const int p = (mrow0 + m + dy) * PW + dx + 16 * ph + c16;
-                                fa[m][ph] = *(const u32x4_t*)(P + p * 64 + ((g16 ^ ((p >> 1) & 2)) << 4));
-                            }
-#pragma unroll
-                        for (int m = 0; m < MM; ++m)
-#pragma unroll
-                            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                                for (int ph = 0; ph < 2; ++ph)
-                                    acc16[m][c][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[d][c]),
-                                                                                              __builtin_bit_cast(bf16x8_t, fa[m][ph]), acc16[m][c][ph], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < MM; ++m) {
-                            const int p = (mrow0 + m + dy) * PW + dx + r;
-#pragma unroll
-                            for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *(const u32x4_t*)(P + swz_off(p, 2 * kk + h));
-                        }
-#pragma unroll
-                        for (int m = 0; m < MM; ++m)
-#pragma unroll
-                            for (int kk = 0; kk < 2; ++kk)
-                                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[m][kk]),
-                                                                                 __builtin_bit_cast(bf16x8_t, bq[d][kk]), acc[m], 0, 0, 0);
-                    }
-                    if (t + PD < TAPS) {
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) bq[d][kk] = M16 ? *(const u32x4_t*)(wsl16 + (t + PD) * (2 * NT * 1024) + kk * 256) : wsl[(((t + PD) * 2 + kk) * NT + nsel) * 64];
-                    }
+                    for (int kk = 0; kk < 2; ++kk) bq[d][kk] = wload(s, tn, kk);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -749,7 +760,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
                 for (int dy = 0; dy < K; ++dy) {
                     if (dy + 1 < K) PF2_LDROW(dy + MM, (dy + MM) % WR, dx)     // next tap row's new pixel row, a tap ahead of its first MFMA
                     PF2_MFMAS(dy, bq[dy])
-                    // refill: the same tap row of the next column, or of the next slice's first column
+                    // refill: the same tap row of the next column, or of the next slice's first column.  The scheduling barriers pin the loads HERE (round 6: the
+                    // compiler had sunk all 2 K refills of a column behind its last MFMA -- the ring then held a column's fragments for ~25 instructions instead of
+                    // a column's worth of MFMAs, and every column opened with an exposed L2 round trip: tools/loopaudit.py, profiles/r06_ring_refills.txt)
+                    __builtin_amdgcn_sched_barrier(0);
                     if (!last_column) {
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) bq[dy][kk] = wfrag(s, dy * K + dx + 1, kk);
@@ -757,6 +771,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_fwd2_kernel(PatchArgs a) {
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) bq[dy][kk] = wfrag(s + 1, dy * K, kk);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
 #pragma unroll 1
