@@ -504,6 +504,35 @@ struct P3LArgs {
     int dshift, tshift;                // matrix-core weight gradient: log2(depth pairs per pixel) or -1 when not a power of two; log2(TW)
 };
 
+// Tile fill, FU chunks per thread in flight (round 6).  The plain `for (idx ...) { v = in-image ? load : 0; store to LDS; }` loops of these kernels compiled to
+// load -> s_waitcnt vmcnt(0) -> ds_write per iteration (tools/loopaudit.py): a workgroup walked ~11 DEPENDENT memory round trips per staged plane.  Here a batch
+// issues FU unguarded loads from clamped (always valid) addresses, selects zeros for the out-of-image chunks and then stores: one round trip per FU chunks.
+//   chunk idx -> (pixel p = idx / cpr of the (rows x PW) tile with origin (h0 - 1, w0 - 1), 16-byte chunk dc = idx % cpr of the pixel's `cpr` chunks)
+//   src: element offset of chunk 0 of image pixel (0, 0) of sample b (+ plane offset); pixel stride ld; image Hi x Wi; LDS pixel stride lds_stride elements
+template <int FU>
+__device__ __forceinline__ void fill_tile_chunks(bf16_t* tile, const bf16_t* src, long ld, int Hi, int Wi, int h0, int w0, int PW, int npix, int cpr, int lds_stride) {
+    const int total = npix * cpr;
+    for (int idx0 = threadIdx.x; idx0 < total; idx0 += (int)blockDim.x * FU) {
+        u32x4_t v[FU];
+        int off[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int idx = idx0 + u * (int)blockDim.x;
+            const int ii = idx < total ? idx : total - 1;
+            const int dc = ii % cpr, p = ii / cpr;
+            const int hh = h0 - 1 + p / PW, ww = w0 - 1 + p % PW;
+            const bool in = (unsigned)hh < (unsigned)Hi && (unsigned)ww < (unsigned)Wi;
+            const int hc = min(max(hh, 0), Hi - 1), wc = min(max(ww, 0), Wi - 1);
+            const u32x4_t t = *(const u32x4_t*)(src + ((long)hc * Wi + wc) * ld + dc * 8);
+            v[u] = in ? t : u32x4_t{0u, 0u, 0u, 0u};
+            off[u] = p * lds_stride + dc * 8;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (idx0 + u * (int)blockDim.x < total) *(u32x4_t*)(tile + off[u]) = v[u];
+    }
+}
+
 // stage packed P tile: tile[(ph)][(pw)][d], d = 4c + s, origin (h0-1, w0-1), zero outside the image.
 // One work item = (packed pixel, 8 channels): the four sub-pixel chunks are loaded as 16 bytes each, interleaved in registers
 // (depth d = 4c + s: word k of the 32 consecutive depths pairs sub-pixels 2(k&1), 2(k&1)+1 of channel k>>1) and stored as four
@@ -617,14 +646,7 @@ __global__ __launch_bounds__(256) void pack3d_bwd_data_lds_kernel(P3LArgs a) {
 #pragma unroll 1
     for (int f = 0; f < 4; ++f) {
         __syncthreads();                                   // previous plane fully consumed
-        for (int idx = threadIdx.x; idx < npix * cpp; idx += 256) {
-            const int dc = idx % cpp; const int p = idx / cpp;
-            const int hh = h0 - 1 + p / PW, ww = w0 - 1 + p % PW;
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if ((unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2)
-                v = *(const u32x4_t*)(a.o + (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + dc * 8);
-            *(u32x4_t*)(tile + p * LDP(D) + dc * 8) = v;
-        }
+        fill_tile_chunks<6>(tile, a.o + (long)b * H2 * W2 * a.ldo + f * D, a.ldo, H2, W2, h0, w0, PW, npix, cpp, LDP(D));
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -1580,14 +1602,7 @@ __global__ __launch_bounds__(512) void conv3d_bwd_weight_mfma_kernel(P3LArgs a) 
         if constexpr (UNPACK) up_tile_coords(a, tl, b, h0, w0); else tile_coords(a, tl, b, h0, w0);
         __syncthreads();
         if constexpr (UNPACK) {
-            for (int idx = threadIdx.x; idx < npix * dbs; idx += blockDim.x) {
-                const int dc = idx % dbs; const int p = idx / dbs;
-                const int hh = h0 - 1 + p / PW, ww = w0 - 1 + p % PW;
-                u32x4_t v = {0u, 0u, 0u, 0u};
-                if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W)
-                    v = *(const u32x4_t*)(a.x + (((long)b * a.H + hh) * a.W + ww) * a.ldx + dc * 8);
-                *(u32x4_t*)(tile + p * LDP(D) + dc * 8) = v;
-            }
+            fill_tile_chunks<4>(tile, a.x + (long)b * a.H * a.W * a.ldx, a.ldx, a.H, a.W, h0, w0, PW, npix, dbs, LDP(D));
         } else {
             stage_packed_tile(a, tile, b, h0, w0);
         }
