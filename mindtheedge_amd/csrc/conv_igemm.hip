@@ -284,7 +284,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
     const int wm = wave / WN, wn = wave % WN;
 #if MTE_IGEMM_MFMA16
     static_assert(ABL == 0, "the ablation arms exist for the 32x32x16 form only");
-    // a wave's (TM*32) x (TN*32) sub-tile as 2TM x 2TN blocks of 16 x 16: D[row = 4 * (lane >> 4) + e][col = lane & 15]
+    // a wave's (TM*32) x (TN*32) sub-tile as 2TM x 2TN blocks of 16 x 16.  Round 6: the operands are swapped (D = W X^T, as in conv_igemm8.hip and the LDS-patch
+    // kernels): a lane holds 4 CONSECUTIVE output channels 4 q16 + e of pixel r16, so the tile is staged with one 8-byte LDS write per block instead of four 2-byte
+    // ones that fell on the same banks, and the split-K / fp32 epilogues store 16 contiguous bytes.  Same products, same K order: bit-identical results.
     constexpr int AM = TM * 2, AN = TN * 2;
     f32x4_t acc[AM][AN];
 #pragma unroll
@@ -305,12 +307,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
 #pragma unroll
         for (int i = 0; i < AM; ++i)
 #pragma unroll
-            for (int j = 0; j < AN; ++j) Mma16<T>::run(fa[i], fb[j], acc[i][j]);
+            for (int j = 0; j < AN; ++j) Mma16<T>::run(fb[j], fa[i], acc[i][j]);
     };
     auto compute = [&](int slot) { read_frags(slot); mfmas(); };
-    // element e of block (i, j): tile row / column
-    auto acc_row = [&](int i, int e) { return (wm * AM + i) * 16 + 4 * q16 + e; };
-    auto acc_col = [&](int j) { return (wn * AN + j) * 16 + r16; };
+    // element e of block (i, j): tile row (pixel) / column (channel)
+    auto acc_row = [&](int i, int e) { (void)e; return (wm * AM + i) * 16 + r16; };
+    auto acc_col = [&](int j, int e) { return (wn * AN + j) * 16 + 4 * q16 + e; };
     constexpr int AE = 4;
 #else
     constexpr int AM = TM, AN = TN;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
         }
     };
     auto acc_row = [&](int i, int e) { return (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h; };
-    auto acc_col = [&](int j) { return (wn * TN + j) * 32 + r; };
+    auto acc_col = [&](int j, int e) { (void)e; return (wn * TN + j) * 32 + r; };
     constexpr int AE = 16;
 #endif
     if constexpr (DMA) {
@@ -437,7 +439,26 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
         unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_cmp = 0, t_a, t_b;
         const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
-        for (int i = 0; i < nst; ++i) {
+        int i = 0;
+#ifndef MTE_STAMPS
+        // Round 6: steady state in groups of ST K-steps with COMPILE-TIME ring slots.  tools/loopaudit.py on the rolled loop: ~48 scalar + 5 vector instructions per
+        // 16 MFMAs and K-step -- two divisions by ST for the slots (s_mul_hi), slot address arithmetic, the rem ladder -- with four waves per SIMD that is more issue
+        // slots than the MFMAs leave (profiles/r05_wgrad9_steps.txt: one instruction per ~4 cycles per SIMD for all of its waves).  While a whole group and the AHEAD
+        // stages it issues exist, no `rem` test is needed: the wait is the constant (AHEAD - 1) * LPS, the slots are u and (u + AHEAD) % ST.  The rolled loop
+        // below finishes the last < ST + AHEAD K-steps.  Same K-steps in the same order: bit-identical.
+        if constexpr (LD == 2 && ABL == 0) {
+            for (; i + ST + AHEAD <= nst; i += ST) {
+#pragma unroll
+                for (int u = 0; u < ST; ++u) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LPS) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    dma_fast(s_begin + i + u + AHEAD, (u + AHEAD) % ST);
+                    compute(u);
+                }
+            }
+        }
+#endif
+        for (; i < nst; ++i) {
 #ifdef MTE_STAMPS
             t_a = __builtin_amdgcn_s_memtime();
 #endif
@@ -505,17 +526,45 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             constexpr int ES = (int)sizeof(T);
             static_assert(BM * BN * ES <= ST * (BM + BN) * 64, "output tile must fit the ring");
             __syncthreads();                              // every wave is done reading the ring
+            // staged image: 16-byte chunk c of tile row r at slot (c + r) % CPR_ -- the 16 lanes of a block write 16 different rows at the same chunk, the rotation
+            // spreads them over the banks (the read side below undoes it)
+            constexpr int CPR_ = BN / PER16;
+#if MTE_IGEMM_MFMA16
 #pragma unroll
             for (int j = 0; j < AN; ++j) {
-                const int col = acc_col(j);
+                const int col0 = acc_col(j, 0);
+                float bv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = (a.bias && n0 + col0 + e < a.N) ? a.bias[n0 + col0 + e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < AM; ++i) {
+                    const int row = acc_row(i, 0);
+                    char* dst = smem + (row * BN) * ES + (((col0 / PER16) + row) % CPR_) * 16 + (col0 % PER16) * ES;
+                    if constexpr (sizeof(T) == 2) {
+                        uint2 pk;
+                        pk.x = pack2bf(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]);
+                        pk.y = pack2bf(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]);
+                        *(uint2*)dst = pk;
+                    } else {
+                        *(f32x4_t*)dst = f32x4_t{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                    }
+                }
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < AN; ++j) {
+                const int col = acc_col(j, 0);
                 const int n = n0 + col;
                 const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
                 for (int i = 0; i < AM; ++i)
 #pragma unroll
-                    for (int e = 0; e < AE; ++e)
-                        Elem<T>::st((T*)(smem + (acc_row(i, e) * BN + col) * ES), acc[i][j][e] + bv);
+                    for (int e = 0; e < AE; ++e) {
+                        const int row = acc_row(i, e);
+                        Elem<T>::st((T*)(smem + (row * BN) * ES + (((col / PER16) + row) % CPR_) * 16 + (col % PER16) * ES), acc[i][j][e] + bv);
+                    }
             }
+#endif
             __syncthreads();
             constexpr int CPR = BN / PER16;                // 16-B chunks per tile row
             const int cvalid = (a.N - n0) / PER16;         // chunks of this tile inside N (N % 8 == 0)
@@ -526,7 +575,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
                 const long m = m0 + row;
                 if (m < Mrows && cc < cvalid) {
                     const long pm = a.rows ? (long)a.rows[m] : m;      // output pixel of this tile row
-                    u32x4_t c = *(const u32x4_t*)(smem + (row * BN + cc * PER16) * ES);
+                    u32x4_t c = *(const u32x4_t*)(smem + (row * BN) * ES + ((cc + row) % CPR) * 16);
                     if (a.accum) {
                         float vn[PER16], vo[PER16];
                         unpack16<T>(c, vn);
@@ -545,13 +594,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
     // ---- epilogue: D[row][col]: col = lane&31 (channel n), row = (e&3) + 8*(e>>2) + 4*h (pixel m)
 #pragma unroll
     for (int j = 0; j < AN; ++j) {
-        const int n = n0 + acc_col(j);
-        if (n >= a.N) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < AM; ++i) {
 #pragma unroll
             for (int e = 0; e < AE; ++e) {
+                const int n = n0 + acc_col(j, e);
+                if (n >= a.N) continue;
+                const float bv = a.bias ? a.bias[n] : 0.f;
                 const long m = m0 + acc_row(i, e);
                 if (m < Mrows) {
                     const float v = acc[i][j][e] + bv;
