@@ -502,7 +502,7 @@ def prefetch_weight_packs():
     packs.sort(key=lambda pk: pk._order)
     if _side["enabled"]:
         if not _side["streams"]:
-            _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
+            _side["streams"] = [_new_side_stream() for _ in range(max(1, _SIDE_STREAMS))]
         side = _side["streams"][0]
         ev = torch.cuda.Event()
         ev.record()                                          # the parameter update (and every earlier user of the packs)
@@ -681,6 +681,20 @@ _CONV_SOLO = 2      # MTE_CONV_SOLO: the forward pass has no weight-gradient ker
 # (bucketed all-reduce).
 _side = {"enabled": True, "streams": [], "next": 0, "keep": [], "keep_bytes": 0, "callback_queued": False, "dirty": False}
 lib.set_option(3, 1, lazy=True)
+def _new_side_stream():
+    """the weight-gradient queue, one HIP priority level BELOW the main queue: the step waits for the main queue, whose one-workgroup-per-CU kernels lose a whole
+    second round of workgroups to every CU the side queue holds.  Same box, alternating, 4 x 30 steps (profiles/r06_side_priority.txt): equal priority 21.60-21.69 ms,
+    below 21.49-21.61, above 21.70.  MTE_SIDE_PRIORITY (development): 0 = equal, -1 = above."""
+    pr = int(os.environ.get("MTE_SIDE_PRIORITY", "1"))
+    if pr == 0:
+        return torch.cuda.Stream()
+    hip = ctypes.CDLL("libamdhip64.so")
+    h = ctypes.c_void_p()
+    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, pr) != 0:           # 1 = hipStreamNonBlocking
+        raise RuntimeError("hipStreamCreateWithPriority(%d) failed" % pr)
+    return torch.cuda.ExternalStream(h.value)
+
+
 _SIDE_STREAMS = 1      # (round 5 measured two weight-gradient streams no faster than one: profiles/r05_side_queue_width.txt; the option is gone)
 _SIDE_KEEP_LIMIT = 24 << 30          # bytes of (x, dy) kept alive for the side stream before a forced join
 
@@ -740,7 +754,7 @@ def _side_stream_for(*tensors):
     """-> side stream (after making it wait for the work queued so far on the current stream), keeping `tensors` alive
     until the next join (their memory must not be recycled by main-stream allocations while the side stream reads it)."""
     if not _side["streams"]:
-        _side["streams"] = [torch.cuda.Stream() for _ in range(max(1, _SIDE_STREAMS))]
+        _side["streams"] = [_new_side_stream() for _ in range(max(1, _SIDE_STREAMS))]
     side = _side["streams"][_side["next"] % len(_side["streams"])]
     _side["next"] += 1
     ev = torch.cuda.Event()

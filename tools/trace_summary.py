@@ -14,6 +14,15 @@ with open(path) as f:
         d[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
 tot = sum(v[1] for v in agg.values())
 print("total kernel time / step: %.2f ms" % (tot / steps * 1e-3))
+# the same sum over whole steps only (adam_dev_kernel closes a step): start-up copies, weight packing and the first-call allocations stay outside
+rows = []
+with open(path) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "adam_dev_kernel" in r["Kernel_Name"]))
+ends = sorted(e for s_, e, a in rows if a)
+if len(ends) >= 2:
+    inside = sum(e - s_ for s_, e, a in rows if ends[0] < e <= ends[-1])
+    print("kernel time / step between the first and the last adam_dev_kernel (%d whole steps): %.2f ms" % (len(ends) - 1, inside * 1e-6 / (len(ends) - 1)))
 for (name, grid, lds), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 70]:
     print("%8.1f us/step %6.1f calls/step %9.1f us/call  grid=%-9s lds=%-6s %s" % (us / steps, n / steps, us / n, grid, lds, name))
 
