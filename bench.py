@@ -61,15 +61,15 @@ class ConvTimer:
         for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad",
                      "mte_conv2d_stem_fwd", "mte_conv2d_stem_wgrad", "mte_conv2d_patch_fwd_rank1", "mte_conv2d_patch_fwd_plus1x1"):
             self._orig[name] = getattr(lib, name)
-        self._optional = ("mte_gn_tail_fwd", "mte_gn_stats_from_records", "mte_conv2d_patch_fwd_gn", "mte_gn_elu_bwd_red_ready", "mte_conv2d_patch_fwd_gr", "mte_conv2d_patch_fwd_plus1x1_gr")   # (the last three: round-5 builds only)   # (entry points an older build of the library lacks: same-box A/B of two trees with ONE bench.py)
-        for name in ("mte_conv2d_patch_fwd_gn", "mte_conv2d_patch_fwd_gr", "mte_conv2d_patch_fwd_plus1x1_gr"):   # round 5: LDS-patch launches that also leave GroupNorm records
+        self._optional = ("mte_gn_tail_fwd", "mte_gn_stats_from_records", "mte_conv2d_patch_fwd_gn")   # (entry points an older build of the library lacks: same-box A/B of two libraries with ONE bench.py)
+        for name in ("mte_conv2d_patch_fwd_gn",):   # round 5: LDS-patch launches that also leave GroupNorm records
             try:
                 self._orig[name] = getattr(lib, name)
             except AttributeError:
                 pass
         self.untimed = {}               # mte_conv2d_* launches seen during the conv timing pass that are NOT in the family (a new entry point someone forgot here)
         self.hbm_records = []           # (name, e0, e1, algorithmic bytes) of the GroupNorm+ELU passes (HBM-bound family)
-        for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd", "mte_gn_tail_fwd", "mte_gn_stats_from_records", "mte_gn_elu_bwd_red_ready"):
+        for name in ("mte_gn_stats", "mte_gn_elu_fwd", "mte_gn_elu_bwd", "mte_gn_tail_fwd", "mte_gn_stats_from_records"):
             try:
                 self._orig[name] = getattr(lib, name)
             except AttributeError:
@@ -125,9 +125,6 @@ class ConvTimer:
                         if name == "mte_gn_stats_from_records":   # (rec, tiles_per_sample, stats, B, stream): reads the records
                             outer.hbm_records.append((name, e0, e1, 128.0 * args[1] * args[3]))
                             return
-                        if name == "mte_gn_elu_bwd_red_ready":    # (dz, lddz, y1, ld1, scale2, stats, gamma, beta, red, d1, ldd1, d2, ldd2, dgamma, dbeta, dbias, B, HW, C, eps, dtype, stream)
-                            outer.hbm_records.append((name, e0, e1, float(3 + bool(args[11])) * args[16] * args[17] * args[18] * (2 if args[20] == 0 else 4)))   # apply pass: read dz, y1; write d1 (+ d2)
-                            return
                         if name == "mte_gn_tail_fwd":       # (y1, ld1, stats1, gamma1, beta1, y2, ld2, scale2, t, ldt, stats_t, gamma_t, beta_t, z, ldz, B, HW, C, eps, dtype, stream)
                             (B_, HW_, C_), dt_ = args[15:18], args[19]
                             tensors = 5                                         # read y1, y2, write t; read t, write z
@@ -144,13 +141,13 @@ class ConvTimer:
                         return
                     if name == "mte_conv2d_patch_fwd_rank1":     # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, inv, w1, stride, stream): 3x3 (+ the map's 16-slot MFMA step)
                         shp = tuple(args[6:11]) + (3, 3)
-                    elif name in ("mte_conv2d_patch_fwd_plus1x1", "mte_conv2d_patch_fwd_plus1x1_gr"):  # (dy, lddy, w, bias, dx, lddx, B, H, W, Cin_p, N, dy3, lddy3, w3, C3, stream): 3x3 over Cin_p + 1x1 over C3 channels
+                    elif name == "mte_conv2d_patch_fwd_plus1x1":  # (dy, lddy, w, bias, dx, lddx, B, H, W, Cin_p, N, dy3, lddy3, w3, C3, stream): 3x3 over Cin_p + 1x1 over C3 channels
                         B_, H_, W_, Ci_, N_ = args[6:11]
                         outer.records.append((name, e0, e1, 2.0 * B_ * H_ * W_ * N_ * (9 * Ci_ + args[14]), (B_, H_, W_, Ci_, N_, 3, 3)))
                         return
                     elif name == "mte_conv2d_igemm":
                         shp = args[7:14]           # (x, ldx, w, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, ...)
-                    elif name in ("mte_conv2d_patch_fwd", "mte_conv2d_patch_fwd_gn", "mte_conv2d_patch_fwd_gr"):
+                    elif name in ("mte_conv2d_patch_fwd", "mte_conv2d_patch_fwd_gn"):
                         shp = args[6:13]           # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, KH, KW, ...)
                     elif name == "mte_conv2d_stem_fwd":
                         shp = args[6:9] + (8,) + args[9:12]      # (x, ldx, wf, bias, y, ldy, B, H, W, N, KH, KW, stream): 8 input channels
@@ -514,7 +511,7 @@ def main():
                 alg = conv2d_flops_per_image(H, W) * B * passes * ksteps          # algorithmic conv2d FLOPs of the timed launches
                 ach = alg / tot_t / 1e12
                 res["roofline"] = {"bound": "mfma", "kernel": "conv2d MFMA family (mte_conv2d_igemm fwd+dgrad, mte_conv2d_wgrad, "
-                                                              "mte_conv2d_patch_fwd (+ _gn, _gr, _rank1, _plus1x1, _plus1x1_gr), mte_conv2d_patch_wgrad, mte_conv2d_stem_fwd, mte_conv2d_stem_wgrad)",
+                                                              "mte_conv2d_patch_fwd (+ _gn, _rank1, _plus1x1), mte_conv2d_patch_wgrad, mte_conv2d_stem_fwd, mte_conv2d_stem_wgrad)",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": pmc_traffic_per_launch(args, B, H, W, n / ksteps),
                                    "launches_per_step": n / ksteps, "avg_launch_ms": tot_t / n * 1e3,
@@ -533,7 +530,7 @@ def main():
             if ht > 0:
                 # second roofline object: the HBM-bound GroupNorm+ELU family (26 of the 84 GB a step moves), same method --
                 # algorithmic bytes of the timed launches / HIP-event time, against the 8 TB/s HBM3E peak
-                res["roofline_hbm"] = {"bound": "hbm", "kernel": "GroupNorm(16)+ELU family (mte_gn_stats (+ _from_records), mte_gn_elu_fwd, mte_gn_elu_bwd (+ _red_ready), mte_gn_tail_fwd)",
+                res["roofline_hbm"] = {"bound": "hbm", "kernel": "GroupNorm(16)+ELU family (mte_gn_stats (+ _from_records), mte_gn_elu_fwd, mte_gn_elu_bwd, mte_gn_tail_fwd)",
                                        "achieved": hb / ht / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / ht / 1e9 / HBM_PEAK_GBS,
                                        "traffic": pmc_traffic_per_launch(args, B, H, W, hn / ksteps, "gn_family_MB_per_step"),
                                        "launches_per_step": hn / ksteps, "ms_per_step": ht / ksteps * 1e3,

@@ -440,17 +440,23 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
         const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
         int i = 0;
-#ifndef MTE_STAMPS
+#if !defined(MTE_STAMPS) && !defined(MTE_IGEMM_ROLLED)
         // Round 6: steady state in groups of ST K-steps with COMPILE-TIME ring slots.  tools/loopaudit.py on the rolled loop: ~48 scalar + 5 vector instructions per
         // 16 MFMAs and K-step -- two divisions by ST for the slots (s_mul_hi), slot address arithmetic, the rem ladder -- with four waves per SIMD that is more issue
         // slots than the MFMAs leave (profiles/r05_wgrad9_steps.txt: one instruction per ~4 cycles per SIMD for all of its waves).  While a whole group and the AHEAD
         // stages it issues exist, no `rem` test is needed: the wait is the constant (AHEAD - 1) * LPS, the slots are u and (u + AHEAD) % ST.  The rolled loop
-        // below finishes the last < ST + AHEAD K-steps.  Same K-steps in the same order: bit-identical.
-        if constexpr (LD == 2 && ABL == 0) {
+        // below finishes the last < ST + AHEAD K-steps.  Same K-steps in the same order: bit-identical.  Not for the four-wave 128 x 128 / 128 x 64 forms: unrolled,
+        // their accumulators + fragments leave three waves per SIMD for two and they run 14-28 % slower (serial traces r06_v1 vs r06_v2: 126.7 -> 144.5 us / 4 calls);
+        // the others gain 2-11 % (1346.7 -> 1290.8 us / 17 calls of <4,2,2,2>, 226.0 -> 201.3 us / 5 calls of <4,2,2,2, RING 4>, 173.4 -> 154.5 us of <2,3,3,1>).
+        if constexpr (LD == 2 && ABL == 0 && WM * WN >= 6) {
             for (; i + ST + AHEAD <= nst; i += ST) {
 #pragma unroll
                 for (int u = 0; u < ST; ++u) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LPS) : "memory");
+                    // lgkmcnt(0): unrolled, the compiler leaves the last fragment reads of compute(u - 1) in flight across this barrier (their MFMAs follow it), and
+                    // the slot they read is the one re-staged right behind it.  A ds_read that has not RETIRED before the barrier is not ordered against another
+                    // wave's LDS-DMA into the same bytes: without this wait the eval forward of the benchmark network differed from call to call in 12-23 of 23
+                    // calls (one sample of eight, |d depth| 0.2-1.4; profiles/r06_igemm_unroll_race.txt) while every single-launch parity test passed.
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * LPS) : "memory");
                     __builtin_amdgcn_s_barrier();
                     dma_fast(s_begin + i + u + AHEAD, (u + AHEAD) % ST);
                     compute(u);

@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256) void unpack3d_bwd_data_lds4_kernel(P3LArgs a) 
 // ([plane][pixel][8 zero | C depths | 8 zero] bf16, 69 KB: two workgroups per CU); a wave owns 4 (tile row, depth block) units.
 int g_p3_tr_passes = 4;                              // development knob (mte_debug_set(1, 3000 + v), v = 1 / 2 / 4): output passes of unpack3d_fwd_tr_kernel
 int g_p3_persist_wgs = 1024;                         // development knob (mte_debug_set(1, 2000 + v)): workgroups of the persistent matrix-core conv3d kernels
-int g_p3_mfma_data = 111;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs), bit 5 = unpack forward with the spatial taps in K (third form), bit 6 = pack forward in that form
+int g_p3_mfma_data = 239;                             // development knob (mte_debug_set(1, 300 + v)): bit 0 = unpack backward data on the matrix cores, bit 1 = its LDS-DMA form for C = 32, bit 2 = 4 waves per workgroup there (0: 2 waves x 4 rows, measured slower), bit 3 = unpack forward on the matrix cores, bit 4 = conv3d weights as ONE bf16 value (no lo part: half the MFMAs), bit 5 = unpack forward with the spatial taps in K (third form), bit 6 = pack forward in that form, bit 7 = pack backward data on the matrix cores (round 6)
 
 __device__ __forceinline__ bf16x8_t banded_fragment(unsigned t0, unsigned t1, const unsigned sel[4]) {
     u32x4_t r;
@@ -1138,6 +1138,129 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 3) void unpack3d_bwd_d
             u32x4_t o = {pack2bf(acc[r][0][0], acc[r][0][1]), pack2bf(acc[r][0][2], acc[r][0][3]), pack2bf(acc[r][1][0], acc[r][1][1]), pack2bf(acc[r][1][2], acc[r][1][3])};
             *(u32x4_t*)(a.dst + (((long)b * a.H + h) * a.W + w) * a.lddst + 8 * g) = o;
         }
+    }
+}
+
+// pack backward data (round 6): dx = un-shuffle(conv3d^T(dO)), C % 32 == 0, the same banded-operand GEMM.  The fp32-VALU stencil above (pack3d_bwd_data_lds_kernel)
+// was the largest non-convolution, non-GroupNorm kernel of the main queue: 0.48 ms per step alone, 0.70 ms beside the weight-gradient queue, at 1.8 TB/s
+// (profiles/r06_v2_pmc_traffic_T8.txt: 800 MB read, 85 MB written) -- arithmetic-bound at 48 v_pk_fma_f32 + ~50 unpacking instructions per 32 outputs, tap and plane.
+//   * work item = (tile of 4 x 16 packed pixels, segment of 128 depths of the D = 4C); a wave owns ONE unit of 32 depths and all four tile rows: the six halo rows
+//     it reads per (plane, kw) feed 4 rows x 3 kh x 2 blocks x (hi, lo) = 48 MFMAs -- one ds_read_b128 per 4 MFMAs.  (First version: a wave = one row, four
+//     units -- one read per 2 MFMAs; the same time to the microsecond: 9.6 cycles per output and SIMD against the 4.5 of the MFMAs, the rest is load latency + the
+//     four meetings per workgroup.)
+//   * the feature side dO[b][h][w][f D + d] is plain [pixel][depth] per plane f: the 16-byte chunks -1 .. 16 of the segment (the two outer ones are the depth
+//     halo: the neighbouring segment's, or zeros at depths -1 / D) of the 6 x 18 halo pixels go to LDS by buffer_load ... lds, chunk-major inside groups of 16
+//     pixels ([group][slot][pixel] x 16 B: the 16 lanes of a read phase -- 16 consecutive pixels, one slot -- cover 256 contiguous bytes); out-of-image pixels and
+//     out-of-range depths load zeros through the buffer bounds check.
+//     One plane at a time, 36 KB: four workgroups per CU.  (Built and measured slower: persistent workgroups, two per CU, with the next plane's records in flight
+//     into a second buffer -- 160 vs 123 us at C = 32 @192x640, 83 vs 61 at C = 64: two waves per SIMD do not cover the LDS latency between the taps.)
+//   * 16-depth block at d0: K entry t of lane group g <-> input depth d0 - 8 + 8 g + t (slot 4 u + 2 blk + g: one aligned ds_read_b128), row m = 4 g' + j of the
+//     banded operand <-> OUTPUT depth d0 + 4 j + g' = channel d0 / 4 + j, sub-pixel g'.  The accumulator registers of lane (pixel n, g) are then 4 consecutive
+//     channels of sub-pixel g, and the two blocks of the unit 8 channels: ONE 16-byte store into dx[b][2 h + g / 2][2 w + g % 2][c0 .. c0 + 7].
+//   * the banded fragments (8 v_perm_b32 for hi + lo) are the same for every block and row: built once per (plane, kh, kw), used by 16 MFMAs.
+// Segments of 256 depths (a wave = two units) were built too and lost on every layer with D >= 256 (74 vs 61 us at C = 64, 56 vs 40 at C = 512: profiles/r06_pack_bwd_mfma.txt).
+template <bool HILO>
+__global__ __launch_bounds__(256, 4) void pack3d_bwd_data_mfma_kernel(P3LArgs a) {
+    constexpr int DS = 128, TH = 4, PW = 18, NPIX = (TH + 2) * PW, NG = (NPIX + 15) / 16, NCH = DS / 8, NSL = (NCH + 2 + 3) & ~3, GS = NSL * 256;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    __shared__ __attribute__((aligned(16))) unsigned wtab[36 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = 4 * a.C, H2 = a.H >> 1, W2 = a.W >> 1, nseg = D / DS;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg0 = (id % nseg) * DS;
+    int b, h0, w0;
+    tile_coords(a, id / nseg, b, h0, w0);
+    const long total = ((long)a.B * H2 * W2 - 1) * a.ldo + 4 * D;                              // elements of the gradient tensor (launcher: < 2^30)
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.o, 0, (int)(total * 2), 0x00020000);
+    auto stage = [&](int f) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int k = wave; k < NG * (NSL / 4); k += 4) {               // one instruction = 16 tile pixels x 4 slots = 1 KB of LDS
+            const int grp = k / (NSL / 4), q = k - grp * (NSL / 4);
+            const int t = 16 * grp + (lane & 15), slot = 4 * q + (lane >> 4);
+            const int py = t / PW, px = t - PW * py;
+            const int hh = h0 - 1 + py, ww = w0 - 1 + px, dd = seg0 + 8 * (slot - 1);
+            const bool ok = t < NPIX && slot < NCH + 2 && (unsigned)hh < (unsigned)H2 && (unsigned)ww < (unsigned)W2 && (unsigned)dd < (unsigned)D;
+            const long el = (((long)b * H2 + hh) * W2 + ww) * a.ldo + f * D + dd;
+            const unsigned off = ok ? (unsigned)(el * 2) : 0x7ffffff0u;                        // out of range: the load returns zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem_ + grp * GS + q * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    stage(0);
+    if (tid < 36) {
+        const int f = tid / 9, k9 = tid - 9 * f;
+        unsigned hi[3], lo[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const float w = a.w3[(f * 3 + kd) * 9 + k9];
+            hi[kd] = f2bf(w); lo[kd] = f2bf(w - bf2f((bf16_t)hi[kd]));
+        }
+        *(u32x4_t*)(wtab + 4 * tid) = u32x4_t{hi[0] | (hi[1] << 16), hi[2], lo[0] | (lo[1] << 16), lo[2]};
+    }
+    // banded operand of this lane: row m = lane % 16 <-> output depth d0 + 4 (m % 4) + m / 4; K entry t of group g <-> input depth d0 - 8 + 8 g + t;
+    // dP[d_out] += w[kd] dO[d_out - kd + 1]: the entry carries w[kd = d_out - d_in + 1]
+    const int n = lane & 15, g = lane >> 4;
+    unsigned sel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned sv = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int kd = (4 * (n & 3) + (n >> 2)) - (8 * g - 8 + 2 * j + e) + 1;
+            const unsigned two = kd == 0 ? 0x0100u : (kd == 1 ? 0x0302u : (kd == 2 ? 0x0504u : 0x0c0cu));
+            sv |= two << (16 * e);
+        }
+        sel[j] = sv;
+    }
+    f32x4_t acc[TH][2];
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) acc[r][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+        if (f) {
+            __syncthreads();                                           // every wave is past its reads of the previous plane
+            stage(f);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            bf16x8_t x[TH + 2][2];                                     // halo rows 0 .. 5, column n + 2 - kw (source pixel p + 1 - k, tile origin (-1, -1)), this wave's unit
+#pragma unroll
+            for (int py = 0; py < TH + 2; ++py) {
+                const int t = py * PW + n + 2 - kw;
+                const char* base = smem_ + (t >> 4) * GS + (t & 15) * 16 + (4 * wave + g) * 256;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) x[py][blk] = *(const bf16x8_t*)(base + 2 * blk * 256);
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const u32x4_t wq = *(const u32x4_t*)(wtab + 4 * (f * 9 + 3 * kh + kw));
+                const bf16x8_t bhi = banded_fragment(wq[0], wq[1], sel), blo = banded_fragment(wq[2], wq[3], sel);
+                // 8 independent accumulators between the two MFMAs of one accumulator (a dependent MFMA waits out the first one's passes)
+#pragma unroll
+                for (int r = 0; r < TH; ++r)
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) acc[r][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x[r + 2 - kh][blk], acc[r][blk], 0, 0, 0);
+                if constexpr (HILO) {
+#pragma unroll
+                    for (int r = 0; r < TH; ++r)
+#pragma unroll
+                        for (int blk = 0; blk < 2; ++blk) acc[r][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x[r + 2 - kh][blk], acc[r][blk], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane (pixel n, sub-pixel g): register j of block blk = channel seg0 / 4 + 8 wave + 4 blk + j of dx pixel (2 h + g / 2, 2 w + g % 2)
+    const int w = w0 + n;
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+        const int h = h0 + r;
+        if (h < H2 && w < W2)
+            *(u32x4_t*)(a.dst + (((long)b * a.H + 2 * h + (g >> 1)) * a.W + 2 * w + (g & 1)) * a.lddst + (seg0 >> 2) + 8 * wave) =
+                u32x4_t{pack2bf(acc[r][0][0], acc[r][0][1]), pack2bf(acc[r][0][2], acc[r][0][3]), pack2bf(acc[r][1][0], acc[r][1][1]), pack2bf(acc[r][1][2], acc[r][1][3])};
     }
 }
 
@@ -1762,6 +1885,15 @@ int mte_pack3d_bwd_data(const void* dout, long ldo, const float* w3, void* dx, l
     if (!dout || !w3 || !dx || !p3_ok(C)) return MTE_ERR_ARG;
     P3Args a{}; a.o = dout; a.ldo = ldo; a.dst = dx; a.lddst = lddx; a.w3 = w3; a.B = B; a.H = H; a.W = W; a.C = C;
     a.total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (dtype == MTE_DT_BF16 && g_p3_lds >= 2 && (g_p3_mfma_data & 128) && C % 32 == 0 && ((long)B * (H / 2) * (W / 2) - 1) * ldo + 16L * C < (1L << 30)) {
+        P3LArgs l{}; l.B = B; l.H = H; l.W = W; l.C = C; l.TH = 4; l.TW = 16;
+        l.tiles_h = (H / 2 + 3) / 4; l.tiles_w = (W / 2 + 15) / 16; l.ntiles = l.tiles_h * l.tiles_w * B;
+        l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
+        const long grid = (long)l.ntiles * (4 * C / 128);
+        if (grid < (1L << 30))
+            return (g_p3_mfma_data & 16) ? launch_p3l(pack3d_bwd_data_mfma_kernel<false>, l, (int)grid, stream, (size_t)7 * 20 * 256)
+                                         : launch_p3l(pack3d_bwd_data_mfma_kernel<true>, l, (int)grid, stream, (size_t)7 * 20 * 256);
+    }
     if (dtype == MTE_DT_BF16 && g_p3_lds && C % 8 == 0 && C <= 512) {
         P3LArgs l = p3l_args(B, H, W, C); l.o = (const bf16_t*)dout; l.ldo = ldo; l.dst = (bf16_t*)dx; l.lddst = lddx; l.w3 = w3;
         return launch_p3l(pack3d_bwd_data_lds_kernel, l, l.ntiles, stream);

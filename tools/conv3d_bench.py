@@ -2,7 +2,7 @@
 """development aid (round 4): the conv3d(1 -> 4) data paths of the pack / unpack layers at their T8 shapes -- us per launch, algorithmic TB/s,
 cycles per output and SIMD -- for the kernel variants behind mte_debug_set(1, v): 300 = fp32-VALU LDS stencils, 300 + bits = matrix-core forms.
 Also prints the largest element-wise difference of each variant against the first one (same inputs).
-usage: conv3d_bench.py [variant ...]   (default: 300 411)"""
+usage: conv3d_bench.py [variant ...]   (default: 300 411 539)"""
 import os
 import sys
 
@@ -23,7 +23,7 @@ if os.environ.get("P3_DEFS"):                                     # private diag
 import torch  # noqa: E402
 from mindtheedge_amd import kernels as K  # noqa: E402
 
-variants = [int(v) for v in sys.argv[1:]] or [300, 411]
+variants = [int(v) for v in sys.argv[1:]] or [300, 411, 539]
 B = 8
 K.set_compute_dtype("bf16")
 lib = K.lib
@@ -33,7 +33,7 @@ for extra in os.environ.get("P3_KNOBS", "").split():             # further value
 only = os.environ.get("P3_ONLY")
 shapes = [("unpack_bwd_data", 32, 192, 640), ("unpack_bwd_data", 64, 96, 320), ("unpack_bwd_data", 128, 48, 160),
           ("unpack_fwd", 32, 192, 640), ("unpack_fwd", 64, 96, 320), ("unpack_fwd", 128, 48, 160), ("unpack_fwd", 256, 24, 80),
-          ("pack_bwd_data", 256, 48, 160), ("pack_bwd_data", 512, 24, 80), ("pack_fwd", 256, 48, 160), ("pack_fwd", 512, 24, 80)]
+          ("pack_bwd_data", 32, 192, 640), ("pack_bwd_data", 64, 96, 320), ("pack_bwd_data", 128, 48, 160), ("pack_bwd_data", 256, 48, 160), ("pack_bwd_data", 512, 24, 80), ("pack_fwd", 256, 48, 160), ("pack_fwd", 512, 24, 80)]
 
 
 def timed(f, n=10):
@@ -92,4 +92,4 @@ for op, C, H, W in shapes:
         line += "| v%d %7.1f us %5.2f TB/s %5.1f cyc/out/SIMD%s " % (v, us, 5 * vol * 2 / us / 1e6, us * 1e-6 * 2.4e9 * 1024 / vol, dtxt)
         out.copy_(keep) if False else None
     print(line)
-lib.mte_debug_set(1, 411)
+lib.mte_debug_set(1, 539)
