@@ -818,62 +818,76 @@ def conv_backward(x, dy, w, pack, need_dx, need_dw=True, need_dbias=True, dw_out
     """-> (dx or None, dw (OIHW fp32) or None, dbias fp32); dw_out / dbias_out: pre-allocated destinations; sunk: they are views
     of the gradient sink (nothing on the backward chain reads them: the weight-gradient kernels may run on the side stream);
     fork_slot: see ForkFn -- the data gradient is accumulated into the gradient another consumer of x already produced"""
-    cout, cin, kh, kw = w.shape
-    B, Cp, H, W = x.shape
-    dyp, lddy = _pl(dy)
-    xp, ldx = _pl(x)
-    st = _stream()
     dw = dbias = dx = None
+    on_side = False
     if need_dw:
         sunk = bool(sunk) and dw_out is not None and (dbias_out is not None or not need_dbias)
-        if sunk and _side["enabled"] and need_dx:
+        on_side = sunk and _side["enabled"] and need_dx
+
+    def wgrad():
+        if on_side:
             if _side["keep_bytes"] > _SIDE_KEEP_LIMIT:
                 join_side_stream()
             with torch.cuda.stream(_side_stream_for(x, dy)):
-                dw, dbias = _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
-        else:
-            dw, dbias = _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
+                return _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
+        return _conv_wgrad(x, dy, w, need_dbias, dw_out, dbias_out)
+
+    # (Round 6 measured the other order -- the weight gradient forked BEHIND the data-gradient launch, so that it starts beside the previous layer's memory-bound
+    #  GroupNorm backward instead of beside the matrix-bound data gradient: 21.74 / 21.82 / 21.66 ms against 21.75 / 21.69 / 21.87, no difference:
+    #  profiles/r06_wgrad_after_dgrad.txt.  The side queue is a FIFO that runs behind the main queue anyway; where a launch is forked does not place it.)
+    if need_dw:
+        dw, dbias = wgrad()
     if need_dx:
-        target = _fork_target(fork_slot, (B, Cp, H, W), x.dtype, keep_pending=True)
-        if (target is None and fork_slot is not None and (kh, kw) == (1, 1) and sites is None and _cfg["fold_shortcut_dgrad"]
-                and not _cfg.get("no_fork_accumulate") and _patch_ok(W, cout, Cp, 1, 1, x.dtype) and _patch_ok(W, 32, Cp, 3, 3, x.dtype)):
-            # a 1x1 whose input has another consumer that has not produced its data gradient yet (a residual block's shortcut: autograd runs it before
-            # the block's conv1): hand out the buffer, leave the launch to that consumer's 3x3 data gradient (below) -- or to whoever touches the slot first
-            dx = new_act(B, Cp, H, W, x.dtype, x.device)
-            fork_slot["buf"] = dx
-            fork_slot["pending"] = (dy, w, pack)
-            return dx, dw, dbias
-        pend = _pending_slot(fork_slot) if target is not None else None
-        if pend is not None:
-            dy3, w3, pack3 = pend["pending"]
-            if ((kh, kw) == (3, 3) and sites is None and target is pend["buf"] and _patch_ok(W, cout, Cp, 3, 3, x.dtype)
-                    and tuple(dy3.shape[2:]) == (H, W) and dy3.dtype == x.dtype):
-                del pend["pending"]
-                d3p, ldd3 = _pl(dy3)
-                dxp, lddx = _pl(target)
-                lib.mte_conv2d_patch_fwd_plus1x1(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
-                                                 d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1], st)
-                fork_slot["buf"] = target
-                return target, dw, dbias
-            _flush_pending(pend)
-        dx = target if target is not None else new_act(B, Cp, H, W, x.dtype, x.device)
-        if target is None and sites is not None:
-            dx.zero_()                                       # (as in conv_forward: inactive sites of a sparse result are exact zeros)
-        acc = 1 if target is not None else 0
-        dxp, lddx = _pl(dx)
-        if sites is not None:                              # sparse data gradient: the same gather-GEMM-scatter with the backward pack
-            _, wb = pack.get(w, x.dtype, True)
-            lib.mte_conv2d_igemm_sparse(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, _dt(x),
-                                        sites.rows.data_ptr(), sites.count.data_ptr(), acc, st)
-        elif _patch_ok(W, cout, Cp, kh, kw, x.dtype):
-            lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
-        else:
-            _, wb = pack.get(w, x.dtype, True)
-            ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
-            lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, acc, st)
-        if fork_slot is not None:
-            fork_slot["buf"] = dx
+        dx = _conv_dgrad(x, dy, w, pack, fork_slot, sites)
     return dx, dw, dbias
+
+
+def _conv_dgrad(x, dy, w, pack, fork_slot, sites):
+    """the data gradient of conv_backward (see there)"""
+    cout, cin, kh, kw = w.shape
+    B, Cp, H, W = x.shape
+    dyp, lddy = _pl(dy)
+    st = _stream()
+    target = _fork_target(fork_slot, (B, Cp, H, W), x.dtype, keep_pending=True)
+    if (target is None and fork_slot is not None and (kh, kw) == (1, 1) and sites is None and _cfg["fold_shortcut_dgrad"]
+            and not _cfg.get("no_fork_accumulate") and _patch_ok(W, cout, Cp, 1, 1, x.dtype) and _patch_ok(W, 32, Cp, 3, 3, x.dtype)):
+        # a 1x1 whose input has another consumer that has not produced its data gradient yet (a residual block's shortcut: autograd runs it before
+        # the block's conv1): hand out the buffer, leave the launch to that consumer's 3x3 data gradient (below) -- or to whoever touches the slot first
+        dx = new_act(B, Cp, H, W, x.dtype, x.device)
+        fork_slot["buf"] = dx
+        fork_slot["pending"] = (dy, w, pack)
+        return dx
+    pend = _pending_slot(fork_slot) if target is not None else None
+    if pend is not None:
+        dy3, w3, pack3 = pend["pending"]
+        if ((kh, kw) == (3, 3) and sites is None and target is pend["buf"] and _patch_ok(W, cout, Cp, 3, 3, x.dtype)
+                and tuple(dy3.shape[2:]) == (H, W) and dy3.dtype == x.dtype):
+            del pend["pending"]
+            d3p, ldd3 = _pl(dy3)
+            dxp, lddx = _pl(target)
+            lib.mte_conv2d_patch_fwd_plus1x1(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp,
+                                             d3p, ldd3, pack3.get_patch(w3, 'b').data_ptr(), dy3.shape[1], st)
+            fork_slot["buf"] = target
+            return target
+        _flush_pending(pend)
+    dx = target if target is not None else new_act(B, Cp, H, W, x.dtype, x.device)
+    if target is None and sites is not None:
+        dx.zero_()                                       # (as in conv_forward: inactive sites of a sparse result are exact zeros)
+    acc = 1 if target is not None else 0
+    dxp, lddx = _pl(dx)
+    if sites is not None:                              # sparse data gradient: the same gather-GEMM-scatter with the backward pack
+        _, wb = pack.get(w, x.dtype, True)
+        lib.mte_conv2d_igemm_sparse(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, _dt(x),
+                                    sites.rows.data_ptr(), sites.count.data_ptr(), acc, st)
+    elif _patch_ok(W, cout, Cp, kh, kw, x.dtype):
+        lib.mte_conv2d_patch_fwd(dyp, lddy, pack.get_patch(w, 'b').data_ptr(), 0, dxp, lddx, B, H, W, cout, Cp, kh, kw, acc, st)
+    else:
+        _, wb = pack.get(w, x.dtype, True)
+        ws, ws_n = _splitk_workspace(B * H * W, Cp, x.device)
+        lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, dxp, lddx, 0, B, H, W, cout, Cp, kh, kw, _dt(x), _ptr(ws), ws_n, acc, st)
+    if fork_slot is not None:
+        fork_slot["buf"] = dx
+    return dx
 
 
 _stats_elems = {}
