@@ -1314,6 +1314,24 @@ int launch_wgrad_dma(WgradArgs a, hipStream_t st, int parts_cap, int* parts_out)
     const long max_splits = (nblk + 15) / 16;                   // at least 16 pixel blocks per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    if (!g_mte_wgrad_shared) {
+        // alone on the chip the launch runs in whole rounds of (CUs x workgroups per CU): 50 tiles x 6 splits = 300 one-per-CU workgroups took two rounds, the second
+        // 17 % full (5x5 512 -> 128 @48x160: 0.366 ms at 550 TFLOP/s; 5 splits = 250 workgroups: one round).  Among the split counts around the one above take the
+        // cheapest in rounds per split; ties go to fewer partial slabs.
+        static int cus = 0;
+        if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+        const size_t lds_wg = (size_t)WG_RING * 32 * (BNO + BC) * 2;
+        long per_cu = (long)(160 * 1024 / lds_wg);
+        if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
+        if (per_cu < 1) per_cu = 1;
+        const long slots = per_cu * cus;
+        long best = splits; double best_cost = 1e30;
+        for (long sc = splits > 2 ? splits - 2 : 1; sc <= splits + 2 && sc <= max_splits && sc <= (parts_cap < 1 ? 1 : parts_cap); ++sc) {
+            const double cost = (double)((base_wgs * sc + slots - 1) / slots) / (double)sc;
+            if (cost < best_cost * 0.98) { best_cost = cost; best = sc; }
+        }
+        splits = best;
+    }
     // one partial gradient per pixel split (plain stores, summed in part order by the unpack pass): never more splits than the caller's stage
     // has parts -- round 4: the fp32-atomic combine that used to take over beyond stage_parts is gone from this kernel's launch path, the
     // weight gradient is a fixed-order sum (the atomics cost 0.4 ms per step when they were the default, and made the result order-dependent)
