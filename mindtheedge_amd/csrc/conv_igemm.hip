@@ -732,6 +732,7 @@ int g_igemm_big_min_tiles = 224;
 #define MTE_IGEMM8_DEFAULT 51
 #endif
 int g_igemm8 = MTE_IGEMM8_DEFAULT;                                   // development knob (mte_debug_set(23, v)): bit 0 = 8-phase 256 x 256 kernel, bit 1 = its 256 x 128 form, bit 2 every eligible launch, bit 5 (32) tap-major K order (the default; without it: slice-major where Cin_p % 64 == 0); bits 3 / 4 belonged to the tile-walking form, removed in round 5
+int g_igemm8_split_bn128 = 64;                        // development knob (mte_debug_set(29, v)): see the split-K rule of the 8-phase kernels
 int g_igemm8_min_tiles = 200;                        // development knob (mte_debug_set(24, v))
 int g_igemm_pp = 1;                                  // development knob (mte_debug_set(21, v)): 0 = the 16-wave one-barrier loop on the 256 x 256 tile
 int g_igemm_big = 3;                                 // development knob (mte_debug_set(6, v)): 0 128x128 only, 1 + 256x128, 2 + 256x256, 3 + 192x96
@@ -772,7 +773,13 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
             } else if ((g_igemm8 & 2) && tiles_big >= g_igemm8_min_tiles && tiles_big <= 256 && nkt >= 36) bn = 128;
             if (!bn && wide && (g_igemm8 & 1) && can_split && t256 < 128 && ksteps >= 32) {        // few tiles, long reduction: split K
                 bn = 256;
-                long sp = 256 / t256;                                                              // one round of workgroups
+                long tsp = t256;
+                // Round 6: very few tiles AND a short reduction (the 512-channel 12x40 / 24x80 layers: K = 4608) -> 256 x 128 tiles with half the K splits.  Such a
+                // launch is dominated by its fp32 slabs (8 x 7.9 MB written and read back for a 3.9 MB result at 12x40); half the slabs: 41.7 -> 35.2 us forward,
+                // 39.7 -> 33.4 data gradient at 512 -> 512 @12x40, 55.9 -> 52.4 at 512 -> 256 @24x80.  With a long reduction (pack4 / pack5.conv: K = 36,864 /
+                // 73,728) the slabs do not matter and the narrower tile loses 15 % (265 -> 305 us): profiles/r06_lowres_split.txt.  Knob 29 = tile bound (0: off).
+                if (t256 <= g_igemm8_split_bn128 && ksteps <= 288) { bn = 128; tsp = tiles_big; }
+                long sp = 256 / tsp;                                                               // one round of workgroups
                 if (sp > smax) sp = smax;
                 if (sp > ksteps / 16) sp = ksteps / 16;                                            // >= 8 K-tiles per split
                 const int per = (int)((ksteps + sp - 1) / (sp < 1 ? 1 : sp));
@@ -1695,6 +1702,7 @@ int mte_debug_set(int key, int value) {
     if (key == 21) { g_igemm_pp = value; return MTE_OK; }
     if (key == 23) { g_igemm8 = value; return MTE_OK; }
     if (key == 24) { g_igemm8_min_tiles = value; return MTE_OK; }
+    if (key == 29) { g_igemm8_split_bn128 = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 25) return mtei_set_gn(4, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }
