@@ -61,8 +61,8 @@ class ConvTimer:
         for name in ("mte_conv2d_igemm", "mte_conv2d_wgrad", "mte_conv2d_patch_fwd", "mte_conv2d_patch_wgrad",
                      "mte_conv2d_stem_fwd", "mte_conv2d_stem_wgrad", "mte_conv2d_patch_fwd_rank1", "mte_conv2d_patch_fwd_plus1x1"):
             self._orig[name] = getattr(lib, name)
-        self._optional = ("mte_gn_tail_fwd", "mte_gn_stats_from_records", "mte_conv2d_patch_fwd_gn")   # (entry points an older build of the library lacks: same-box A/B of two libraries with ONE bench.py)
-        for name in ("mte_conv2d_patch_fwd_gn",):   # round 5: LDS-patch launches that also leave GroupNorm records
+        self._optional = ("mte_gn_tail_fwd", "mte_gn_stats_from_records", "mte_conv2d_patch_fwd_gn", "mte_conv2d_igemm_unshuffle")   # (entry points an older build of the library lacks: same-box A/B of two libraries with ONE bench.py)
+        for name in ("mte_conv2d_patch_fwd_gn", "mte_conv2d_igemm_unshuffle"):   # round 5 / round 6 (the folded pack layers' data gradient without the shuffle pass behind it); round 5: LDS-patch launches that also leave GroupNorm records
             try:
                 self._orig[name] = getattr(lib, name)
             except AttributeError:
@@ -147,6 +147,8 @@ class ConvTimer:
                         return
                     elif name == "mte_conv2d_igemm":
                         shp = args[7:14]           # (x, ldx, w, bias, y, ldy, out_f32, B, H, W, Cin_p, N, KH, KW, ...)
+                    elif name == "mte_conv2d_igemm_unshuffle":
+                        shp = args[5:12]           # (x, ldx, w, y, ldy, B, H, W, Cin_p, N, KH, KW, ...)
                     elif name in ("mte_conv2d_patch_fwd", "mte_conv2d_patch_fwd_gn"):
                         shp = args[6:13]           # (x, ldx, w, bias, y, ldy, B, H, W, Cin_p, N, KH, KW, ...)
                     elif name == "mte_conv2d_stem_fwd":
@@ -510,7 +512,7 @@ def main():
                 peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
                 alg = conv2d_flops_per_image(H, W) * B * passes * ksteps          # algorithmic conv2d FLOPs of the timed launches
                 ach = alg / tot_t / 1e12
-                res["roofline"] = {"bound": "mfma", "kernel": "conv2d MFMA family (mte_conv2d_igemm fwd+dgrad, mte_conv2d_wgrad, "
+                res["roofline"] = {"bound": "mfma", "kernel": "conv2d MFMA family (mte_conv2d_igemm fwd+dgrad (+ _unshuffle), mte_conv2d_wgrad, "
                                                               "mte_conv2d_patch_fwd (+ _gn, _rank1, _plus1x1), mte_conv2d_patch_wgrad, mte_conv2d_stem_fwd, mte_conv2d_stem_wgrad)",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": pmc_traffic_per_launch(args, B, H, W, n / ksteps),

@@ -49,6 +49,13 @@ typedef struct ihipStream_t* mte_stream_t; /* hipStream_t */
 int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bias, void* y, long ldy, int out_f32,
                      int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype,
                      float* workspace, long workspace_elems, int accumulate, mte_stream_t stream);
+/* Round 6: the data gradient of a folded pack layer (reference: networks/layers/packnet/layers01.py:214-250, PackLayerConv3d backward) written WITHOUT the
+ * mte_pixel_shuffle pass behind it.  The N = 4 C output channels are the packed depths d = 4 c + s of the [B][H][W] packed grid; y is the un-shuffled tensor
+ * [B][2H][2W][C] (pixel stride ldy): GEMM row (b, h, w), column d goes to y[b][2h + s / 2][2w + s % 2][c].  accumulate as in mte_conv2d_igemm (bit 0).  bf16.
+ * Returns MTE_ERR_UNSUPPORTED where the launch would not take a tile form that stages its result in LDS (no K split, no 8-phase kernel): the caller then runs
+ * mte_conv2d_igemm + mte_pixel_shuffle -- the results are bit-identical. */
+int mte_conv2d_igemm_unshuffle(const void* x, long ldx, const void* wpack, void* y, long ldy,
+                               int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, int accumulate, mte_stream_t stream);
 /* Library options.  MTE_OPT_GN_PREZEROED (0): when 1, the GroupNorm statistics / reduction / bias-gradient buffers handed to
  * mte_gn_stats and mte_gn_elu_bwd -- and, since round 4, that call's dgamma / dbeta -- are already zero (the caller clears one arena
  * per step with a single fill; a zeroed flat gradient buffer qualifies) and the library skips its own per-call fills. */

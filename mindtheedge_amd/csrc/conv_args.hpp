@@ -25,6 +25,10 @@ struct ConvArgs {
     // tap brought into the XCD's L2 (a slice of the resident tiles' inputs fits it; a whole tap sweep over all channels does not: 9 x the input was
     // fetched from the Infinity Cache).  A different summation order: results agree with the tap-major forms to fp32 rounding, not bit for bit.
     int kslice;
+    // Un-shuffled output (round 6; mte_conv2d_igemm_unshuffle): the N = 4 C output channels are the packed depths d = 4 c + s of a pixel-unshuffled tensor and y is
+    // that tensor BEFORE the unshuffle, [B][2H][2W][C] with pixel stride ldy: GEMM row (b, h, w), column d goes to y[b][2h + s / 2][2w + s % 2][c].  0 = off, else C.
+    // Only the tile forms that stage their result in LDS write it (one workgroup holds a packed pixel's whole 32-depth groups); no K split.
+    int unshuffle_c;
 };
 
 // conv_igemm8.hip: the 8-phase 256-row tile kernels (bf16, buffer-descriptor LDS-DMA).  bn = 256 or 128 output columns per tile.

@@ -575,6 +575,47 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_igemm_kernel(ConvArgs
             constexpr int CPR = BN / PER16;                // 16-B chunks per tile row
             const int cvalid = (a.N - n0) / PER16;         // chunks of this tile inside N (N % 8 == 0)
             const int cc = tid % CPR;
+            if constexpr (sizeof(T) == 2 && BN % 32 == 0) {
+                if (a.unshuffle_c) {
+                    // work item = (tile row, group c8 of 8 channels = 32 packed depths = the four staged chunks 4 c8 .. 4 c8 + 3): chunk j holds channels 2j, 2j + 1 as
+                    // [c][s] -- element 4 e + s = channel 2j + e, sub-pixel s.  Four ds_read_b128, then for every sub-pixel s the 8 channels are 4 byte permutes
+                    // (v_perm_b32: the two halves e = 0 / 1 of chunk j from dwords s / 2 and 2 + s / 2) and leave as ONE 16-byte store into the un-shuffled tensor.
+                    // (First version: a thread per (row, s, c8) with eight 2-byte LDS reads per store -- +40 us per launch: gpurun_out/r06_unshuffle.txt.)
+                    constexpr int C8 = BN / 32;
+                    const int hw = a.H * a.W;
+                    for (int idx = tid; idx < BM * C8; idx += NTHR) {
+                        const int row = idx / C8, c8l = idx - row * C8;
+                        const int c0 = (n0 >> 2) + c8l * 8;
+                        const long m = m0 + row;
+                        if (m < Mrows && c0 + 8 <= a.unshuffle_c) {
+                            const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+                            const int h = rem / a.W, w = rem - h * a.W;
+                            const char* rowp = smem + (row * BN) * ES;
+                            u32x4_t q[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) q[j] = *(const u32x4_t*)(rowp + ((4 * c8l + j + row) % CPR) * 16);
+                            T* dst0 = (T*)a.y + ((((long)b * 2 * a.H + 2 * h) * (2 * a.W) + 2 * w) * a.ldy + c0);
+#pragma unroll
+                            for (int s_ = 0; s_ < 4; ++s_) {
+                                u32x4_t c;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_perm(q[j][2 + (s_ >> 1)], q[j][s_ >> 1], (s_ & 1) ? 0x07060302u : 0x05040100u);
+                                T* dst = dst0 + ((long)(s_ >> 1) * (2 * a.W) + (s_ & 1)) * a.ldy;
+                                if (a.accum) {
+                                    float vn[PER16], vo[PER16];
+                                    unpack16<T>(c, vn);
+                                    unpack16<T>(*(const u32x4_t*)dst, vo);
+#pragma unroll
+                                    for (int k = 0; k < PER16; ++k) vn[k] += vo[k];
+                                    c = pack16<T>(vn);
+                                }
+                                *(u32x4_t*)dst = c;
+                            }
+                        }
+                    }
+                    return;
+                }
+            }
 #pragma unroll
             for (int it = 0; it < BM * CPR / NTHR; ++it) {
                 const int row = tid / CPR + it * (NTHR / CPR);
@@ -658,6 +699,7 @@ int launch_igemm(ConvArgs a, long ws_elems, hipStream_t st) {
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int ksteps = (a.KH * a.KW * (a.Cin_p / Elem<T>::PER16) + 3) / 4;
     a.splits = (a.ws && !a.out_f32 && !a.rows) ? choose_splits(tiles, ksteps, a.M, a.N, ws_elems, NTHR) : 1;
+    if (a.unshuffle_c && (a.splits != 1 || a.out_f32 || a.rows || sizeof(T) != 2 || BN % 32 != 0 || (BN * 4) % NTHR != 0 || !g_igemm_dma)) return MTE_ERR_UNSUPPORTED;
     if constexpr ((BN * 4) % NTHR == 0) {
         if (g_igemm_dma) {
             const size_t lds4 = 4 * (BM + BN) * 64;
@@ -758,7 +800,7 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         if (smax > 8) smax = 8;
         const long reach256 = t256 * (can_split ? (ksteps / 16 < smax ? (ksteps / 16 > 0 ? ksteps / 16 : 1) : smax) : 1);
         // ---- round 4: the 8-phase kernels (conv_igemm8.hip) take every launch the 256-row tiles took
-        if (g_igemm8 && dma_ok && !a.out_f32 && !a.rows && a.N > 64) {
+        if (g_igemm8 && dma_ok && !a.out_f32 && !a.rows && a.N > 64 && !a.unshuffle_c) {
             const bool wide = a.N > 128 && (a.N % 256 == 0 || a.N % 256 > 128);
             const int nkt = (ksteps + 1) / 2;                                                      // K-tiles of 64
             int bn = 0, splits = 1;
@@ -1730,6 +1772,20 @@ int mte_conv2d_igemm(const void* x, long ldx, const void* wpack, const float* bi
     if (dtype == MTE_DT_BF16) return dispatch_igemm<bf16_t>(a, workspace_elems, stream);
     if (dtype == MTE_DT_F32) return dispatch_igemm<float>(a, workspace_elems, stream);
     return MTE_ERR_UNSUPPORTED;
+}
+
+// The data gradient of a folded pack layer written WITHOUT the pixel-shuffle pass behind it (round 6): N = 4 C packed depths d = 4 c + s per pixel of the [B][H][W]
+// packed grid, y = the un-shuffled tensor [B][2H][2W][C] (pixel stride ldy); accumulate as in mte_conv2d_igemm (bit 0).  MTE_ERR_UNSUPPORTED where the launch
+// would not take a tile form that stages its result in LDS (the caller then runs mte_conv2d_igemm + mte_pixel_shuffle).  bf16 only.
+int mte_conv2d_igemm_unshuffle(const void* x, long ldx, const void* wpack, void* y, long ldy,
+                               int B, int H, int W, int Cin_p, int N, int KH, int KW, int dtype, int accumulate, hipStream_t stream) {
+    (void)hipGetLastError();   // drop stale errors left by other runtime users (e.g. event queries)
+    if (!x || !wpack || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0) return MTE_ERR_ARG;
+    if (dtype != MTE_DT_BF16) return MTE_ERR_UNSUPPORTED;
+    if (Cin_p % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || (KH & 1) == 0 || (KW & 1) == 0 || N % 32 != 0) return MTE_ERR_ARG;
+    ConvArgs a{x, ldx, wpack, nullptr, y, ldy, 0, B, H, W, Cin_p, N, KH, KW, (long)B * H * W, 1, nullptr, accumulate & 1, 0, nullptr, nullptr, 0, N / 4};
+    if (!(g_igemm_dma == 1 && Cin_p % 32 == 0)) return MTE_ERR_UNSUPPORTED;
+    return dispatch_igemm<bf16_t>(a, 0, stream);
 }
 
 // The same convolution over the ACTIVE SITES of a sparse map only (SAN branch): x / y are the dense zero-filled NHWC maps, `sites` the

@@ -1474,6 +1474,36 @@ def _refold_all():
     _fold_hooks[:] = live
 
 
+_unshuffle_ok = {}           # (B, H2, W2, cout_p, 4C, k) -> the library took mte_conv2d_igemm_unshuffle for this shape
+
+
+def _dgrad_unshuffled(dy, Wf, pack, dx, k):
+    """data gradient of a folded pack convolution written straight into the UN-shuffled dx [B,C,H,W] (mte_conv2d_igemm_unshuffle: no packed gradient tensor, no
+    pixel-shuffle pass).  -> False where the library does not take that form for the shape (decided by the first call per shape; the caller then runs the
+    two-launch path, bit-identical).  Layers with 4C > 256 keep the 8-phase implicit GEMM + shuffle: there the older tile form would cost more than the pass saves."""
+    B, C, H, W = dx.shape
+    cp = dy.shape[1]
+    if dy.dtype != torch.bfloat16 or 4 * C > 256 or os.environ.get("MTE_NO_UNSHUFFLE") == "1":
+        return False
+    key = (B, H // 2, W // 2, cp, 4 * C, k)
+    ok = _unshuffle_ok.get(key)
+    if ok is False:
+        return False
+    _, wb = pack.get(Wf, dy.dtype, True)
+    dyp, lddy = _pl(dy)
+    dxp, lddx = _pl(dx)
+    args = (dyp, lddy, wb.data_ptr(), dxp, lddx, B, H // 2, W // 2, cp, 4 * C, k, k, _dt(dy), 0, _stream())
+    if ok is None:                                           # first call for this shape: the raw entry point, to see MTE_ERR_UNSUPPORTED instead of an exception
+        from . import _lib as _L
+        rc = _L.lib.load().mte_conv2d_igemm_unshuffle(*args)
+        if rc not in (0, -3):                                # (-3 = MTE_ERR_UNSUPPORTED, include/mte_kernels.h)
+            raise MteError("mte_conv2d_igemm_unshuffle failed: %s" % rc)
+        _unshuffle_ok[key] = rc == 0
+        return rc == 0
+    lib.mte_conv2d_igemm_unshuffle(*args)
+    return True
+
+
 class PackFoldedConvGnEluFn(torch.autograd.Function):
     """PackLayerConv3d as ONE (k+2)x(k+2) convolution over the packed tensor: conv3d(1->4) is folded into the k x k conv
     weights (csrc/pack_fold.hip), halving the MACs of pack1 and removing the 16C-channel intermediate.  The k/2-pixel
@@ -1595,11 +1625,12 @@ class PackFoldedConvGnEluFn(torch.autograd.Function):
                 g3, gb3, gw, gb = weight_grads()
         else:
             g3, gb3, gw, gb = weight_grads()
-        dP, _, _ = conv_backward(P, dy, Wf, pack_fold, True, need_dw=False)
         dx = new_act(B, C, H, W, P.dtype, dev)
-        sp, lds_ = _pl(dP)
-        dp_, ldd = _pl(dx)
-        lib.mte_pixel_shuffle(sp, lds_, dp_, ldd, B, H, W, C, 1, dt, _stream())
+        if not _dgrad_unshuffled(dy, Wf, pack_fold, dx, k + 2):
+            dP, _, _ = conv_backward(P, dy, Wf, pack_fold, True, need_dw=False)
+            sp, lds_ = _pl(dP)
+            dp_, ldd = _pl(dx)
+            lib.mte_pixel_shuffle(sp, lds_, dp_, ldd, B, H, W, C, 1, dt, _stream())
         bands.join()
         # (the four bands overlap in the corners: two launches so that no element is read-modified by two operations at once)
         _rects([(dxb[0][:B], 0, 0, dx, 0, 0, 2 * hb, W, 1), (dxb[0][B:], 0, 0, dx, H - 2 * hb, 0, 2 * hb, W, 1)])

@@ -518,3 +518,41 @@ def test_weight_gradient_launch_width_follows_the_schedule_and_not_the_result(ci
     scale = float(ref.abs().max())
     for shared in (True, False):
         assert float((out[shared].double() - ref).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("C,cout,k,B,H2,W2", [(32, 32, 7, 2, 24, 64), (32, 32, 7, 1, 13, 40), (64, 64, 5, 2, 16, 48), (8, 32, 3, 1, 9, 33), (64, 40, 5, 1, 8, 24)])
+def test_unshuffled_data_gradient_equals_igemm_then_pixel_shuffle(C, cout, k, B, H2, W2):
+    """round 6: mte_conv2d_igemm_unshuffle writes the folded pack layer's data gradient straight into the un-shuffled tensor; bit-identical to the two launches it
+    replaces (mte_conv2d_igemm into a packed [B, 4C, H/2, W/2] gradient, then mte_pixel_shuffle), with and without accumulation into the destination"""
+    from mindtheedge_amd import kernels as K
+    K.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(C + cout + k)
+    coutp = K.round8(cout)
+    dy = K.image_to_act((torch.rand(B, coutp, H2, W2, generator=g) * 2 - 1).cuda())
+    Wf = ((torch.rand(cout, 4 * C, k, k, generator=g) - 0.5) * 0.2).cuda()
+    pack = K.WeightPack()
+    _, wb = pack.get(Wf, dy.dtype, True)
+    dyp, lddy = K._pl(dy)
+    for accumulate in (0, 1):
+        base = K.image_to_act((torch.rand(B, C, 2 * H2, 2 * W2, generator=g) * 2 - 1).cuda())
+        # reference: packed gradient, then the shuffle (accumulating: shuffle into a scratch tensor and add in fp32 with one rounding, as the epilogue does)
+        dP = K.new_act(B, 4 * C, H2, W2)
+        pp, ldp = K._pl(dP)
+        K.lib.mte_conv2d_igemm(dyp, lddy, wb.data_ptr(), 0, pp, ldp, 0, B, H2, W2, coutp, 4 * C, k, k, K._dt(dy), 0, 0, 0, K._stream())
+        ref = K.new_act(B, C, 2 * H2, 2 * W2)
+        rp, ldr = K._pl(ref)
+        K.lib.mte_pixel_shuffle(pp, ldp, rp, ldr, B, 2 * H2, 2 * W2, C, 1, K._dt(dy), K._stream())
+        want = ref.float()
+        if accumulate:
+            want = (want + base.float()).to(torch.bfloat16).float()
+        got = base.clone() if accumulate else K.new_act(B, C, 2 * H2, 2 * W2).fill_(7.0)
+        got = K.as_act(got, torch.bfloat16)
+        gp, ldg = K._pl(got)
+        from mindtheedge_amd import _lib as L
+        rc = L.lib.load().mte_conv2d_igemm_unshuffle(dyp, lddy, wb.data_ptr(), gp, ldg, B, H2, W2, coutp, 4 * C, k, k, K._dt(dy), accumulate, K._stream())
+        if 4 * C <= 64 or coutp % 32:
+            assert rc == -3, rc                                  # (narrow tiles / no LDS-DMA loader: nothing staged in LDS -- the caller keeps the two-launch path)
+            return
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert torch.equal(got.float()[:, :C].cpu(), want[:, :C].cpu()), accumulate
