@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 3) void unpack3d_bwd_d
 
 // pack backward data (round 6): dx = un-shuffle(conv3d^T(dO)), C % 32 == 0, the same banded-operand GEMM.  The fp32-VALU stencil above (pack3d_bwd_data_lds_kernel)
 // was the largest non-convolution, non-GroupNorm kernel of the main queue: 0.48 ms per step alone, 0.70 ms beside the weight-gradient queue, at 1.8 TB/s
-// (profiles/r06_v5_pmc_traffic_T8.txt: 800 MB read, 85 MB written) -- arithmetic-bound at 48 v_pk_fma_f32 + ~50 unpacking instructions per 32 outputs, tap and plane.
+// (profiles/r06_v6_pmc_traffic_T8.txt: 800 MB read, 85 MB written) -- arithmetic-bound at 48 v_pk_fma_f32 + ~50 unpacking instructions per 32 outputs, tap and plane.
 //   * work item = (tile of 4 x 16 packed pixels, segment of 128 depths of the D = 4C); a wave owns ONE unit of 32 depths and all four tile rows: the six halo rows
 //     it reads per (plane, kw) feed 4 rows x 3 kh x 2 blocks x (hi, lo) = 48 MFMAs -- one ds_read_b128 per 4 MFMAs.  (First version: a wave = one row, four
 //     units -- one read per 2 MFMAs; the same time to the microsecond: 9.6 cycles per output and SIMD against the 4.5 of the MFMAs, the rest is load latency + the
