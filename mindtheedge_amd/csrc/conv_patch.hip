@@ -1207,6 +1207,11 @@ template <int K, int NT> int launch_wgrad(const PatchWgradArgs& a, hipStream_t s
         // pixel rows of the two-slice layout are exactly full, dy is read once instead of once per slice pair (0.40 -> 0.29 ms)
         if (a.Cin_p > 64 && a.Cin_p <= 96 && g_patch_wgrad_8w) return launch_wgrad_sl<K, NT, 3, 8>(a, st, parts_cap, parts_out);
     }
+    if constexpr (K == 3 && NT == 2) {
+        // round 6: the same for 64 outputs (iconv2: the 96-channel concat @192x640) -- 27 (tap, slice) units over 8 waves instead of two slice groups of 18, the
+        // second one half empty: a third fewer MFMA steps (0.191 -> 0.147 ms, profiles/r06_lowres_split.txt; 4-row tiles: with 8 rows the staged next tile pushed it past 256 VGPRs)
+        if (a.Cin_p > 64 && a.Cin_p <= 96 && g_patch_wgrad_8w) return launch_wgrad_sl<K, NT, 3, 8, 1, 4>(a, st, parts_cap, parts_out);
+    }
     if constexpr (K <= 3 || (K == 5 && NT == 1)) {
         if (a.Cin_p > 32) {
             if constexpr (K * K * 2 >= 16 && (NT == 2 || K * K * 2 >= 32)) {
