@@ -774,6 +774,7 @@ int g_igemm_big_min_tiles = 224;
 #define MTE_IGEMM8_DEFAULT 51
 #endif
 int g_igemm8 = MTE_IGEMM8_DEFAULT;                                   // development knob (mte_debug_set(23, v)): bit 0 = 8-phase 256 x 256 kernel, bit 1 = its 256 x 128 form, bit 2 every eligible launch, bit 5 (32) tap-major K order (the default; without it: slice-major where Cin_p % 64 == 0); bits 3 / 4 belonged to the tile-walking form, removed in round 5
+int g_igemm_n32_dma = 1;                              // development knob (mte_debug_set(32, v)): N <= 32 on the two-wave LDS-DMA form
 int g_igemm8_split_bn128 = 64;                        // development knob (mte_debug_set(29, v)): see the split-K rule of the 8-phase kernels
 int g_igemm8_min_tiles = 200;                        // development knob (mte_debug_set(24, v))
 int g_igemm_pp = 1;                                  // development knob (mte_debug_set(21, v)): 0 = the 16-wave one-barrier loop on the 256 x 256 tile
@@ -860,7 +861,16 @@ template <typename T> int dispatch_igemm(const ConvArgs& a, long ws_elems, hipSt
         if (g_igemm_big && dma_ok && !a.out_f32 && a.N > 64 && tiles_big >= g_igemm_big_min_tiles)
             return launch_igemm<T, 4, 2, 2, 2>(a, 0, st);
     }
-    if (a.N <= 32) return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st);       // 128 x 32
+    if (a.N <= 32) {
+        // round 6: two waves of 64 x 32 where the LDS-DMA loader applies (its B stage needs (BN * 4) % threads == 0, which the four-wave 128 x 32 form misses: that
+        // one stages through registers) -- the 32-output band convolutions of the folded pack layers (K = 25 x 512)
+        if constexpr (sizeof(T) == 2) {
+            if (g_igemm_n32_dma && g_igemm_dma == 1 && a.Cin_p % 32 == 0 && !a.out_f32 && ((a.M - 1) * a.ldx + a.Cin_p) * 2 < 0x7ff00000L &&
+                (long)a.N * a.KH * a.KW * a.Cin_p * 2 < 0x7ff00000L)
+                return launch_igemm<T, 2, 1, 2, 1>(a, ws_elems, st);
+        }
+        return launch_igemm<T, 4, 1, 1, 1>(a, ws_elems, st);       // 128 x 32
+    }
     if (a.N <= 64) return launch_igemm<T, 2, 2, 2, 1>(a, ws_elems, st);        // 128 x 64
     return launch_igemm<T, 2, 2, 2, 2>(a, ws_elems, st);                      // 128 x 128
 }
@@ -1745,6 +1755,7 @@ int mte_debug_set(int key, int value) {
     if (key == 23) { g_igemm8 = value; return MTE_OK; }
     if (key == 24) { g_igemm8_min_tiles = value; return MTE_OK; }
     if (key == 29) { g_igemm8_split_bn128 = value; return MTE_OK; }
+    if (key == 32) { g_igemm_n32_dma = value; return MTE_OK; }
     if (key == 14) return mtei_set_gn(3, value);
     if (key == 25) return mtei_set_gn(4, value);
     if (key == 4) { g_wgrad_dma = value; return MTE_OK; }

@@ -550,8 +550,8 @@ def test_unshuffled_data_gradient_equals_igemm_then_pixel_shuffle(C, cout, k, B,
         gp, ldg = K._pl(got)
         from mindtheedge_amd import _lib as L
         rc = L.lib.load().mte_conv2d_igemm_unshuffle(dyp, lddy, wb.data_ptr(), gp, ldg, B, H2, W2, coutp, 4 * C, k, k, K._dt(dy), accumulate, K._stream())
-        if 4 * C <= 64 or coutp % 32:
-            assert rc == -3, rc                                  # (narrow tiles / no LDS-DMA loader: nothing staged in LDS -- the caller keeps the two-launch path)
+        if coutp % 32:
+            assert rc == -3, rc                                  # (no LDS-DMA loader: nothing staged in LDS -- the caller keeps the two-launch path)
             return
         assert rc == 0, rc
         torch.cuda.synchronize()
